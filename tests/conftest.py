@@ -1,0 +1,57 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    """npz fixture -> (cfg, batch, feats, params, ref) in the package's host types."""
+    import gnnrag_amd  # noqa: F401
+    from gnnrag_amd import synth
+    z = np.load(os.path.join(GOLDEN, name))
+    cfg = synth.GraphConfig(
+        name=name, B=int(z["B"]), N=int(z["N"]), E=0, R=int(z["R1"]) - 2, D=int(z["D"]),
+        I=int(z["I"]), L=int(z["L"]), T=int(z["T"]),
+        normalized_gnn=bool(int(z["normalized_gnn"])), pos_emb=bool(int(z["pos_emb"])))
+    F = len(z["heads"])
+    edge_tuple = (z["heads"], z["rels"], z["tails"], z["batch_ids"], np.arange(F, dtype=np.int64),
+                  z["weight_list"].tolist(), z["weight_rel_list"].tolist())
+    batch = synth.Batch(cfg=cfg, local_entity=z["local_entity"], query_entities=z["query_entities"],
+                        seed_dist=z["seed_dist"], edge_tuple=edge_tuple,
+                        num_entity=int(z["num_entity"]), n_real=z["n_real"])
+    feats = {k[5:]: z[k] for k in z.files if k.startswith("feat.")}
+    params = {k[6:]: z[k] for k in z.files if k.startswith("param.")}
+    ref = {k[4:]: z[k] for k in z.files if k.startswith("ref.")}
+    return cfg, batch, feats, params, ref
+
+
+@pytest.fixture(scope="session")
+def golden_loader():
+    return load_golden

@@ -1,0 +1,91 @@
+"""Pins both CPU oracles against fixtures recorded from the LIVE reference modules
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden
+
+import oracle.rearev_torch_cpu as otorch
+import oracle.rearev_np64 as onp
+
+
+@pytest.mark.parametrize("name", ["layer_d200.npz", "layer_d50.npz"])
+def test_torch_restatement_matches_reference(name):
+    cfg, batch, feats, params, ref = load_golden(name)
+    out = otorch.run_stack(batch, feats, params)
+    for c in range(cfg.T * cfg.L):
+        # same library, same op order: only COO summation order inside sparse.mm can differ
+        np.testing.assert_allclose(out["h"][c], ref["h"][c], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(out["dist"][c], ref["dist"][c], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(out["score"][c], ref["score"][c], rtol=1e-6, atol=2e-6)
+        assert (out["dist"][c].argmax(1) == ref["dist"][c].argmax(1)).all()
+
+
+@pytest.mark.parametrize("name", ["layer_d200.npz", "layer_d50.npz"])
+def test_factored_np64_matches_reference(name):
+    cfg, batch, feats, params, ref = load_golden(name)
+    out = onp.run_stack(batch, feats, params, dtype=np.float64)
+    for c in range(cfg.T * cfg.L):
+        # fp64 factored form vs fp32 reference: fp32 rounding of the reference only
+        np.testing.assert_allclose(out["h"][c], ref["h"][c], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(out["dist"][c], ref["dist"][c], rtol=0, atol=1e-6)
+        valid = ref["score"][c] > -1e10
+        np.testing.assert_allclose(out["score"][c][valid], ref["score"][c][valid], rtol=0, atol=2e-5)
+        assert (out["dist"][c].argmax(1) == ref["dist"][c].argmax(1)).all()
+
+
+def test_masked_slots_and_all_masked_question():
+    """Masked slots get probability exactly 0; a question whose slots are ALL masked (1 real node =
+    the masked seed) softmaxes to exactly uniform 1/N because score-1e11 rounds to -1e11 in fp32."""
+    cfg, batch, feats, params, ref = load_golden("layer_d50.npz")
+    mask = batch.local_entity != batch.num_entity
+    some = mask.any(axis=1)
+    assert (~some).any(), "fixture must contain an all-masked question"
+    out = otorch.run_stack(batch, feats, params)
+    for dist in list(ref["dist"]) + [out["dist"][-1]]:
+        assert (dist[some][~mask[some]] == 0).all()
+        np.testing.assert_array_equal(dist[~some], np.float32(1.0) / np.float32(cfg.N))
+
+
+@pytest.mark.parametrize("norm_rel", [False, True])
+def test_type_layer_oracles_match_reference(norm_rel):
+    z = np.load(os.path.join(GOLDEN, "typelayer.npz"))
+    F = len(z["heads"])
+    et = (z["heads"], z["rels"], z["tails"], z["batch_ids"], np.arange(F), z["weight_list"].tolist(),
+          z["weight_rel_list"].tolist())
+    B, N = int(z["B"]), int(z["N"])
+    W = z["param.type_layer.kb_self_linear.weight"]
+    b = z["param.type_layer.kb_self_linear.bias"]
+    ref = z["ref.h0_norm%d" % int(norm_rel)]
+    import torch
+    got_t = otorch.type_layer(et, B, N, torch.from_numpy(z["feat.rel_features"]), torch.from_numpy(W),
+                              torch.from_numpy(b), norm_rel).numpy()
+    np.testing.assert_allclose(got_t, ref, rtol=0, atol=2e-6)
+    got_n = onp.type_layer(et, B, N, z["feat.rel_features"], W, b, norm_rel)
+    np.testing.assert_allclose(got_n, ref, rtol=0, atol=2e-5)
+
+
+def test_e2e_call_site_fixture_replays_through_oracle():
+    """rearev_e2e.npz holds the tensors crossing the layer boundary inside a real
+    ReaRev.forward (dataset_load -> get_batch -> model).  Replaying the recorded calls
+    through the oracle must reproduce the recorded outputs, including the final pred."""
+    import torch
+    z = np.load(os.path.join(GOLDEN, "rearev_e2e.npz"))
+    B, N = int(z["B"]), int(z["N"])
+    F = len(z["heads"])
+    et = (z["heads"], z["rels"], z["tails"], z["batch_ids"], np.arange(F), z["weight_list"].tolist(),
+          z["weight_rel_list"].tolist())
+    st = otorch.Structure(et, B, N, normalized_gnn=False)
+    params = otorch.to_torch_params({k[6:]: z[k] for k in z.files if k.startswith("param.")})
+    mask = torch.from_numpy((z["local_entity"] != int(z["num_entity"])).astype(np.float32))
+    h = torch.from_numpy(z["h0"])
+    rf, rfi = torch.from_numpy(z["rel_features"]), torch.from_numpy(z["rel_features_inv"])
+    for c, step in enumerate(z["call.step"]):
+        _, dist, h = otorch.layer_forward(st, h, mask, torch.from_numpy(z["call.dist_in"][c]),
+                                          torch.from_numpy(z["call.ins"][c]), params, int(step), rf, rfi, False)
+        np.testing.assert_allclose(dist.numpy(), z["call.dist_out"][c], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(h.numpy(), z["call.h_out"][c], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(dist.numpy(), z["pred_dist"], rtol=0, atol=1e-7)
+    assert (dist.numpy().argmax(1) == z["pred"]).all()
