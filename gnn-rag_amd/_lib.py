@@ -1,0 +1,86 @@
+"""ctypes binding of libgnnrag_hip.so (C ABI declared in include/gnnrag.h).
+
+There is deliberately NO fallback: if the HIP library is missing or an entry point
+is absent, importing/using the product path raises.  (CPU restatements live under
+``oracle/`` and are test infrastructure only.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "lib", "libgnnrag_hip.so")
+
+c_i32p = C.POINTER(C.c_int32)
+c_f32p = C.POINTER(C.c_float)
+
+
+class CsrStruct(C.Structure):
+    """Mirror of ``struct gnnrag_csr`` (include/gnnrag.h)."""
+    _fields_ = [
+        ("B", C.c_int32), ("N", C.c_int32), ("R1", C.c_int32), ("heavy_deg", C.c_int32),
+        ("F", C.c_int64),
+        ("row_ptr", C.c_void_p * 2), ("edge", C.c_void_p * 2), ("perm", C.c_void_p * 2),
+        ("w_gnn", C.c_void_p * 2), ("w_rel", C.c_void_p * 2),
+        ("heavy", C.c_void_p * 2), ("n_heavy", C.c_void_p),
+        ("heavy_cap", C.c_int32), ("reserved_", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/gnnrag.h declares
+_VP = C.c_void_p
+SIGNATURES = {
+    "gnnrag_csr_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int, C.c_int]),
+    "gnnrag_csr_scratch_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "gnnrag_csr_build": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                   _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(CsrStruct), _VP]),
+    "gnnrag_csr_permute_weight": (C.c_int, [C.POINTER(CsrStruct), _VP, C.c_int, _VP, _VP, _VP]),
+    "gnnrag_linear": (C.c_int, [_VP, C.c_int64, C.c_int32, _VP, _VP, _VP, C.c_int64, C.c_int, _VP,
+                                C.c_int32, _VP]),
+    "gnnrag_aggregate": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32, _VP]),
+    "gnnrag_update_score": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_int32,
+                                      C.c_int32, _VP]),
+    "gnnrag_masked_softmax": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, _VP]),
+    "gnnrag_typelayer": (C.c_int, [C.POINTER(CsrStruct), _VP, C.c_int, _VP, C.c_int32, _VP]),
+    "gnnrag_layer_workspace_bytes": (C.c_size_t, [C.c_int32] * 5),
+    "gnnrag_reason_layer": (C.c_int, [C.POINTER(CsrStruct)] + [_VP] * 9 + [C.c_int32] + [_VP] * 8 +
+                            [_VP, C.c_size_t, C.c_int32, C.c_int32, _VP]),
+    "gnnrag_stream_copy": (C.c_int, [_VP, _VP, C.c_int64, _VP]),
+    "gnnrag_abi_version": (C.c_int, []),
+    "gnnrag_error_string": (C.c_char_p, [C.c_int]),
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class GnnragError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the library once; raises if it is not built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GnnragError(
+            "HIP extension %s is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gnnrag_abi_version() != ABI_VERSION:
+        raise GnnragError("ABI mismatch: library %d, binding %d" % (lib.gnnrag_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str = ""):
+    if code != 0:
+        msg = load().gnnrag_error_string(code)
+        raise GnnragError("%s failed (%d): %s" % (what or "gnnrag call", code,
+                                                  msg.decode() if msg else "?"))

@@ -1,0 +1,213 @@
+// Destination-sorted structure of a batch of question subgraphs (both directions).
+//
+// Replaces BaseGNNLayer.build_matrix (reference gnn/modules/kg_reasoning/base_gnn.py:19-51),
+// which materialises 7 uncoalesced COO tensors from Python lists on the host.  Here the batch
+// tuple's int32 arrays are uploaded once and sorted on the device:
+//
+//   key = destination node (tail for the forward direction, head for the inverse one),
+//   value = fact id, stable LSD radix sort over ceil(log2(B*N)) bits  ->  facts of one
+//   destination are contiguous and in ascending fact id (one fixed summation order).
+//
+// The sort itself is rocPRIM's device radix sort (a plain library op); everything around it
+// (record gather, row pointers, heavy-row list) is hand written.  All of it is HBM-bound
+// integer work: coalesced 4/8-byte streams, no atomics except the heavy-row append.
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+
+#include "gnnrag_common.h"
+
+namespace gnnrag {
+
+struct CsrLayout {
+  size_t row_ptr[2], edge[2], perm[2], w_gnn[2], w_rel[2], heavy[2], n_heavy, total;
+  int32_t heavy_cap;
+};
+
+static CsrLayout csr_layout(int64_t F, int32_t B, int32_t N, int has_w_gnn, int has_w_rel) {
+  CsrLayout L;
+  size_t off = 0;
+  const size_t BN = (size_t)B * (size_t)N;
+  const size_t Fp = (size_t)(F > 0 ? F : 1);
+  L.heavy_cap = (int32_t)(Fp / kHeavyDeg + 1);
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off = align_up(off + bytes, 256);
+    return o;
+  };
+  for (int d = 0; d < 2; ++d) L.row_ptr[d] = take((BN + 1) * sizeof(int32_t));
+  for (int d = 0; d < 2; ++d) L.edge[d] = take(Fp * 2 * sizeof(int32_t));
+  for (int d = 0; d < 2; ++d) L.perm[d] = take(Fp * sizeof(int32_t));
+  for (int d = 0; d < 2; ++d) L.w_gnn[d] = has_w_gnn ? take(Fp * sizeof(float)) : 0;
+  for (int d = 0; d < 2; ++d) L.w_rel[d] = has_w_rel ? take(Fp * sizeof(float)) : 0;
+  for (int d = 0; d < 2; ++d) L.heavy[d] = take((size_t)L.heavy_cap * sizeof(int32_t));
+  L.n_heavy = take(2 * sizeof(int32_t));
+  L.total = off;
+  return L;
+}
+
+static unsigned key_bits(size_t BN) {
+  unsigned bits = 1;
+  while (bits < 32 && ((size_t)1 << bits) < BN) ++bits;
+  return bits;
+}
+
+static size_t sort_temp_bytes(int64_t F, unsigned bits) {
+  size_t bytes = 0;
+  const uint32_t* kin = nullptr;
+  uint32_t* kout = nullptr;
+  int32_t* vout = nullptr;
+  rocprim::counting_iterator<int32_t> vin(0);
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, (size_t)F, 0u, bits,
+                                           (hipStream_t)0, false);
+  if (e != hipSuccess || bytes == 0) {
+    (void)hipGetLastError();
+    bytes = (size_t)16 * (size_t)(F > 0 ? F : 1) + ((size_t)1 << 20);  // conservative bound (no device to ask)
+  }
+  return bytes;
+}
+
+// One thread per sorted position: gather the (source, relation) record and the weights of the
+// fact that landed there.  Reads perm coalesced, gathers 3-5 words, writes coalesced.
+__global__ __launch_bounds__(256) void k_csr_fill(const int32_t* __restrict__ perm,
+                                                  const int32_t* __restrict__ src,
+                                                  const int32_t* __restrict__ rels,
+                                                  const float* __restrict__ wg,
+                                                  const float* __restrict__ wr, int64_t F,
+                                                  int2* __restrict__ edge, float* __restrict__ wg_out,
+                                                  float* __restrict__ wr_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F) return;
+  const int32_t f = perm[i];
+  edge[i] = make_int2(src[f], rels[f]);
+  if (wg_out) {
+    const float v = wg[f];
+    wg_out[i] = v * v;  // the weight enters head2fact AND fact2tail (base_gnn.py:44-47)
+  }
+  if (wr_out) wr_out[i] = wr[f];
+}
+
+// row_ptr[n] = first sorted position whose destination is >= n  (binary search, n in [0, BN]).
+__global__ __launch_bounds__(256) void k_csr_row_ptr(const uint32_t* __restrict__ keys, int64_t F,
+                                                     int64_t BN, int32_t* __restrict__ row_ptr) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n > BN) return;
+  int64_t lo = 0, hi = F;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)keys[mid] < n) lo = mid + 1; else hi = mid;
+  }
+  row_ptr[n] = (int32_t)lo;
+}
+
+__global__ __launch_bounds__(256) void k_csr_heavy(const int32_t* __restrict__ row_ptr, int64_t BN,
+                                                   int32_t heavy_deg, int32_t* __restrict__ list,
+                                                   int32_t cap, int32_t* __restrict__ count) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= BN) return;
+  if (row_ptr[n + 1] - row_ptr[n] > heavy_deg) {
+    const int32_t pos = atomicAdd(count, 1);
+    if (pos < cap) list[pos] = (int32_t)n;  // order is irrelevant: each row's own sum order is fixed
+  }
+}
+
+__global__ __launch_bounds__(256) void k_csr_permute_weight(const int32_t* __restrict__ perm,
+                                                            const float* __restrict__ w, int64_t F, int square,
+                                                            float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F) return;
+  const float v = w[perm[i]];
+  out[i] = square ? v * v : v;
+}
+
+}  // namespace gnnrag
+
+using namespace gnnrag;
+
+extern "C" int gnnrag_csr_permute_weight(const gnnrag_csr* csr, const float* w_per_fact, int square,
+                                         float* out_fwd, float* out_inv, gnnrag_stream_t stream) {
+  if (!csr || !out_fwd || !out_inv) return GNNRAG_E_BADARG;
+  if (csr->F == 0) return 0;
+  if (!w_per_fact) return GNNRAG_E_BADARG;
+  const int nb = (int)((csr->F + 255) / 256);
+  float* outs[2] = {out_fwd, out_inv};
+  for (int d = 0; d < 2; ++d) {
+    hipLaunchKernelGGL(k_csr_permute_weight, dim3(nb), dim3(256), 0, (hipStream_t)stream, csr->perm[d],
+                       w_per_fact, csr->F, square, outs[d]);
+    GNNRAG_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" size_t gnnrag_csr_bytes(int64_t F, int32_t B, int32_t N, int has_w_gnn, int has_w_rel) {
+  if (F < 0 || B <= 0 || N <= 0) return 0;
+  return csr_layout(F, B, N, has_w_gnn, has_w_rel).total;
+}
+
+extern "C" size_t gnnrag_csr_scratch_bytes(int64_t F, int32_t B, int32_t N) {
+  if (F < 0 || B <= 0 || N <= 0) return 0;
+  const size_t Fp = (size_t)(F > 0 ? F : 1);
+  const unsigned bits = key_bits((size_t)B * (size_t)N);
+  return align_up(Fp * sizeof(uint32_t), 256) + align_up(sort_temp_bytes(F, bits), 256);
+}
+
+extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const int32_t* tails,
+                                const float* w_gnn, const float* w_rel, int64_t F, int32_t B, int32_t N,
+                                int32_t R1, void* csr_mem, size_t csr_bytes, void* scratch,
+                                size_t scratch_bytes, gnnrag_csr* out, gnnrag_stream_t stream_) {
+  if (!out || !csr_mem || B <= 0 || N <= 0 || R1 <= 0 || F < 0) return GNNRAG_E_BADARG;
+  if (F > 0 && (!heads || !rels || !tails || !scratch)) return GNNRAG_E_BADARG;
+  const int64_t BN = (int64_t)B * N;
+  if (BN >= ((int64_t)1 << 31) || F >= ((int64_t)1 << 31)) return GNNRAG_E_UNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_;
+  const CsrLayout L = csr_layout(F, B, N, w_gnn != nullptr, w_rel != nullptr);
+  if (csr_bytes < L.total) return GNNRAG_E_WORKSPACE;
+  char* base = (char*)csr_mem;
+  memset(out, 0, sizeof(*out));
+  out->B = B; out->N = N; out->R1 = R1; out->F = F;
+  out->heavy_deg = kHeavyDeg;
+  out->heavy_cap = L.heavy_cap;
+  for (int d = 0; d < 2; ++d) {
+    out->row_ptr[d] = (int32_t*)(base + L.row_ptr[d]);
+    out->edge[d] = (int32_t*)(base + L.edge[d]);
+    out->perm[d] = (int32_t*)(base + L.perm[d]);
+    out->w_gnn[d] = w_gnn ? (float*)(base + L.w_gnn[d]) : nullptr;
+    out->w_rel[d] = w_rel ? (float*)(base + L.w_rel[d]) : nullptr;
+    out->heavy[d] = (int32_t*)(base + L.heavy[d]);
+  }
+  out->n_heavy = (int32_t*)(base + L.n_heavy);
+  GNNRAG_HIP(hipMemsetAsync(out->n_heavy, 0, 2 * sizeof(int32_t), stream));
+
+  const unsigned bits = key_bits((size_t)BN);
+  const size_t keys_bytes = align_up((size_t)(F > 0 ? F : 1) * sizeof(uint32_t), 256);
+  size_t temp_bytes = 0;
+  if (F > 0) {
+    temp_bytes = sort_temp_bytes(F, bits);
+    if (scratch_bytes < keys_bytes + temp_bytes) return GNNRAG_E_WORKSPACE;
+  }
+  uint32_t* keys_sorted = (uint32_t*)scratch;
+  void* temp = (char*)scratch + keys_bytes;
+
+  const int nb_rows = (int)((BN + 1 + 255) / 256);
+  for (int d = 0; d < 2; ++d) {
+    const int32_t* dst = d == 0 ? tails : heads;
+    const int32_t* src = d == 0 ? heads : tails;
+    if (F > 0) {
+      rocprim::counting_iterator<int32_t> iota(0);
+      size_t tb = temp_bytes;
+      GNNRAG_HIP(rocprim::radix_sort_pairs(temp, tb, (const uint32_t*)dst, keys_sorted, iota,
+                                           out->perm[d], (size_t)F, 0u, bits, stream, false));
+      const int nb = (int)((F + 255) / 256);
+      hipLaunchKernelGGL(k_csr_fill, dim3(nb), dim3(256), 0, stream, out->perm[d], src, rels, w_gnn,
+                         w_rel, F, (int2*)out->edge[d], out->w_gnn[d], out->w_rel[d]);
+      GNNRAG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_csr_row_ptr, dim3(nb_rows), dim3(256), 0, stream, keys_sorted, F, BN,
+                       out->row_ptr[d]);
+    GNNRAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_csr_heavy, dim3((int)((BN + 255) / 256)), dim3(256), 0, stream,
+                       out->row_ptr[d], BN, (int32_t)kHeavyDeg, out->heavy[d], out->heavy_cap,
+                       out->n_heavy + d);
+    GNNRAG_LAUNCH_CHECK();
+  }
+  return 0;
+}

@@ -1,0 +1,289 @@
+// Exact-fp32 dense projections on the gfx950 matrix cores (v_mfma_f32_16x16x4_f32).
+//
+//   C[M, Nout] = act( A[M, K] . W[Nout, K]^T + bias + add )       (W is an nn.Linear weight)
+//
+// used for
+//   * T_d = rel_linear_step(rel_features_d) (+ pos_emb)            reasongnn.py:75-79 / :102-105
+//   * kb_self_linear(rel_features)                                 layer_init.py:47-49
+//   * h' = relu(e2e_linear_step(cat(h, agg))), fused with
+//     score = score_func(h') + (1 - mask) * -1e11                  reasongnn.py:161-168
+//
+// The reference needs 1e-4 fp32 parity, so bf16/fp8 MFMA are out; gfx950 has no xf32.  The
+// f32-input MFMA is bit-for-bit an fmaf chain and runs at the fp32 vector peak (157 TF), about
+// 2.4x what a VALU GEMM reaches (guide: cdna_hip_programming.md section 3).
+//
+// Tiling (wave64): workgroup = 4 waves = 128 rows x all Nout columns (Nout = D <= 208 for the
+// fused update, so A - the big operand, [B*N, (2I+1)D] - streams from HBM exactly once);
+// wave w owns rows [32w, 32w+32) as 2 x NT accumulator tiles of 16x16 (NT = ceil(Nout/16)).
+// K is consumed in 32-wide tiles staged through LDS (row stride 40 floats: conflict-free for the
+// ds_read_b128 fragment reads below and for the ds_write_b128 staging writes).  A lane reads a
+// float4 = 4 consecutive k of its row; register s of that float4 feeds MFMA sub-step s, so the
+// k index a lane group supplies is 16c + 4*(lane>>4) + s for both operands - a permutation of
+// the k order inside the tile that A and W share, which the sum does not see.  Global loads of
+// tile t+1 are issued before the MFMAs of tile t (register prefetch), two workgroups per CU.
+#include "gnnrag_common.h"
+
+namespace gnnrag {
+
+constexpr int kBM = 128;   // rows per workgroup
+constexpr int kBK = 32;    // k per LDS tile
+constexpr int kLS = 40;    // LDS row stride (floats)
+
+enum { EPI_LINEAR = 0, EPI_UPDATE = 1 };
+
+struct GemmArgs {
+  const float* A0;      // [M, K0]  (plain: K0 = K; update: h, K0 = D)
+  const float* A1;      // [M, K-K0] or nullptr (update: agg)
+  const float* W;       // [Nout, K]
+  const float* bias;    // [Nout] or nullptr
+  const float* add;     // [add_rows, Nout] or nullptr
+  float* C;             // [M, Nout]
+  const float* w_s;     // EPI_UPDATE: score_func.weight [Nout]
+  const float* b_s;     // EPI_UPDATE: score_func.bias [1]
+  const float* mask;    // EPI_UPDATE: [M]
+  float* score;         // EPI_UPDATE: [M]
+  int32_t M, K, K0, Nout, add_rows, relu;
+  int32_t n0;           // first output column of this launch's column block (EPI_LINEAR, Nout > 208)
+};
+
+// 4 consecutive k of logical row m of A (= [A0 | A1]); zero beyond M / K.
+template <bool V4>
+__device__ __forceinline__ f32x4 load_a4(const GemmArgs& g, int m, int k) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (m >= g.M) return v;
+  if constexpr (V4) {
+    // K0, K-K0 multiples of 4 and 16-byte aligned bases: a float4 never straddles the split
+    if (k < g.K0) v = *reinterpret_cast<const f32x4*>(g.A0 + (size_t)m * g.K0 + k);
+    else if (k < g.K) v = *reinterpret_cast<const f32x4*>(g.A1 + (size_t)m * (g.K - g.K0) + (k - g.K0));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kk = k + j;
+      if (kk < g.K0) v[j] = g.A0[(size_t)m * g.K0 + kk];
+      else if (kk < g.K) v[j] = g.A1[(size_t)m * (g.K - g.K0) + (kk - g.K0)];
+    }
+  }
+  return v;
+}
+
+template <bool V4>
+__device__ __forceinline__ f32x4 load_w4(const GemmArgs& g, int j, int k) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (j >= g.Nout) return v;
+  if constexpr (V4) {
+    if (k < g.K) v = *reinterpret_cast<const f32x4*>(g.W + (size_t)j * g.K + k);
+  } else {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+      if (k + jj < g.K) v[jj] = g.W[(size_t)j * g.K + k + jj];
+  }
+  return v;
+}
+
+template <int NT, bool V4, int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs g) {
+  constexpr int WR = (NT * 16 + 31) / 32;  // W staging rounds (32 rows per round)
+  __shared__ __attribute__((aligned(16))) float As[kBM * kLS];
+  __shared__ __attribute__((aligned(16))) float Ws[NT * 16 * kLS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int lr = tid >> 3;   // staging row 0..31
+  const int kq = tid & 7;    // staging float4 within the 32-wide k tile
+  const int m0 = blockIdx.x * kBM;
+  const int n0 = g.n0;
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  f32x4 ra[4], rw[WR];
+  const int nT = (g.K + kBK - 1) / kBK;
+
+  auto gload = [&](int t) {
+    const int k = t * kBK + kq * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ra[r] = load_a4<V4>(g, m0 + lr + 32 * r, k);
+#pragma unroll
+    for (int r = 0; r < WR; ++r) {
+      const int j = lr + 32 * r;
+      rw[r] = (j < NT * 16) ? load_w4<V4>(g, n0 + j, k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(&As[(lr + 32 * r) * kLS + kq * 4]) = ra[r];
+#pragma unroll
+    for (int r = 0; r < WR; ++r) {
+      const int j = lr + 32 * r;
+      if (j < NT * 16) *reinterpret_cast<f32x4*>(&Ws[j * kLS + kq * 4]) = rw[r];
+    }
+  };
+
+  gload(0);
+  sstore();
+  __syncthreads();
+
+  const int fr = lane & 15;  // fragment row (A) / column (W) inside a 16x16 tile
+  const int fg = lane >> 4;  // k group
+  for (int t = 0; t < nT; ++t) {
+    if (t + 1 < nT) gload(t + 1);
+#pragma unroll
+    for (int c = 0; c < kBK / 16; ++c) {
+      f32x4 a[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        a[mt] = *reinterpret_cast<const f32x4*>(&As[(wave * 32 + mt * 16 + fr) * kLS + c * 16 + fg * 4]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&Ws[(nt * 16 + fr) * kLS + c * 16 + fg * 4]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][s], b[s], acc[0][nt], 0, 0, 0);
+          acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][s], b[s], acc[1][nt], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (t + 1 < nT) {
+      sstore();
+      __syncthreads();
+    }
+  }
+
+  // C/D layout of the 16x16 tile: column = lane & 15, row = (lane >> 4) * 4 + reg.
+  float part[2][4];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[mt][r] = 0.f;
+
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = n0 + nt * 16 + fr;
+    const bool cok = col < g.Nout;
+    const float bia = (cok && g.bias) ? g.bias[col] : 0.f;
+    const float ws = (EPI == EPI_UPDATE && cok) ? g.w_s[col] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wave * 32 + mt * 16 + fg * 4 + r;
+        float v = acc[mt][nt][r] + bia;
+        if (EPI == EPI_LINEAR && g.add && cok && row < g.add_rows) v += g.add[(size_t)row * g.Nout + col];
+        if (EPI == EPI_UPDATE || g.relu) v = fmaxf(v, 0.f);
+        if (cok && row < g.M) g.C[(size_t)row * g.Nout + col] = v;
+        if (EPI == EPI_UPDATE) part[mt][r] += v * ws;
+      }
+    }
+  }
+  if constexpr (EPI == EPI_UPDATE) {
+    const float bs = g.b_s[0];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = part[mt][r];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 8, 64);
+        const int row = m0 + wave * 32 + mt * 16 + fg * 4 + r;
+        if (fr == 0 && row < g.M) {
+          // fp32 on purpose: score - 1e11 rounds to exactly -1e11, as in the reference
+          g.score[row] = (s + bs) + (1.0f - g.mask[row]) * kVeryNeg;
+        }
+      }
+  }
+}
+
+// score for Nout > 208 (column blocks): one wave per row, dot(h', w_s)
+__global__ __launch_bounds__(256) void k_score_rows(const float* __restrict__ h, const float* __restrict__ w_s,
+                                                    const float* __restrict__ b_s,
+                                                    const float* __restrict__ mask, float* __restrict__ score,
+                                                    int M, int D) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) s += h[(size_t)row * D + c] * w_s[c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) score[row] = (s + b_s[0]) + (1.0f - mask[row]) * kVeryNeg;
+}
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+template <int EPI>
+static int launch_gemm(GemmArgs g, hipStream_t stream) {
+  if (g.M <= 0) return 0;
+  const bool v4 = (g.K % 4 == 0) && (g.K0 % 4 == 0) && aligned16(g.A0) && aligned16(g.W) &&
+                  (g.A1 == nullptr || aligned16(g.A1));
+  const int nblk = (g.M + kBM - 1) / kBM;
+  const int ncol = g.Nout - g.n0;
+#define GNNRAG_GEMM_CASE(NT)                                                                          \
+  do {                                                                                                \
+    if (v4) hipLaunchKernelGGL((k_gemm_f32<NT, true, EPI>), dim3(nblk), dim3(256), 0, stream, g);     \
+    else hipLaunchKernelGGL((k_gemm_f32<NT, false, EPI>), dim3(nblk), dim3(256), 0, stream, g);       \
+  } while (0)
+  if (ncol <= 64) GNNRAG_GEMM_CASE(4);
+  else if (ncol <= 128) GNNRAG_GEMM_CASE(8);
+  else GNNRAG_GEMM_CASE(13);
+#undef GNNRAG_GEMM_CASE
+  GNNRAG_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace gnnrag
+
+using namespace gnnrag;
+
+extern "C" int gnnrag_linear(const float* A, int64_t M, int32_t K, const float* W, const float* bias,
+                             const float* add, int64_t add_rows, int relu, float* C, int32_t Nout,
+                             gnnrag_stream_t stream) {
+  if (!A || !W || !C || M < 0 || K <= 0 || Nout <= 0) return GNNRAG_E_BADARG;
+  if (M >= ((int64_t)1 << 31)) return GNNRAG_E_UNSUPPORTED;
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A0 = A; g.W = W; g.bias = bias; g.add = add; g.C = C;
+  g.M = (int32_t)M; g.K = K; g.K0 = K; g.Nout = Nout;
+  g.add_rows = add ? (int32_t)(add_rows < M ? add_rows : M) : 0;
+  g.relu = relu;
+  for (int n0 = 0; n0 < Nout; n0 += 208) {
+    g.n0 = n0;
+    const int rc = launch_gemm<EPI_LINEAR>(g, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int gnnrag_update_score(const float* h, const float* agg, const float* W, const float* b,
+                                   const float* w_s, const float* b_s, const float* mask, float* h_out,
+                                   float* score, int64_t BN, int32_t D, int32_t I, gnnrag_stream_t stream) {
+  if (!h || !agg || !W || !b || !w_s || !b_s || !mask || !h_out || !score || BN < 0 || D <= 0 || I <= 0)
+    return GNNRAG_E_BADARG;
+  if (BN >= ((int64_t)1 << 31)) return GNNRAG_E_UNSUPPORTED;
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A0 = h; g.A1 = agg; g.W = W; g.bias = b; g.C = h_out;
+  g.w_s = w_s; g.b_s = b_s; g.mask = mask; g.score = score;
+  g.M = (int32_t)BN; g.K = (2 * I + 1) * D; g.K0 = D; g.Nout = D;
+  g.relu = 1;
+  if (D <= 208) {
+    g.n0 = 0;
+    return launch_gemm<EPI_UPDATE>(g, (hipStream_t)stream);
+  }
+  // wide hidden sizes: column blocks of 208 with plain bias+ReLU epilogue, then a row-dot for the score
+  for (int n0 = 0; n0 < D; n0 += 208) {
+    g.n0 = n0;
+    const int rc = launch_gemm<EPI_LINEAR>(g, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_score_rows, dim3((int)((BN + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h_out, w_s,
+                     b_s, mask, score, (int)BN, D);
+  GNNRAG_LAUNCH_CHECK();
+  return 0;
+}

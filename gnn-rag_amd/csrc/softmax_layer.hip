@@ -1,0 +1,135 @@
+// Per-question masked softmax, the one-call layer driver and small utilities.
+#include "gnnrag_common.h"
+
+namespace gnnrag {
+
+// dist[g,:] = softmax(score[g,:])  (reasongnn.py:169).  One 1024-thread workgroup per question:
+// the N scores (<= 80 KB at N = 20k) are read three times, the 2nd/3rd time from L1/L2.
+// Masked slots hold exactly -1e11 (fp32), so exp(-1e11 - max) == 0 exactly; a question whose
+// slots are all masked gets exactly 1/N everywhere, like the reference.
+__global__ __launch_bounds__(1024) void k_masked_softmax(const float* __restrict__ score,
+                                                         float* __restrict__ dist, int N) {
+  __shared__ float red[16];
+  __shared__ float bcast;
+  const float* s = score + (size_t)blockIdx.x * N;
+  float* o = dist + (size_t)blockIdx.x * N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < N; i += 1024) m = fmaxf(m, s[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float mm = red[0];
+    for (int w = 1; w < 16; ++w) mm = fmaxf(mm, red[w]);
+    bcast = mm;
+  }
+  __syncthreads();
+  m = bcast;
+  __syncthreads();
+
+  float sum = 0.f;
+  for (int i = threadIdx.x; i < N; i += 1024) sum += expf(s[i] - m);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    bcast = t;
+  }
+  __syncthreads();
+  const float total = bcast;
+  for (int i = threadIdx.x; i < N; i += 1024) o[i] = expf(s[i] - m) / total;
+}
+
+__global__ __launch_bounds__(256) void k_stream_copy(const f32x4* __restrict__ src, f32x4* __restrict__ dst,
+                                                     int64_t n4) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; i < n4; i += stride) dst[i] = src[i];
+}
+
+struct LayerWs { size_t T_fwd, T_inv, agg, total; };
+static LayerWs layer_ws(int32_t B, int32_t N, int32_t R1, int32_t D, int32_t I) {
+  LayerWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  w.T_fwd = take((size_t)R1 * D * sizeof(float));
+  w.T_inv = take((size_t)R1 * D * sizeof(float));
+  w.agg = take((size_t)B * N * 2 * I * D * sizeof(float));
+  w.total = off;
+  return w;
+}
+
+}  // namespace gnnrag
+
+using namespace gnnrag;
+
+extern "C" int gnnrag_masked_softmax(const float* score, float* dist, int32_t B, int32_t N,
+                                     gnnrag_stream_t stream) {
+  if (!score || !dist || B <= 0 || N <= 0) return GNNRAG_E_BADARG;
+  hipLaunchKernelGGL(k_masked_softmax, dim3(B), dim3(1024), 0, (hipStream_t)stream, score, dist, N);
+  GNNRAG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gnnrag_stream_copy(const float* src, float* dst, int64_t n, gnnrag_stream_t stream) {
+  if (!src || !dst || n < 0 || (n & 3)) return GNNRAG_E_BADARG;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_stream_copy, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src,
+                     (f32x4*)dst, n / 4);
+  GNNRAG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t gnnrag_layer_workspace_bytes(int32_t B, int32_t N, int32_t R1, int32_t D, int32_t I) {
+  if (B <= 0 || N <= 0 || R1 <= 0 || D <= 0 || I <= 0) return 0;
+  return layer_ws(B, N, R1, D, I).total;
+}
+
+extern "C" int gnnrag_reason_layer(const gnnrag_csr* csr, const float* h, const float* dist, const float* ins,
+                                   const float* relfeat_fwd, const float* relfeat_inv, const float* W_rel,
+                                   const float* b_rel, const float* pos_fwd, const float* pos_inv,
+                                   int32_t pos_rows, const float* W_e2e, const float* b_e2e,
+                                   const float* w_score, const float* b_score, const float* mask,
+                                   float* h_out, float* score_out, float* dist_out, void* workspace,
+                                   size_t workspace_bytes, int32_t D, int32_t I, gnnrag_stream_t stream) {
+  if (!csr || !h || !dist || !ins || !relfeat_fwd || !relfeat_inv || !W_rel || !b_rel || !W_e2e || !b_e2e ||
+      !w_score || !b_score || !mask || !h_out || !score_out || !dist_out || !workspace)
+    return GNNRAG_E_BADARG;
+  const LayerWs w = layer_ws(csr->B, csr->N, csr->R1, D, I);
+  if (workspace_bytes < w.total) return GNNRAG_E_WORKSPACE;
+  char* base = (char*)workspace;
+  float* T_fwd = (float*)(base + w.T_fwd);
+  float* T_inv = (float*)(base + w.T_inv);
+  float* agg = (float*)(base + w.agg);
+  int rc;
+  // T_d = rel_linear(rel_features_d) (+ pos_emb_d): once per relation row, not once per fact
+  rc = gnnrag_linear(relfeat_fwd, csr->R1, D, W_rel, b_rel, pos_fwd, pos_fwd ? pos_rows : 0, 0, T_fwd, D, stream);
+  if (rc) return rc;
+  rc = gnnrag_linear(relfeat_inv, csr->R1, D, W_rel, b_rel, pos_inv, pos_inv ? pos_rows : 0, 0, T_inv, D, stream);
+  if (rc) return rc;
+  rc = gnnrag_aggregate(csr, dist, ins, T_fwd, T_inv, agg, D, I, stream);
+  if (rc) return rc;
+  rc = gnnrag_update_score(h, agg, W_e2e, b_e2e, w_score, b_score, mask, h_out, score_out,
+                           (int64_t)csr->B * csr->N, D, I, stream);
+  if (rc) return rc;
+  return gnnrag_masked_softmax(score_out, dist_out, csr->B, csr->N, stream);
+}
+
+extern "C" int gnnrag_abi_version(void) { return GNNRAG_ABI_VERSION; }
+
+extern "C" const char* gnnrag_error_string(int code) {
+  switch (code) {
+    case 0: return "success";
+    case GNNRAG_E_BADARG: return "gnnrag: bad argument (null pointer, negative or inconsistent size)";
+    case GNNRAG_E_UNSUPPORTED: return "gnnrag: shape outside the compiled kernel set";
+    case GNNRAG_E_WORKSPACE: return "gnnrag: caller-provided buffer too small";
+  }
+  if (code > 0) return hipGetErrorString((hipError_t)code);
+  return "gnnrag: unknown error";
+}

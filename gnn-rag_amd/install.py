@@ -1,0 +1,64 @@
+"""Makes the reference's own entry points (``main.py``, ``train_model.py``,
+``evaluate.py``, ``models/ReaRev/rearev.py``) use the MI355X modules without editing
+a single reference file.
+
+Two ways:
+
+1. ``install()`` BEFORE the reference imports its model code: registers this package's
+   modules under the names the reference imports
+   (``modules.kg_reasoning.reasongnn``, ``modules.kg_reasoning.base_gnn``,
+   ``modules.layer_init``), so ``from modules.kg_reasoning.reasongnn import
+   ReasonGNNLayer`` (rearev.py:8) resolves to the HIP-backed class.
+2. ``swap(model)`` AFTER construction: replaces ``model.reasoning`` / ``model.type_layer``
+   of an existing ReaRev instance, carrying the parameters over.
+"""
+from __future__ import annotations
+
+import importlib
+import sys
+
+_TARGETS = {
+    "modules.kg_reasoning.reasongnn": "gnnrag_amd.modules.kg_reasoning.reasongnn",
+    "modules.kg_reasoning.base_gnn": "gnnrag_amd.modules.kg_reasoning.base_gnn",
+    "modules.layer_init": "gnnrag_amd.modules.layer_init",
+}
+
+
+def install() -> None:
+    already = [n for n in _TARGETS if n in sys.modules and
+               not getattr(sys.modules[n], "__name__", "").startswith("gnnrag_amd")]
+    if already:
+        raise RuntimeError("install() must run before the reference imports %s "
+                           "(use swap(model) on an existing model instead)" % already)
+    for ref_name, our_name in _TARGETS.items():
+        sys.modules[ref_name] = importlib.import_module(our_name)
+
+
+def uninstall() -> None:
+    for ref_name in _TARGETS:
+        m = sys.modules.get(ref_name)
+        if m is not None and m.__name__.startswith("gnnrag_amd"):
+            del sys.modules[ref_name]
+
+
+def swap(model, args: dict):
+    """Replaces the reasoning layer (and TypeLayer, if present) of a constructed ReaRev."""
+    from .modules.kg_reasoning.reasongnn import ReasonGNNLayer
+    from .modules.layer_init import TypeLayer
+    old = model.reasoning
+    # old.num_relation is overwritten by init_reason (reasongnn.py:55); the constructor value,
+    # which sizes pos_emb, is kept by BaseModel (base_model.py:21)
+    num_relation = getattr(model, "num_relation", old.num_relation)
+    new = ReasonGNNLayer(args, old.num_entity, num_relation, old.entity_dim, old.alg)
+    new.load_state_dict(old.state_dict(), strict=True)
+    new.to(next(old.parameters()).device)
+    new.train(old.training)
+    model.reasoning = new
+    if getattr(model, "type_layer", None) is not None:
+        tl_old = model.type_layer
+        tl = TypeLayer(tl_old.in_features, tl_old.out_features, tl_old.linear_drop, tl_old.device,
+                       tl_old.norm_rel)
+        tl.load_state_dict(tl_old.state_dict(), strict=True)
+        tl.to(next(tl_old.parameters()).device)
+        model.type_layer = tl
+    return model

@@ -1,0 +1,62 @@
+"""Drop-in for the reference's ``modules/kg_reasoning/base_gnn.py``.
+
+``BaseGNNLayer.build_matrix`` (reference ``base_gnn.py:19-51``) turns the batch tuple
+into seven COO tensors through Python lists.  Here it uploads the three int arrays once
+and builds a destination-sorted structure on the GPU (``ops.CsrPlan`` ->
+``gnnrag_csr_build``).  Same class name, constructor and attributes the callers read.
+"""
+from __future__ import annotations
+
+import torch
+
+from ... import ops
+from ..._lib import GnnragError
+
+VERY_NEG_NUMBER = -100000000000
+
+# ReaRev hands the SAME kb_adj_mat tuple object to TypeLayer and to the reasoning layer
+# (rearev.py:81-83,147-153); keep the last plan so the batch is sorted once, not twice.
+_last_plan = {"key": None, "plan": None, "tuple": None}
+
+
+def plan_for(edge_list, B: int, N: int, R1: int, device) -> "ops.CsrPlan":
+    key = (id(edge_list), B, N, R1, str(device))
+    if _last_plan["key"] == key and _last_plan["tuple"] is edge_list:
+        return _last_plan["plan"]
+    heads, rels, tails = edge_list[0], edge_list[1], edge_list[2]
+    plan = ops.CsrPlan(heads, rels, tails, B, N, R1, device)
+    _last_plan.update(key=key, plan=plan, tuple=edge_list)
+    return plan
+
+
+def _device_from_args(args) -> torch.device:
+    if not args.get("use_cuda", False):
+        raise GnnragError("gnnrag_amd runs on the GPU only (args['use_cuda'] is False); "
+                          "use the reference modules for a CPU run")
+    if not torch.cuda.is_available():
+        raise GnnragError("no ROCm device visible to torch; gnnrag_amd has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class BaseGNNLayer(torch.nn.Module):
+    """Builds the sparse structure of a batch (reference: base_gnn.py:9-54)."""
+
+    def __init__(self, args, num_entity, num_relation):
+        super().__init__()
+        self.num_relation = num_relation
+        self.num_entity = num_entity
+        self._args_use_cuda = bool(args.get("use_cuda", False))
+        self.device = torch.device("cuda" if self._args_use_cuda else "cpu")
+        self.normalized_gnn = args["normalized_gnn"]
+        self._args = dict(use_cuda=self._args_use_cuda)
+
+    def build_matrix(self):
+        """Same inputs as the reference method (``self.edge_list``, ``self.batch_size``,
+        ``self.max_local_entity``, ``self.num_relation`` = rows of the relation tables,
+        set by ``init_reason``); result is ``self.plan``."""
+        device = _device_from_args(self._args)
+        edge_list = self.edge_list
+        self.num_fact = len(edge_list[4])
+        self.plan = plan_for(edge_list, self.batch_size, self.max_local_entity, self.num_relation, device)
+        if self.normalized_gnn:
+            self.plan.attach_w_gnn(edge_list[5])

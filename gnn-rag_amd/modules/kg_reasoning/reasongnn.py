@@ -1,0 +1,99 @@
+"""Drop-in for the reference's ``modules/kg_reasoning/reasongnn.py``.
+
+Same class name, constructor, registered parameters (so released checkpoints load:
+``rel_linear{i}``, ``e2e_linear{i}``, ``score_func``, ``pos_emb{i}``/``pos_emb_inv{i}``,
+and the unused-but-present ``glob_lin``, ``lin``, ``lin_m`` - reference
+``reasongnn.py:26-44``), same ``init_reason`` / ``forward`` signatures, return values and
+side effects (``local_entity_emb``, ``local_entity_mask``, ``possible_cand``).  The body of
+``forward`` is one call into libgnnrag_hip.so (``gnnrag_reason_layer``).
+
+Inference only: the HIP operator has no backward yet, so calling
+it with autograd enabled raises instead of silently computing without a graph.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ..._lib import GnnragError
+from .base_gnn import BaseGNNLayer
+
+VERY_NEG_NUMBER = -100000000000
+
+
+class ReasonGNNLayer(BaseGNNLayer):
+    """GNN reasoning layer of ReaRev on MI355X (reference: reasongnn.py:10-174)."""
+
+    def __init__(self, args, num_entity, num_relation, entity_dim, alg):
+        super().__init__(args, num_entity, num_relation)
+        self.num_entity = num_entity
+        self.num_relation = num_relation
+        self.entity_dim = entity_dim
+        self.alg = alg
+        self.num_ins = args["num_ins"]
+        self.num_gnn = args["num_gnn"]
+        self.use_posemb = args["pos_emb"]
+        self.init_layers(args)
+        self._ws = ops.LayerWorkspace()
+
+    def init_layers(self, args):
+        D = self.entity_dim
+        if self.alg != "bfs":
+            raise ValueError("ReasonGNNLayer supports alg='bfs' only (as the reference, reasongnn.py:33)")
+        self.softmax_d1 = nn.Softmax(dim=1)
+        self.score_func = nn.Linear(in_features=D, out_features=1)
+        self.glob_lin = nn.Linear(in_features=D, out_features=D)          # unused, kept for state_dict parity
+        self.lin = nn.Linear(in_features=2 * D, out_features=D)           # unused, kept for state_dict parity
+        self.linear_dropout = args["linear_dropout"]
+        self.linear_drop = nn.Dropout(p=self.linear_dropout)
+        for i in range(self.num_gnn):
+            self.add_module("rel_linear" + str(i), nn.Linear(in_features=D, out_features=D))
+            self.add_module("e2e_linear" + str(i),
+                            nn.Linear(in_features=2 * self.num_ins * D + D, out_features=D))
+            if self.use_posemb:
+                self.add_module("pos_emb" + str(i), nn.Embedding(self.num_relation, D))
+                self.add_module("pos_emb_inv" + str(i), nn.Embedding(self.num_relation, D))
+        self.lin_m = nn.Linear(in_features=self.num_ins * D, out_features=D)  # unused, state_dict parity
+
+    def init_reason(self, local_entity, kb_adj_mat, local_entity_emb, rel_features, rel_features_inv,
+                    query_entities, query_node_emb=None):
+        batch_size, max_local_entity = local_entity.size()
+        self.local_entity_mask = (local_entity != self.num_entity).float()
+        self.batch_size = batch_size
+        self.max_local_entity = max_local_entity
+        self.edge_list = kb_adj_mat
+        self.rel_features = rel_features
+        self.rel_features_inv = rel_features_inv
+        self.local_entity_emb = local_entity_emb
+        self.num_relation = self.rel_features.size(0)
+        self.possible_cand = []
+        self.build_matrix()
+        self.query_entities = query_entities
+
+    def forward(self, current_dist, relational_ins, step=0, return_score=False):
+        """Next distribution and node representations (reference: reasongnn.py:134-174)."""
+        if torch.is_grad_enabled():
+            raise GnnragError(
+                "gnnrag_amd.ReasonGNNLayer is inference-only (no backward kernel yet): call it under "
+                "torch.no_grad(), as Evaluator.evaluate does (evaluate.py:159)")
+        if self.training and self.linear_dropout > 0:
+            raise GnnragError("dropout > 0 in training mode is not supported by the HIP path")
+        rel_linear = getattr(self, "rel_linear" + str(step))
+        e2e_linear = getattr(self, "e2e_linear" + str(step))
+        pos = pos_inv = None
+        if self.use_posemb:
+            pos = getattr(self, "pos_emb" + str(step)).weight
+            pos_inv = getattr(self, "pos_emb_inv" + str(step)).weight
+        B, N, D = self.batch_size, self.max_local_entity, self.entity_dim
+        h_out, score_tp, new_dist = ops.reason_layer(
+            self.plan, self.local_entity_emb.detach().float(), current_dist.detach().float(),
+            relational_ins.detach().float(), self.rel_features.detach(), self.rel_features_inv.detach(),
+            rel_linear.weight, rel_linear.bias, e2e_linear.weight, e2e_linear.bias,
+            self.score_func.weight, self.score_func.bias, self.local_entity_mask,
+            pos=pos, pos_inv=pos_inv, ws=self._ws)
+        self.local_entity_emb = h_out
+        self.possible_cand.append(self.local_entity_mask)
+        if return_score:
+            return score_tp, new_dist
+        return new_dist, self.local_entity_emb

@@ -1,0 +1,286 @@
+"""Tensor-level wrappers over the C ABI: device memory and streams come from
+PyTorch-ROCm (plumbing), every computation is a call into libgnnrag_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.float32, shape=None) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.GnnragError("%s must live on the GPU (got %s); there is no CPU path" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        t = t.contiguous()
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+    return t
+
+
+class CsrPlan:
+    """Device-side destination-sorted structure of one batch (both directions).
+
+    Built from the first three arrays of the reference batch tuple
+    (``kb_adj_mat`` = heads, rels, tails, ..., ``gnn/dataset_load.py:527``).
+    Replaces ``BaseGNNLayer.build_matrix`` (``base_gnn.py:19-51``)."""
+
+    def __init__(self, heads, rels, tails, B: int, N: int, R1: int, device, validate: bool = True):
+        lib = _lib.load()
+        heads = np.asarray(heads)
+        rels = np.asarray(rels)
+        tails = np.asarray(tails)
+        F = int(heads.shape[0])
+        if rels.shape[0] != F or tails.shape[0] != F:
+            raise ValueError("heads/rels/tails differ in length")
+        if B <= 0 or N <= 0 or R1 <= 0:
+            raise ValueError("B, N, R1 must be positive")
+        if B * N >= 2 ** 31 or F >= 2 ** 31:
+            raise ValueError("batch too large for int32 indices")
+        if validate and F:
+            lo = min(int(heads.min()), int(tails.min()), int(rels.min()))
+            if lo < 0 or max(int(heads.max()), int(tails.max())) >= B * N or int(rels.max()) >= R1:
+                raise ValueError("edge tuple out of range: node ids must lie in [0, B*N), relation ids in [0, R1)")
+            # edges never cross questions (heads/tails are offset per sample, dataset_load.py:483)
+            if ((heads // N) != (tails // N)).any():
+                raise ValueError("a fact connects two different questions")
+        self.B, self.N, self.R1, self.F = int(B), int(N), int(R1), F
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.GnnragError("CsrPlan needs a GPU device, got %s" % self.device)
+        hrt = np.empty((3, max(F, 1)), dtype=np.int32)
+        hrt[0, :F], hrt[1, :F], hrt[2, :F] = heads, rels, tails
+        with torch.cuda.device(self.device):
+            self._hrt = torch.from_numpy(hrt).to(self.device, non_blocking=False)   # ONE int32 upload
+            nbytes = lib.gnnrag_csr_bytes(F, B, N, 0, 0)
+            sbytes = lib.gnnrag_csr_scratch_bytes(F, B, N)
+            self._mem = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+            scratch = torch.empty(max(sbytes, 256), dtype=torch.uint8, device=self.device)
+            self.c = _lib.CsrStruct()
+            row = self._hrt
+            _lib.check(lib.gnnrag_csr_build(
+                row[0].data_ptr(), row[1].data_ptr(), row[2].data_ptr(), None, None,
+                F, B, N, R1, self._mem.data_ptr(), self._mem.numel(),
+                scratch.data_ptr(), scratch.numel(), C.byref(self.c), _stream()), "gnnrag_csr_build")
+            # scratch is only read by kernels already enqueued on this stream; the caching
+            # allocator re-issues it to later work on the same stream only, so dropping it is safe
+        self._w = {}
+
+    # -- lazily attached per-fact weights ----------------------------------------------------
+    def _attach(self, key: str, w_per_fact, square: bool):
+        if key in self._w:
+            return
+        lib = _lib.load()
+        w = np.asarray(w_per_fact, dtype=np.float32)
+        if w.shape[0] != self.F:
+            raise ValueError("%s has %d entries for %d facts" % (key, w.shape[0], self.F))
+        with torch.cuda.device(self.device):
+            src = torch.from_numpy(w).to(self.device) if self.F else torch.zeros(1, device=self.device)
+            out = torch.empty((2, max(self.F, 1)), dtype=torch.float32, device=self.device)
+            _lib.check(lib.gnnrag_csr_permute_weight(C.byref(self.c), src.data_ptr(), int(square),
+                                                     out[0].data_ptr(), out[1].data_ptr(), _stream()),
+                       "gnnrag_csr_permute_weight")
+        self._w[key] = out
+        arr = getattr(self.c, key)
+        arr[0], arr[1] = out[0].data_ptr(), out[1].data_ptr()
+
+    def attach_w_gnn(self, weight_list):
+        """``weight_list`` = 1/outdeg(head); used squared when ``normalized_gnn`` (base_gnn.py:38-47)."""
+        self._attach("w_gnn", weight_list, True)
+
+    def attach_w_rel(self, weight_rel_list):
+        """``weight_rel_list`` = 1/count(head, rel); TypeLayer ``norm_rel`` (layer_init.py:39-40)."""
+        self._attach("w_rel", weight_rel_list, False)
+
+    # -- debug / test views --------------------------------------------------------------------
+    def _view(self, addr: int, n: int, dtype):
+        if n == 0:
+            return torch.zeros(0, dtype=dtype)
+        base = self._mem.data_ptr()
+        off = addr - base
+        nbytes = n * torch.empty(0, dtype=dtype).element_size()
+        return self._mem[off: off + nbytes].view(dtype).cpu()
+
+    def to_host(self) -> dict:
+        """Copies the structure back (tests only)."""
+        BN = self.B * self.N
+        out = {}
+        for d in (0, 1):
+            out["row_ptr%d" % d] = self._view(self.c.row_ptr[d], BN + 1, torch.int32).numpy()
+            out["edge%d" % d] = self._view(self.c.edge[d], 2 * self.F, torch.int32).numpy().reshape(-1, 2)
+            out["perm%d" % d] = self._view(self.c.perm[d], self.F, torch.int32).numpy()
+        nh = self._view(self.c.n_heavy, 2, torch.int32).numpy()
+        out["n_heavy"] = nh
+        for d in (0, 1):
+            out["heavy%d" % d] = np.sort(self._view(self.c.heavy[d], int(min(nh[d], self.c.heavy_cap)),
+                                                    torch.int32).numpy())
+        for key, t in self._w.items():
+            out[key] = t.cpu().numpy()
+        return out
+
+
+def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
+           add: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+    """act(A W^T + bias (+ add on the first add.shape[0] rows)) on fp32 MFMA."""
+    lib = _lib.load()
+    A = _chk(A, "A")
+    W = _chk(W, "W")
+    M, K = A.shape
+    Nout = W.shape[0]
+    if W.shape[1] != K:
+        raise ValueError("W is %s, A is %s" % (tuple(W.shape), tuple(A.shape)))
+    bias = None if bias is None else _chk(bias, "bias", shape=(Nout,))
+    add_rows = 0
+    if add is not None:
+        add = _chk(add, "add")
+        if add.shape[1] != Nout:
+            raise ValueError("add must have %d columns" % Nout)
+        add_rows = add.shape[0]
+    out = torch.empty((M, Nout), dtype=torch.float32, device=A.device)
+    with torch.cuda.device(A.device):
+        _lib.check(lib.gnnrag_linear(A.data_ptr(), M, K, W.data_ptr(), _ptr(bias), _ptr(add), add_rows,
+                                     int(relu), out.data_ptr(), Nout, _stream()), "gnnrag_linear")
+    return out
+
+
+def aggregate(plan: CsrPlan, dist: torch.Tensor, ins: torch.Tensor, T_fwd: torch.Tensor,
+              T_inv: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    B, N = plan.B, plan.N
+    ins = _chk(ins, "ins")
+    _, I, D = ins.shape
+    dist = _chk(dist, "dist").reshape(-1)
+    if dist.numel() != B * N or ins.shape[0] != B:
+        raise ValueError("dist/ins do not match the plan (B=%d, N=%d)" % (B, N))
+    T_fwd = _chk(T_fwd, "T_fwd", shape=(plan.R1, D))
+    T_inv = _chk(T_inv, "T_inv", shape=(plan.R1, D))
+    agg = torch.empty((B * N, 2 * I * D), dtype=torch.float32, device=dist.device)
+    with torch.cuda.device(dist.device):
+        _lib.check(lib.gnnrag_aggregate(C.byref(plan.c), dist.data_ptr(), ins.data_ptr(), T_fwd.data_ptr(),
+                                        T_inv.data_ptr(), agg.data_ptr(), D, I, _stream()), "gnnrag_aggregate")
+    return agg
+
+
+def update_score(h, agg, W, b, w_s, b_s, mask, I: int):
+    lib = _lib.load()
+    h = _chk(h, "h")
+    BN, D = h.shape
+    agg = _chk(agg, "agg", shape=(BN, 2 * I * D))
+    W = _chk(W, "W", shape=(D, (2 * I + 1) * D))
+    b = _chk(b, "b", shape=(D,))
+    w_s = _chk(w_s, "w_s").reshape(-1)
+    b_s = _chk(b_s, "b_s").reshape(-1)
+    mask = _chk(mask, "mask").reshape(-1)
+    if w_s.numel() != D or b_s.numel() != 1 or mask.numel() != BN:
+        raise ValueError("score_func / mask shapes do not match")
+    h_out = torch.empty_like(h)
+    score = torch.empty(BN, dtype=torch.float32, device=h.device)
+    with torch.cuda.device(h.device):
+        _lib.check(lib.gnnrag_update_score(h.data_ptr(), agg.data_ptr(), W.data_ptr(), b.data_ptr(),
+                                           w_s.data_ptr(), b_s.data_ptr(), mask.data_ptr(), h_out.data_ptr(),
+                                           score.data_ptr(), BN, D, I, _stream()), "gnnrag_update_score")
+    return h_out, score
+
+
+def masked_softmax(score: torch.Tensor, B: int, N: int) -> torch.Tensor:
+    lib = _lib.load()
+    score = _chk(score, "score")
+    if score.numel() != B * N:
+        raise ValueError("score has %d entries, expected %d" % (score.numel(), B * N))
+    dist = torch.empty((B, N), dtype=torch.float32, device=score.device)
+    with torch.cuda.device(score.device):
+        _lib.check(lib.gnnrag_masked_softmax(score.data_ptr(), dist.data_ptr(), B, N, _stream()),
+                   "gnnrag_masked_softmax")
+    return dist
+
+
+def typelayer(plan: CsrPlan, T: torch.Tensor, use_w_rel: bool) -> torch.Tensor:
+    lib = _lib.load()
+    T = _chk(T, "T")
+    D = T.shape[1]
+    if T.shape[0] != plan.R1:
+        raise ValueError("T has %d rows, plan has R1=%d" % (T.shape[0], plan.R1))
+    h0 = torch.empty((plan.B * plan.N, D), dtype=torch.float32, device=T.device)
+    with torch.cuda.device(T.device):
+        _lib.check(lib.gnnrag_typelayer(C.byref(plan.c), T.data_ptr(), int(use_w_rel), h0.data_ptr(), D,
+                                        _stream()), "gnnrag_typelayer")
+    return h0
+
+
+class LayerWorkspace:
+    """Scratch of gnnrag_reason_layer (T_fwd, T_inv, agg), reused across layer calls."""
+
+    def __init__(self):
+        self.key = None
+        self.buf = None
+
+    def get(self, B, N, R1, D, I, device) -> torch.Tensor:
+        key = (B, N, R1, D, I, str(device))
+        if key != self.key:
+            nbytes = _lib.load().gnnrag_layer_workspace_bytes(B, N, R1, D, I)
+            self.buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+            self.key = key
+        return self.buf
+
+
+def reason_layer(plan: CsrPlan, h, dist, ins, relfeat, relfeat_inv, W_rel, b_rel, W_e2e, b_e2e, w_score,
+                 b_score, mask, pos=None, pos_inv=None, ws: Optional[LayerWorkspace] = None):
+    """One ReasonGNNLayer.forward (reasongnn.py:134-174) = ONE call into the library.
+    Returns (h_out [B,N,D], score [B,N], dist_out [B,N])."""
+    lib = _lib.load()
+    B, N, R1 = plan.B, plan.N, plan.R1
+    ins = _chk(ins, "ins")
+    _, I, D = ins.shape
+    h = _chk(h, "h").reshape(B * N, D)
+    dist = _chk(dist, "dist").reshape(-1)
+    mask = _chk(mask, "mask").reshape(-1)
+    relfeat = _chk(relfeat, "rel_features", shape=(R1, D))
+    relfeat_inv = _chk(relfeat_inv, "rel_features_inv", shape=(R1, D))
+    W_rel = _chk(W_rel, "rel_linear.weight", shape=(D, D))
+    b_rel = _chk(b_rel, "rel_linear.bias", shape=(D,))
+    W_e2e = _chk(W_e2e, "e2e_linear.weight", shape=(D, (2 * I + 1) * D))
+    b_e2e = _chk(b_e2e, "e2e_linear.bias", shape=(D,))
+    w_score = _chk(w_score, "score_func.weight").reshape(-1)
+    b_score = _chk(b_score, "score_func.bias").reshape(-1)
+    if dist.numel() != B * N or mask.numel() != B * N or ins.shape[0] != B or w_score.numel() != D:
+        raise ValueError("layer inputs do not match the plan (B=%d, N=%d, D=%d)" % (B, N, D))
+    pos_rows = 0
+    if pos is not None:
+        pos = _chk(pos, "pos_emb.weight")
+        pos_inv = _chk(pos_inv, "pos_emb_inv.weight", shape=tuple(pos.shape))
+        pos_rows = pos.shape[0]
+        if pos.shape[1] != D or pos_rows > R1:
+            raise ValueError("pos_emb must be [<=R1, D]")
+    ws = ws or LayerWorkspace()
+    wbuf = ws.get(B, N, R1, D, I, h.device)
+    h_out = torch.empty((B, N, D), dtype=torch.float32, device=h.device)
+    score = torch.empty((B, N), dtype=torch.float32, device=h.device)
+    dist_out = torch.empty((B, N), dtype=torch.float32, device=h.device)
+    with torch.cuda.device(h.device):
+        _lib.check(lib.gnnrag_reason_layer(
+            C.byref(plan.c), h.data_ptr(), dist.data_ptr(), ins.data_ptr(), relfeat.data_ptr(),
+            relfeat_inv.data_ptr(), W_rel.data_ptr(), b_rel.data_ptr(), _ptr(pos), _ptr(pos_inv), pos_rows,
+            W_e2e.data_ptr(), b_e2e.data_ptr(), w_score.data_ptr(), b_score.data_ptr(), mask.data_ptr(),
+            h_out.data_ptr(), score.data_ptr(), dist_out.data_ptr(), wbuf.data_ptr(), wbuf.numel(), D, I,
+            _stream()), "gnnrag_reason_layer")
+    return h_out, score, dist_out
+
+
+def stream_copy(src: torch.Tensor, dst: torch.Tensor):
+    lib = _lib.load()
+    with torch.cuda.device(src.device):
+        _lib.check(lib.gnnrag_stream_copy(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()),
+                   "gnnrag_stream_copy")

@@ -1,0 +1,147 @@
+/* gnnrag.h - C ABI of libgnnrag_hip.so: the MI355X (gfx950) implementation of the
+ * GNN-RAG / ReaRev reasoning hot path.
+ *
+ * The reference (cmavro/GNN-RAG @ v2) is pure Python: it has NO plugin / operator / FFI
+ * interface for this path.  The seam is the Python class
+ * `ReasonGNNLayer` (gnn/modules/kg_reasoning/reasongnn.py:10-174) plus `TypeLayer`
+ * (gnn/modules/layer_init.py:9-65); the entry points below are what a ctypes binding inside
+ * those classes calls (the binding itself is shown in INTEGRATION.md and shipped as
+ * gnn-rag_amd/modules/).  Each entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *  - plain C: pointers + sizes only, no torch types.  All data pointers are DEVICE pointers
+ *    owned by the caller; the library never allocates, frees or retains them.
+ *  - all work is enqueued on the given hipStream_t (passed as void*); no internal
+ *    synchronisation, no global state, re-entrant per stream.
+ *  - fp32 values, int32 indices, row-major contiguous.
+ *  - return value: 0 = success; > 0 = hipError_t of a failed runtime call / launch;
+ *    < 0 = GNNRAG_E_* argument error.  gnnrag_error_string() renders either.
+ *  - node index = question * N + slot (the reference pre-offsets heads/tails the same
+ *    way, gnn/dataset_load.py:483,492-493); direction 0 = forward (head -> tail),
+ *    direction 1 = inverse (tail -> head).
+ */
+#ifndef GNNRAG_H_
+#define GNNRAG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNNRAG_ABI_VERSION 1
+
+#define GNNRAG_E_BADARG      (-1)  /* null pointer / negative size / inconsistent sizes   */
+#define GNNRAG_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set (see DESIGN)  */
+#define GNNRAG_E_WORKSPACE   (-3)  /* caller-provided buffer too small                    */
+
+typedef void* gnnrag_stream_t; /* hipStream_t */
+
+/* Destination-sorted structure of one batch of question subgraphs, both directions.
+ * Replaces the 7 COO tensors of BaseGNNLayer.build_matrix (base_gnn.py:19-51), of which
+ * ReaRev uses fact2tail/head2fact (forward) and fact2head/tail2fact (inverse).
+ * Facts of one destination are stored in ascending fact id, so every sum has one fixed
+ * order (bit-reproducible, independent of how a batch is sharded over GPUs). */
+typedef struct gnnrag_csr {
+  int32_t B;            /* questions in the batch                                          */
+  int32_t N;            /* max_local_entity: node slots per question                       */
+  int32_t R1;           /* rows of the relation tables (num_kb_relation + 1)               */
+  int32_t heavy_deg;    /* rows with more facts than this are walked by a whole workgroup  */
+  int64_t F;            /* facts (typed edges + self loops) in the batch                   */
+  int32_t* row_ptr[2];  /* [B*N+1]  first fact of each destination node                    */
+  int32_t* edge[2];     /* [F][2]   (source node, relation id) per fact, sorted by dst     */
+  int32_t* perm[2];     /* [F]      sorted position -> fact id of the caller's tuple       */
+  float*   w_gnn[2];    /* [F] v_f^2 (normalized_gnn: weight enters both sparse products,
+                                      base_gnn.py:38-47) or NULL                           */
+  float*   w_rel[2];    /* [F] weight_rel_list (TypeLayer norm_rel, layer_init.py:39-40)
+                                      or NULL                                              */
+  int32_t* heavy[2];    /* [heavy_cap] list of heavy destination nodes                     */
+  int32_t* n_heavy;     /* [2] device counters                                             */
+  int32_t  heavy_cap;
+  int32_t  reserved_;
+} gnnrag_csr;
+
+/* Bytes of caller-owned device memory a gnnrag_csr needs (persistent part / build scratch). */
+size_t gnnrag_csr_bytes(int64_t F, int32_t B, int32_t N, int has_w_gnn, int has_w_rel);
+size_t gnnrag_csr_scratch_bytes(int64_t F, int32_t B, int32_t N);
+
+/* Builds the structure on the device.  heads/rels/tails are the batch tuple's first three
+ * arrays (dataset_load.py:527) narrowed to int32; w_gnn = weight_list (used when
+ * args['normalized_gnn']), w_rel = weight_rel_list (used when norm_rel), either may be NULL.
+ * Replaces BaseGNNLayer.build_matrix (base_gnn.py:19-51) and the two COO builds inside
+ * TypeLayer.forward (layer_init.py:35-36,53-54). */
+int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const int32_t* tails,
+                     const float* w_gnn, const float* w_rel,
+                     int64_t F, int32_t B, int32_t N, int32_t R1,
+                     void* csr_mem, size_t csr_bytes, void* scratch, size_t scratch_bytes,
+                     gnnrag_csr* out, gnnrag_stream_t stream);
+
+/* Permutes a per-fact weight array of the caller's tuple into the structure's sorted order for
+ * both directions: out_d[i] = w[perm_d[i]] (squared if square != 0).  Lets a binding attach
+ * weight_list / weight_rel_list lazily (only when normalized_gnn / norm_rel ask for them). */
+int gnnrag_csr_permute_weight(const gnnrag_csr* csr, const float* w_per_fact, int square,
+                              float* out_fwd, float* out_inv, gnnrag_stream_t stream);
+
+/* C[M,Nout] = act( A[M,K] . W[Nout,K]^T + bias[Nout] + add[row < add_rows, :] ), fp32 MFMA.
+ * Used for  T_d = rel_linear_step(rel_features_d) (+ pos_emb_d(rel)), computed once per
+ * relation row instead of once per fact (reasongnn.py:71,75-79 / :98,102-105), and for
+ * TypeLayer's kb_self_linear(rel_features) (layer_init.py:47-49).
+ * bias/add may be NULL.  relu != 0 applies max(.,0). */
+int gnnrag_linear(const float* A, int64_t M, int32_t K, const float* W, const float* bias,
+                  const float* add, int64_t add_rows, int relu,
+                  float* C, int32_t Nout, gnnrag_stream_t stream);
+
+/* agg[n, 2i+d, :] = sum_{f: dst_d(f)=n} w_f * dist[src_d(f)] * relu(T_d[rel_f,:] * ins[n/N, i, :])
+ * = reason_layer (reasongnn.py:61-89, d=0) and reason_layer_inv (reasongnn.py:91-116, d=1)
+ * for every instruction i, in the concat order of reasongnn.py:150-158.
+ * dist [B*N], ins [B,I,D], T_fwd/T_inv [R1,D], agg [B*N, 2*I*D]. */
+int gnnrag_aggregate(const gnnrag_csr* csr, const float* dist, const float* ins,
+                     const float* T_fwd, const float* T_inv, float* agg,
+                     int32_t D, int32_t I, gnnrag_stream_t stream);
+
+/* h_out = relu(e2e_linear(cat(h, agg)))            (reasongnn.py:161-163)
+ * score = score_func(h_out) + (1 - mask) * -1e11   (reasongnn.py:165-168), mask add in fp32.
+ * h [BN,D], agg [BN,2I*D], W [D,(2I+1)D], b [D], w_s [D], b_s [1] (device), mask [BN]. */
+int gnnrag_update_score(const float* h, const float* agg, const float* W, const float* b,
+                        const float* w_s, const float* b_s, const float* mask,
+                        float* h_out, float* score, int64_t BN, int32_t D, int32_t I,
+                        gnnrag_stream_t stream);
+
+/* dist[g,:] = softmax(score[g,:]) over the N slots of each question (reasongnn.py:169). */
+int gnnrag_masked_softmax(const float* score, float* dist, int32_t B, int32_t N,
+                          gnnrag_stream_t stream);
+
+/* h0[n,:] = relu( sum_{tail_f=n} v_f T[rel_f,:] + sum_{head_f=n} v_f T[rel_f,:] ),
+ * v_f = w_rel if use_w_rel else 1   (TypeLayer.forward, layer_init.py:53-57);
+ * T [R1,D] = kb_self_linear(rel_features) from gnnrag_linear. */
+int gnnrag_typelayer(const gnnrag_csr* csr, const float* T, int use_w_rel, float* h0,
+                     int32_t D, gnnrag_stream_t stream);
+
+/* One whole ReasonGNNLayer.forward (reasongnn.py:134-174) enqueued with a single call:
+ * rel transform (both directions) -> aggregate -> update+score -> softmax.
+ * pos_fwd/pos_inv: pos_emb{step}.weight / pos_emb_inv{step}.weight [pos_rows,D] or NULL.
+ * workspace: gnnrag_layer_workspace_bytes() bytes of device scratch. */
+size_t gnnrag_layer_workspace_bytes(int32_t B, int32_t N, int32_t R1, int32_t D, int32_t I);
+int gnnrag_reason_layer(const gnnrag_csr* csr,
+                        const float* h, const float* dist, const float* ins,
+                        const float* relfeat_fwd, const float* relfeat_inv,
+                        const float* W_rel, const float* b_rel,
+                        const float* pos_fwd, const float* pos_inv, int32_t pos_rows,
+                        const float* W_e2e, const float* b_e2e,
+                        const float* w_score, const float* b_score, const float* mask,
+                        float* h_out, float* score_out, float* dist_out,
+                        void* workspace, size_t workspace_bytes,
+                        int32_t D, int32_t I, gnnrag_stream_t stream);
+
+/* Plain HBM copy kernel (float4 per lane) used by bench.py to measure the achievable
+ * streaming ceiling next to the 8 TB/s spec.  n = number of floats (multiple of 4). */
+int gnnrag_stream_copy(const float* src, float* dst, int64_t n, gnnrag_stream_t stream);
+
+int gnnrag_abi_version(void);
+const char* gnnrag_error_string(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNRAG_H_ */

@@ -1,0 +1,133 @@
+"""CPU-side checks: the C-ABI library builds/loads and exports every symbol the header
+declares, the host mirror keeps the reference's surface, and the product path refuses to
+run without the GPU (no silent fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, load_golden
+
+import gnnrag_amd  # noqa: F401
+from gnnrag_amd import _lib, synth
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from gnnrag_amd import build
+    build.build(verbose=False)          # hipcc cross-compiles gfx950 without a GPU
+    return _lib.load()
+
+
+def _header_functions():
+    src = open(os.path.join(REPO, "include", "gnnrag.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gnnrag_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = _header_functions()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), "missing export: " + n
+        assert n in _lib.SIGNATURES, "binding lacks a signature for " + n
+    assert sorted(_lib.SIGNATURES) == names
+    assert lib.gnnrag_abi_version() == 1
+    assert b"bad argument" in lib.gnnrag_error_string(-1)
+
+
+def test_size_queries_and_struct_layout(lib):
+    assert ctypes.sizeof(_lib.CsrStruct) == 4 * 4 + 8 + 8 * 2 * 6 + 8 + 8
+    n = lib.gnnrag_csr_bytes(768000, 64, 2000, 0, 0)
+    # 2 row_ptr arrays + 2 x (edge 8 B + perm 4 B) per fact, plus small lists
+    assert 2 * 128001 * 4 + 768000 * 24 <= n <= 2 * 128001 * 4 + 768000 * 24 + 64 * 1024
+    assert lib.gnnrag_csr_bytes(768000, 64, 2000, 1, 1) >= n + 4 * 768000 * 4
+    assert lib.gnnrag_csr_bytes(-1, 64, 2000, 0, 0) == 0
+    ws = lib.gnnrag_layer_workspace_bytes(64, 2000, 602, 200, 2)
+    assert ws >= 2 * 602 * 200 * 4 + 128000 * 800 * 4
+
+
+def test_argument_errors_without_gpu(lib):
+    assert lib.gnnrag_masked_softmax(None, None, 1, 1, None) == -1
+    assert lib.gnnrag_linear(None, 1, 1, None, None, None, 0, 0, None, 1, None) == -1
+    assert lib.gnnrag_aggregate(None, None, None, None, None, None, 200, 2, None) == -1
+
+
+def test_module_surface_matches_reference_state_dict():
+    """Parameter names/shapes are those recorded from the reference layer (fixture), so released
+    checkpoints load (SURVEY.md section 5 'Checkpoint')."""
+    from gnnrag_amd.modules.kg_reasoning.reasongnn import ReasonGNNLayer
+    for name in ("layer_d200.npz", "layer_d50.npz"):
+        cfg, batch, feats, params, _ = load_golden(name)
+        args = dict(use_cuda=True, normalized_gnn=cfg.normalized_gnn, num_ins=cfg.I, num_gnn=cfg.L,
+                    pos_emb=cfg.pos_emb, linear_dropout=0.0)
+        layer = ReasonGNNLayer(args, batch.num_entity, cfg.num_kb_relation, cfg.D, "bfs")
+        want = {k: v.shape for k, v in params.items() if not k.startswith("type_layer.")}
+        got = {k: tuple(v.shape) for k, v in layer.state_dict().items()}
+        assert got == want
+        layer.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()
+                               if not k.startswith("type_layer.")}, strict=True)
+        for m in ("init_reason", "forward", "build_matrix", "init_layers"):
+            assert callable(getattr(layer, m))
+
+
+def test_product_refuses_to_run_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from gnnrag_amd import ops, stack
+    cfg = synth.CONFIGS["tiny"]
+    batch = synth.make_batch(cfg)
+    with pytest.raises(_lib.GnnragError):
+        ops.CsrPlan(batch.edge_tuple[0], batch.edge_tuple[1], batch.edge_tuple[2], cfg.B, cfg.N, cfg.R1, "cpu")
+    layer = stack.build_layer(cfg, batch, synth.make_layer_params(cfg), "cpu")
+    with torch.no_grad(), pytest.raises(_lib.GnnragError):
+        layer.init_reason(local_entity=torch.from_numpy(batch.local_entity), kb_adj_mat=batch.edge_tuple,
+                          local_entity_emb=torch.zeros(cfg.B, cfg.N, cfg.D),
+                          rel_features=torch.zeros(cfg.R1, cfg.D), rel_features_inv=torch.zeros(cfg.R1, cfg.D),
+                          query_entities=torch.zeros(cfg.B, cfg.N))
+    with pytest.raises(_lib.GnnragError):
+        ops.linear(torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+def test_no_product_module_imports_the_oracle():
+    pkg = os.path.join(REPO, "gnn-rag_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(root, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, os.path.join(root, f)
+
+
+def test_install_substitutes_reference_module_names():
+    import sys
+    from gnnrag_amd import install
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "modules" or k.startswith("modules.")}
+    try:
+        install.install()
+        from modules.kg_reasoning.reasongnn import ReasonGNNLayer     # noqa: the reference's import line
+        from modules.layer_init import TypeLayer                       # noqa
+        assert ReasonGNNLayer.__module__.startswith("gnnrag_amd.")
+        assert TypeLayer.__module__.startswith("gnnrag_amd.")
+    finally:
+        install.uninstall()
+        sys.modules.update(saved)
+
+
+def test_synth_edge_tuple_semantics():
+    """make_edge_tuple restates _build_fact_mat (dataset_load.py:473-527): offsets, contiguous
+    questions, self loops with rel id num_kb_relation-1, 1/outdeg and 1/count(head,rel)."""
+    from collections import Counter
+    cfg = synth.CONFIGS["tiny50"]
+    batch = synth.make_batch(cfg)
+    h, r, t, b, f, wl, wrl = batch.edge_tuple
+    assert (np.diff(b) >= 0).all() and (h // cfg.N == b).all() and (t // cfg.N == b).all()
+    loops = r == cfg.num_kb_relation - 1
+    assert (h[loops] == t[loops]).all() and loops.sum() == batch.n_real.sum()
+    hc = Counter(h.tolist())
+    hrc = Counter(zip(h.tolist(), r.tolist()))
+    assert wl == [1.0 / hc[x] for x in h.tolist()]
+    assert wrl == [1.0 / hrc[x] for x in zip(h.tolist(), r.tolist())]
+    assert (f == np.arange(len(h))).all()

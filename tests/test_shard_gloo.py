@@ -1,0 +1,84 @@
+"""Multi-process (world_size 2, gloo, CPU) test of the question-sharded layout:
+shard -> per-rank compute -> one all-gather == unsharded result, bit for bit.
+The per-rank compute is the CPU oracle here (no GPU in this container); on GPUs the same
+shard/gather code runs over RCCL (bench.py --gpus N)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, B, q):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gnnrag_amd  # noqa: F401
+        from gnnrag_amd import shard, synth
+        import oracle.rearev_torch_cpu as otorch
+        torch.set_num_threads(1)
+        cfg = synth.GraphConfig(name="s", B=B, N=24, E=60, R=5, D=16, I=2, L=2, T=1, seed=9, n_real_min=3)
+        batch = synth.make_batch(cfg)
+        feats = synth.make_features(cfg)
+        params = synth.make_layer_params(cfg)
+        full = otorch.run_stack(batch, feats, params)["dist"][-1]
+        ref_batch = (batch.local_entity, batch.query_entities, batch.edge_tuple, np.zeros((B, 1)),
+                     batch.seed_dist, None, np.zeros((B, cfg.N)))
+        lo, hi = shard.question_range(B, rank, world)
+        sb = shard.shard_batch(ref_batch, rank, world)
+        sub = synth.Batch(cfg=synth.GraphConfig(**{**cfg.__dict__, "B": hi - lo}), local_entity=sb[0],
+                          query_entities=sb[1], seed_dist=sb[4], edge_tuple=sb[2],
+                          num_entity=batch.num_entity, n_real=batch.n_real[lo:hi])
+        sfe = dict(feats)
+        sfe["h0"] = feats["h0"][lo:hi]
+        sfe["ins"] = feats["ins"][:, lo:hi]
+        local = otorch.run_stack(sub, sfe, params)["dist"][-1]
+        gathered = shard.gather_rows(torch.from_numpy(local), B).numpy()
+        ok = gathered.shape == full.shape and np.array_equal(gathered, full)
+        q.put((rank, bool(ok), float(np.abs(gathered - full).max()) if gathered.shape == full.shape else -1.0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [6, 5])      # even split and ragged split (padding path)
+def test_shard_and_gather_world2(B):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, err in res:
+        assert ok, "rank %d: gathered != unsharded (max err %g)" % (rank, err)
+
+
+def test_question_range_partition():
+    from gnnrag_amd import shard
+    for B in (1, 5, 64, 250):
+        for world in (1, 2, 3, 8):
+            rs = [shard.question_range(B, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == B
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+            sizes = [h - l for l, h in rs]
+            assert max(sizes) - min(sizes) <= 1
