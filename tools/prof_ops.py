@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Runs the hot-path ops of one workload a few times each, op by op, so that rocprofv3
+kernel traces / PMC counters are attributable per kernel.
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out -o name -- python tools/prof_ops.py --workload C2 --reps 5
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import gnnrag_amd  # noqa: E402
+from gnnrag_amd import ops, stack, synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="C2")
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--ops", default="rel,agg,upd,sm,layer")
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    cfg = synth.CONFIGS[a.workload]
+    batch = synth.make_batch(cfg)
+    feats = synth.make_features(cfg)
+    params = synth.make_layer_params(cfg)
+    devin = stack.DeviceInputs(batch, feats, dev)
+    layer = stack.build_layer(cfg, batch, params, dev)
+    stack.init_reason(layer, batch, devin, devin.h0)
+    B, N, D, I = cfg.B, cfg.N, cfg.D, cfg.I
+    which = a.ops.split(",")
+    with torch.no_grad():
+        dist1, _ = layer(devin.seed_dist, devin.ins[0], step=0)          # a dense prior
+        h = devin.h0.reshape(B * N, D)
+        rl, e2e = layer.rel_linear1, layer.e2e_linear1
+        Tf = ops.linear(devin.rel_features, rl.weight, rl.bias)
+        Ti = ops.linear(devin.rel_features_inv, rl.weight, rl.bias)
+        agg = ops.aggregate(layer.plan, dist1, devin.ins[0], Tf, Ti)
+        torch.cuda.synchronize()
+        for _ in range(a.reps):
+            if "rel" in which:
+                ops.linear(devin.rel_features, rl.weight, rl.bias)
+            if "agg" in which:
+                ops.aggregate(layer.plan, dist1, devin.ins[0], Tf, Ti)          # dense prior
+                ops.aggregate(layer.plan, devin.seed_dist, devin.ins[0], Tf, Ti)  # sparse (seed) prior
+            if "upd" in which:
+                h2, sc = ops.update_score(h, agg, e2e.weight, e2e.bias, layer.score_func.weight,
+                                          layer.score_func.bias, layer.local_entity_mask, I)
+                if "sm" in which:
+                    ops.masked_softmax(sc, B, N)
+            if "layer" in which:
+                layer.local_entity_emb = devin.h0
+                layer(dist1, devin.ins[0], step=1)
+        torch.cuda.synchronize()
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
