@@ -23,8 +23,9 @@ class CsrStruct(C.Structure):
         ("F", C.c_int64),
         ("row_ptr", C.c_void_p * 2), ("edge", C.c_void_p * 2), ("perm", C.c_void_p * 2),
         ("w_gnn", C.c_void_p * 2), ("w_rel", C.c_void_p * 2),
-        ("heavy", C.c_void_p * 2), ("n_heavy", C.c_void_p),
-        ("heavy_cap", C.c_int32), ("reserved_", C.c_int32),
+        ("heavy", C.c_void_p * 2), ("chunk_off", C.c_void_p * 2),
+        ("n_heavy", C.c_void_p), ("n_chunks", C.c_void_p),
+        ("heavy_cap", C.c_int32), ("max_chunks", C.c_int32),
     ]
 
 
@@ -38,20 +39,27 @@ SIGNATURES = {
     "gnnrag_csr_permute_weight": (C.c_int, [C.POINTER(CsrStruct), _VP, C.c_int, _VP, _VP, _VP]),
     "gnnrag_linear": (C.c_int, [_VP, C.c_int64, C.c_int32, _VP, _VP, _VP, C.c_int64, C.c_int, _VP,
                                 C.c_int32, _VP]),
-    "gnnrag_aggregate": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32, _VP]),
+    "gnnrag_aggregate_workspace_bytes": (C.c_size_t, [C.POINTER(CsrStruct), C.c_int32, C.c_int32]),
+    "gnnrag_aggregate": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32,
+                                   _VP, C.c_size_t, _VP]),
+    "gnnrag_aggregate_fused": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, C.c_int32, _VP, C.c_size_t, _VP]),
+    "gnnrag_relation_tables": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP]),
+    "gnnrag_update_score_fused": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_int32,
+                                            C.c_int32, _VP]),
     "gnnrag_update_score": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_int32,
                                       C.c_int32, _VP]),
     "gnnrag_masked_softmax": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, _VP]),
-    "gnnrag_typelayer": (C.c_int, [C.POINTER(CsrStruct), _VP, C.c_int, _VP, C.c_int32, _VP]),
-    "gnnrag_layer_workspace_bytes": (C.c_size_t, [C.c_int32] * 5),
+    "gnnrag_typelayer": (C.c_int, [C.POINTER(CsrStruct), _VP, C.c_int, _VP, C.c_int32, _VP, C.c_size_t, _VP]),
+    "gnnrag_layer_workspace_bytes": (C.c_size_t, [C.POINTER(CsrStruct), C.c_int32, C.c_int32]),
     "gnnrag_reason_layer": (C.c_int, [C.POINTER(CsrStruct)] + [_VP] * 9 + [C.c_int32] + [_VP] * 8 +
-                            [_VP, C.c_size_t, C.c_int32, C.c_int32, _VP]),
+                            [_VP, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, _VP]),
     "gnnrag_stream_copy": (C.c_int, [_VP, _VP, C.c_int64, _VP]),
     "gnnrag_abi_version": (C.c_int, []),
     "gnnrag_error_string": (C.c_char_p, [C.c_int]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
+PATH_AUTO, PATH_UNFUSED, PATH_FUSED = 0, 1, 2
 _lib = None
 
 

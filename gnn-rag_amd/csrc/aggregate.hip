@@ -1,32 +1,36 @@
 // Relation-typed neighbour aggregation over the destination-sorted structure.
 //
-//   agg[n, 2i+d, :] = sum_{f : dst_d(f) = n}  w_f * dist[src_d(f)] * relu( T_d[rel_f, :] * ins[n/N, i, :] )
+//   REASON:  agg[n, 2i+d, :] = sum_{f : dst_d(f) = n}  w_f * dist[src_d(f)] * relu( T_d[rel_f, :] * ins[n/N, i, :] )
+//   FUSED :  out[n, :]       = sum_d sum_{f : dst_d(f) = n}  w_f * dist[src_d(f)] * P[d, n/N, rel_f, :]
+//   TYPE  :  h0[n, :]        = relu( sum_d sum_{f : dst_d(f) = n} v_f * T[rel_f, :] )
 //
-// = ReasonGNNLayer.reason_layer / reason_layer_inv of the reference
+// REASON = ReasonGNNLayer.reason_layer / reason_layer_inv of the reference
 // (gnn/modules/kg_reasoning/reasongnn.py:61-89 / :91-116), with rel_linear hoisted from the
-// gathered per-fact rows [F,D] to the relation table [R1,D] (it is row-wise, so this is the
-// same arithmetic per row), and with the two torch.sparse.mm products (prior gather :80/:106,
-// scatter-add :84/:111) replaced by a CSR walk.  No [F,D] temporary ever exists and there are
-// no floating-point atomics: one (sub-)wavefront owns one destination node and accumulates its
-// facts in ascending fact id in registers.
+// gathered per-fact rows [F,D] to the relation table [R1,D] (row-wise op, same arithmetic per row)
+// and the two torch.sparse.mm products (prior gather :80/:106, scatter-add :84/:111) replaced by a
+// CSR walk.  FUSED is the same walk after e2e_linear has been pushed through the (linear) sum:
+// P[d,b,r,:] = sum_i W_e2e[:, block(i,d)] relu(T_d[r,:] * ins[b,i,:]) is a per-question relation
+// table (gemm_f32.hip), so the walk emits the [D] contribution to e2e_linear directly instead of
+// the [2I*D] concat operand.  TYPE = TypeLayer.forward (gnn/modules/layer_init.py:25-62).
+// No [F,D] temporary ever exists and there are no floating-point atomics: every destination node
+// is summed in ascending fact id by one owner, in registers.
 //
 // Mapping to CDNA4 (wave64):
-//  * a group of LPN lanes (16/32/64, chosen from D) owns one node; lane `sub` holds the
-//    VEC-wide column chunks sub, sub+LPN, ... of the D-vector (float4 chunks for D%4==0);
-//  * the group reads LPN (src, rel) records with ONE coalesced 8-byte load per lane, gathers
-//    dist[src] per lane, then broadcasts (p, rel) fact by fact with v_readlane / ds_bpermute;
-//  * facts whose prior is exactly 0 are skipped (they contribute exact zeros) - on the first
-//    layer of every iteration dist is the seed distribution, so only the seeds' facts are live;
-//  * the T_d row gather (D*4 bytes, contiguous) is served from L2: both tables are 2*R1*D*4
-//    bytes (0.96 MB at R1=602, D=200) against 4 MB of L2 per XCD;
-//  * one wave writes the complete [2I*D] output row of its node (3200 B at D=200, I=2), so
-//    HBM sees full 128-byte lines; this write stream is the kernel's compulsory traffic;
-//  * destination nodes with more than kHeavyDeg facts (Freebase hubs) are skipped here and
-//    walked by a 16-wave workgroup that splits the fact range and reduces through LDS in a
-//    fixed order (k_heavy) - deterministic, no atomics.
-//
-// TypeLayer.forward (gnn/modules/layer_init.py:25-62) is the same walk with p = v_f (or 1),
-// no instruction, both directions summed and a final ReLU.
+//  * a group of LPN lanes (16/32/64, from D) owns one node; lane `sub` holds the VEC-wide column
+//    chunks sub, sub+LPN, ... of the D-vector (float4 chunks when D % 4 == 0);
+//  * row pointers, the first 64 (src, rel) records of BOTH directions and their priors dist[src]
+//    are requested before any of them is consumed (one 8-byte coalesced load per lane, streamed
+//    with the non-temporal hint so the CSR does not evict the relation tables from L2);
+//  * facts whose prior is exactly 0 are skipped (they contribute exact zeros): on the first layer
+//    of every iteration dist is the seed distribution and only the seeds' facts are live;
+//  * live facts are consumed U at a time: U table rows (D*4 contiguous bytes each, L2 resident)
+//    are requested back to back, then combined in fact order - the kernel is bound by gather
+//    latency, not by arithmetic, so memory-level parallelism per wave is what matters;
+//  * one wave writes the complete output row of its node (3200 B at D=200, I=2) -> full 128-byte
+//    lines; this write stream is the kernel's compulsory HBM traffic;
+//  * destination nodes with more than kHeavyDeg facts (Freebase hubs) are cut into 256-fact
+//    chunks, one wave per chunk (k_heavy_partial), and reduced in chunk order (k_heavy_reduce):
+//    deterministic, no atomics, scales to hubs with 10^5 facts.
 #include "gnnrag_common.h"
 
 namespace gnnrag {
@@ -45,6 +49,10 @@ __device__ __forceinline__ void vstore(float* p, typename VecT<VEC>::type v) {
   *reinterpret_cast<typename VecT<VEC>::type*>(p) = v;
 }
 template <int VEC>
+__device__ __forceinline__ void vstore_nt(float* p, typename VecT<VEC>::type v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<typename VecT<VEC>::type*>(p));
+}
+template <int VEC>
 __device__ __forceinline__ typename VecT<VEC>::type vzero() {
   typename VecT<VEC>::type z = {};
   return z;
@@ -55,106 +63,123 @@ __device__ __forceinline__ f32x4 vrelu(f32x4 x) {
   return __builtin_elementwise_max(x, (f32x4){0.f, 0.f, 0.f, 0.f});
 }
 
-enum { MODE_REASON = 0, MODE_TYPE = 1 };
+enum { MODE_REASON = 0, MODE_TYPE = 1, MODE_FUSED = 2 };
 
 struct WalkArgs {
   const int32_t* row_ptr[2];
   const int2* edge[2];
-  const float* w[2];       // per-fact weight in sorted order or nullptr
-  const float* T[2];       // relation tables [R1,D]
-  const float* dist;       // [BN] (MODE_REASON)
-  const float* ins;        // [B,I,D] (MODE_REASON)
-  float* out;              // REASON: [BN,2I*D]; TYPE: [BN,D]
+  const float* w[2];          // per-fact weight in sorted order or nullptr
+  const float* T[2];          // REASON/TYPE: [R1,D]; FUSED: P[d] = [B][R1][D]
+  const float* dist;          // [BN] (REASON, FUSED)
+  const float* ins;           // [B,I,D] (REASON)
+  float* out;                 // REASON: [BN,2I*D]; TYPE/FUSED: [BN,D]
   const int32_t* heavy[2];
+  const int32_t* chunk_off[2];
   const int32_t* n_heavy;
-  int32_t heavy_cap;
-  int32_t heavy_deg;
-  int32_t BN, N, D, I, i0;
+  const int32_t* n_chunks;
+  float* partial;             // [2][max_chunks][NI*D] heavy-chunk partial sums
+  int32_t max_chunks, heavy_cap, heavy_deg;
+  int32_t BN, N, D, I, i0, R1, B;
+  int32_t bpg;                // FUSED: workgroups per question for the XCD-aware mapping (0 = off)
+  int32_t dir;                // k_heavy_reduce in read-modify-write modes: direction of this launch
 };
 
-template <int LPN>
-__device__ __forceinline__ float bcast_f(float v, int j) {
-  if constexpr (LPN == 64) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
-  } else {
-    return __shfl(v, j, LPN);
-  }
-}
-template <int LPN>
-__device__ __forceinline__ int bcast_i(int v, int j) {
-  if constexpr (LPN == 64) {
-    return __builtin_amdgcn_readlane(v, j);
-  } else {
-    return __shfl(v, j, LPN);
+template <int MODE, int NI> struct AccN { static constexpr int n = (MODE == MODE_REASON) ? NI : 1; };
+
+// acc[i][m] += pj * f(t): the per-fact message in the three modes
+template <int MODE, int VEC, int CPL, int NI>
+__device__ __forceinline__ void fma_row(float pj, const typename VecT<VEC>::type (&t)[CPL], const bool (&cv)[CPL],
+                                        const typename VecT<VEC>::type (&q)[NI][CPL],
+                                        typename VecT<VEC>::type (&acc)[NI][CPL]) {
+#pragma unroll
+  for (int m = 0; m < CPL; ++m) {
+    if (cv[m]) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        if constexpr (MODE == MODE_REASON) acc[i][m] += pj * vrelu(t[m] * q[i][m]);
+        else acc[i][m] += pj * t[m];
+      }
+    }
   }
 }
 
-// Walks `len` facts starting at sorted position `beg` of one direction for the node owned by this
-// lane group and accumulates into acc.  `maxlen` >= len is uniform over the wavefront (groups of
-// one wave may own rows of different length).
+// One batch of <= LPN facts held one per lane as (p, r): consume the live ones in fact order.
 template <int MODE, int VEC, int LPN, int CPL, int NI>
-__device__ __forceinline__ void walk_row(const int2* __restrict__ edge, const float* __restrict__ w,
-                                         const float* __restrict__ dist, const float* __restrict__ T,
-                                         int D, int beg, int len, int maxlen, int sub,
-                                         const int (&col)[CPL], const bool (&cv)[CPL],
-                                         const typename VecT<VEC>::type (&q)[NI][CPL],
-                                         typename VecT<VEC>::type (&acc)[NI][CPL]) {
+__device__ __forceinline__ void consume_batch(float p, int r, int cnt, const float* __restrict__ T, int D,
+                                              const int (&col)[CPL], const bool (&cv)[CPL],
+                                              const typename VecT<VEC>::type (&q)[NI][CPL],
+                                              typename VecT<VEC>::type (&acc)[NI][CPL]) {
   typedef typename VecT<VEC>::type V;
-  for (int base = 0; base < maxlen; base += LPN) {
-    float p = 0.f;
-    int r = 0;
-    if (base + sub < len) {
-      const int idx = beg + base + sub;
-      const int2 e = edge[idx];
-      r = e.y;
-      if constexpr (MODE == MODE_REASON) {
-        p = dist[e.x];
-        if (w) p *= w[idx];
-      } else {
-        p = w ? w[idx] : 1.f;
+  constexpr int U = (CPL == 1) ? 8 : (CPL == 2) ? 4 : 2;   // table rows in flight per wave
+  if constexpr (LPN == 64) {
+    // one node per wave: (p, rel) of a fact are wave-uniform -> scalar control flow
+    unsigned long long live = __ballot(p != 0.f);
+    while (live) {
+      float pj[U];
+      int rj[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (live) {
+          const int j = __builtin_ctzll(live);
+          live &= live - 1;
+          pj[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), j));
+          rj[u] = __builtin_amdgcn_readlane(r, j);
+        } else {
+          pj[u] = 0.f;          // padding: +0 * f(row rj[0]) leaves the sum unchanged
+          rj[u] = rj[0];
+        }
       }
+      V t[U][CPL];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int m = 0; m < CPL; ++m)
+          t[u][m] = cv[m] ? vload<VEC>(T + (size_t)rj[u] * D + col[m]) : vzero<VEC>();
+#pragma unroll
+      for (int u = 0; u < U; ++u) fma_row<MODE, VEC, CPL, NI>(pj[u], t[u], cv, q, acc);
     }
-    const int cnt = min(LPN, maxlen - base);
-    if constexpr (LPN == 64) {
-      // one node per wave: (p, rel) are wave-uniform -> scalar control flow, skip dead facts
-      unsigned long long live = __ballot(p != 0.f);
-      while (live) {
-        const int j = __builtin_ctzll(live);
-        live &= live - 1;
-        const float pj = bcast_f<64>(p, j);
-        const int rj = bcast_i<64>(r, j);
-        const float* trow = T + (size_t)rj * D;
+  } else {
+    // several nodes per wave (D <= 128): each LPN-lane group broadcasts its own facts
+    for (int j0 = 0; j0 < cnt; j0 += U) {
+      float pj[U];
+      int rj[U];
 #pragma unroll
-        for (int m = 0; m < CPL; ++m) {
-          if (cv[m]) {
-            const V t = vload<VEC>(trow + col[m]);
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-              if constexpr (MODE == MODE_REASON) acc[i][m] += pj * vrelu(t * q[i][m]);
-              else acc[i][m] += pj * t;
-            }
-          }
-        }
+      for (int u = 0; u < U; ++u) {
+        const int j = j0 + u;
+        const bool ok = j < cnt;
+        pj[u] = __shfl(p, ok ? j : 0, LPN);
+        rj[u] = __shfl(r, ok ? j : 0, LPN);
+        if (!ok) pj[u] = 0.f;
       }
+      V t[U][CPL];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int m = 0; m < CPL; ++m)
+          t[u][m] = (cv[m] && pj[u] != 0.f) ? vload<VEC>(T + (size_t)rj[u] * D + col[m]) : vzero<VEC>();
+#pragma unroll
+      for (int u = 0; u < U; ++u) fma_row<MODE, VEC, CPL, NI>(pj[u], t[u], cv, q, acc);
+    }
+  }
+}
+
+// (p, r) of the fact at sorted position beg + off (off < len), else (0, 0)
+template <int MODE>
+__device__ __forceinline__ void load_fact(const int2* __restrict__ edge, const float* __restrict__ w,
+                                          const float* __restrict__ dist, int beg, int off, int len, float& p,
+                                          int& r) {
+  p = 0.f;
+  r = 0;
+  if (off < len) {
+    const int idx = beg + off;
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    const i32x2 e = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(edge) + idx);
+    r = e.y;
+    if constexpr (MODE == MODE_TYPE) {
+      p = w ? __builtin_nontemporal_load(w + idx) : 1.f;
     } else {
-      for (int j = 0; j < cnt; ++j) {
-        const float pj = bcast_f<LPN>(p, j);
-        const int rj = bcast_i<LPN>(r, j);
-        if (pj != 0.f) {
-          const float* trow = T + (size_t)rj * D;
-#pragma unroll
-          for (int m = 0; m < CPL; ++m) {
-            if (cv[m]) {
-              const V t = vload<VEC>(trow + col[m]);
-#pragma unroll
-              for (int i = 0; i < NI; ++i) {
-                if constexpr (MODE == MODE_REASON) acc[i][m] += pj * vrelu(t * q[i][m]);
-                else acc[i][m] += pj * t;
-              }
-            }
-          }
-        }
-      }
+      p = dist[e.x];
+      if (w) p *= __builtin_nontemporal_load(w + idx);
     }
   }
 }
@@ -166,16 +191,45 @@ __device__ __forceinline__ int wave_max_over_groups(int v) {
   return v;
 }
 
+template <int MODE, int VEC, int CPL, int NI>
+__device__ __forceinline__ void load_q(const WalkArgs& a, int b, const int (&col)[CPL], const bool (&cv)[CPL],
+                                       typename VecT<VEC>::type (&q)[NI][CPL]) {
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int m = 0; m < CPL; ++m) {
+      if constexpr (MODE == MODE_REASON)
+        q[i][m] = cv[m] ? vload<VEC>(a.ins + ((size_t)b * a.I + a.i0 + i) * a.D + col[m]) : vzero<VEC>();
+      else
+        q[i][m] = vzero<VEC>();
+    }
+}
+
+__device__ __forceinline__ const float* table_of(const WalkArgs& a, int mode, int d, int b) {
+  return (mode == MODE_FUSED) ? a.T[d] + (size_t)b * a.R1 * a.D : a.T[d];
+}
+
 // ---- light rows: one LPN-lane group per destination node, both directions ------------------
 template <int MODE, int VEC, int LPN, int CPL, int NI>
 __global__ __launch_bounds__(256) void k_walk_light(const WalkArgs a) {
   typedef typename VecT<VEC>::type V;
-  const int gtid = blockIdx.x * 256 + threadIdx.x;
+  constexpr int NA = AccN<MODE, NI>::n;
+  int blk = blockIdx.x;
+  if (a.bpg > 0) {
+    // XCD-aware order (workgroup b runs on XCD b % 8): all workgroups of question g go to XCD
+    // g % 8, so a question's relation table P[:, g] stays in ONE 4 MB L2 while it is walked.
+    const int xcd = blk & 7, slot = blk >> 3;
+    const int g = (slot / a.bpg) * 8 + xcd;
+    if (g >= a.B) return;
+    blk = g * a.bpg + slot % a.bpg;
+  }
+  const int gtid = blk * 256 + threadIdx.x;
   const int sub = threadIdx.x & (LPN - 1);
   int n = gtid / LPN;
   const bool live = n < a.BN;
   if (!live) n = a.BN - 1;  // keep every lane in the shuffles
   const int D = a.D;
+  const int b = n / a.N;
   int col[CPL];
   bool cv[CPL];
 #pragma unroll
@@ -183,74 +237,78 @@ __global__ __launch_bounds__(256) void k_walk_light(const WalkArgs a) {
     col[m] = (sub + m * LPN) * VEC;
     cv[m] = col[m] < D;
   }
-  V q[NI][CPL];
-  if constexpr (MODE == MODE_REASON) {
-    const int b = n / a.N;
+  // structure first: both directions' row bounds, first fact batches and priors are in flight
+  // together before anything is consumed
+  int beg[2], len[2];
+  bool heavy[2];
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-      for (int m = 0; m < CPL; ++m)
-        q[i][m] = cv[m] ? vload<VEC>(a.ins + ((size_t)b * a.I + a.i0 + i) * D + col[m]) : vzero<VEC>();
-  } else {
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-      for (int m = 0; m < CPL; ++m) q[i][m] = vzero<VEC>();
+  for (int d = 0; d < 2; ++d) {
+    beg[d] = a.row_ptr[d][n];
+    len[d] = a.row_ptr[d][n + 1] - beg[d];
+    heavy[d] = len[d] > a.heavy_deg;
+    if (!live || heavy[d]) len[d] = 0;
   }
+  float p0[2];
+  int r0[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) load_fact<MODE>(a.edge[d], a.w[d], a.dist, beg[d], sub, len[d], p0[d], r0[d]);
+  V q[NA][CPL];
+  load_q<MODE, VEC, CPL, NA>(a, b, col, cv, q);
 
-  V acc[NI][CPL];
-  bool any_heavy = false;
+  V acc[NA][CPL];
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
     if (MODE == MODE_REASON || d == 0) {
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
+      for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int m = 0; m < CPL; ++m) acc[i][m] = vzero<VEC>();
     }
-    const int beg = a.row_ptr[d][n];
-    int len = a.row_ptr[d][n + 1] - beg;
-    const bool heavy = len > a.heavy_deg;
-    if (!live || heavy) len = 0;
-    any_heavy |= heavy;
-    const int maxlen = wave_max_over_groups<LPN>(len);
-    walk_row<MODE, VEC, LPN, CPL, NI>(a.edge[d], a.w[d], a.dist, a.T[d], D, beg, len, maxlen, sub, col,
-                                      cv, q, acc);
+    const float* T = table_of(a, MODE, d, b);
+    const int maxlen = wave_max_over_groups<LPN>(len[d]);
+    for (int base = 0; base < maxlen; base += LPN) {
+      float p = p0[d];
+      int r = r0[d];
+      if (base > 0) load_fact<MODE>(a.edge[d], a.w[d], a.dist, beg[d], base + sub, len[d], p, r);
+      consume_batch<MODE, VEC, LPN, CPL, NA>(p, r, min(LPN, maxlen - base), T, D, col, cv, q, acc);
+    }
     if constexpr (MODE == MODE_REASON) {
-      if (live && !heavy) {
+      if (live && !heavy[d]) {
         float* orow = a.out + (size_t)n * (2 * a.I) * D;
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+        for (int i = 0; i < NA; ++i)
 #pragma unroll
           for (int m = 0; m < CPL; ++m)
-            if (cv[m]) vstore<VEC>(orow + (size_t)(2 * (a.i0 + i) + d) * D + col[m], acc[i][m]);
+            if (cv[m]) vstore_nt<VEC>(orow + (size_t)(2 * (a.i0 + i) + d) * D + col[m], acc[i][m]);
       }
     }
   }
-  if constexpr (MODE == MODE_TYPE) {
-    // both directions summed, then ReLU (layer_init.py:57).  A node with a heavy direction is
-    // finished by k_walk_heavy, which re-walks both of its rows.
-    if (live && !any_heavy) {
+  if constexpr (MODE != MODE_REASON) {
+    // both directions summed.  If a direction is heavy its chunks are added by k_heavy_reduce
+    // afterwards (which also applies TYPE's final ReLU); store the light part raw in that case.
+    if (live) {
+      const bool fin = !(heavy[0] || heavy[1]);
 #pragma unroll
       for (int m = 0; m < CPL; ++m)
-        if (cv[m]) vstore<VEC>(a.out + (size_t)n * D + col[m], vrelu(acc[0][m]));
+        if (cv[m]) {
+          V v = acc[0][m];
+          if (MODE == MODE_TYPE && fin) v = vrelu(v);
+          vstore<VEC>(a.out + (size_t)n * D + col[m], v);
+        }
     }
   }
 }
 
-// ---- heavy rows: a 16-wave workgroup per destination node ------------------------------------
-// grid = (blocks, 2 directions).  Each wave walks one contiguous 1/16 slice of the row; partials
-// go through LDS and are summed in wave order (fixed order => deterministic).
+// ---- heavy rows, pass 1: one wave per 256-fact chunk -> partial sums --------------------------
 template <int MODE, int VEC, int CPL, int NI>
-__global__ __launch_bounds__(1024) void k_walk_heavy(const WalkArgs a) {
+__global__ __launch_bounds__(256) void k_heavy_partial(const WalkArgs a) {
   typedef typename VecT<VEC>::type V;
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [16][NI][D]
+  constexpr int NA = AccN<MODE, NI>::n;
   const int d = blockIdx.y;
-  const int wave = threadIdx.x >> 6;
-  const int sub = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6, sub = threadIdx.x & 63;
   const int D = a.D;
-  int cnt = a.n_heavy[d];
-  if (cnt > a.heavy_cap) cnt = a.heavy_cap;
+  const int cnt = min(a.n_heavy[d], a.heavy_cap);
+  const int nch = min(a.n_chunks[d], a.max_chunks);
   int col[CPL];
   bool cv[CPL];
 #pragma unroll
@@ -258,70 +316,73 @@ __global__ __launch_bounds__(1024) void k_walk_heavy(const WalkArgs a) {
     col[m] = (sub + m * 64) * VEC;
     cv[m] = col[m] < D;
   }
-  for (int h = blockIdx.x; h < cnt; h += gridDim.x) {
-    const int n = a.heavy[d][h];
-    V q[NI][CPL];
-    if constexpr (MODE == MODE_REASON) {
-      const int b = n / a.N;
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int m = 0; m < CPL; ++m)
-          q[i][m] = cv[m] ? vload<VEC>(a.ins + ((size_t)b * a.I + a.i0 + i) * D + col[m]) : vzero<VEC>();
-    } else {
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int m = 0; m < CPL; ++m) q[i][m] = vzero<VEC>();
+  const int32_t* off = a.chunk_off[d];
+  for (int c = blockIdx.x * 4 + wave; c < nch; c += gridDim.x * 4) {
+    int lo = 0, hi = cnt;                       // largest e with off[e] <= c
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (off[mid] <= c) lo = mid; else hi = mid;
     }
-    V acc[NI][CPL];
+    const int n = a.heavy[d][lo];
+    const int lc = c - off[lo];
+    const int rbeg = a.row_ptr[d][n];
+    const int beg = rbeg + lc * kHeavyDeg;
+    const int len = min(kHeavyDeg, a.row_ptr[d][n + 1] - beg);
+    const int b = n / a.N;
+    V q[NA][CPL];
+    load_q<MODE, VEC, CPL, NA>(a, b, col, cv, q);
+    V acc[NA][CPL];
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
       for (int m = 0; m < CPL; ++m) acc[i][m] = vzero<VEC>();
+    const float* T = table_of(a, MODE, d, b);
+    for (int base = 0; base < len; base += 64) {
+      float p;
+      int r;
+      load_fact<MODE>(a.edge[d], a.w[d], a.dist, beg, base + sub, len, p, r);
+      consume_batch<MODE, VEC, 64, CPL, NA>(p, r, min(64, len - base), T, D, col, cv, q, acc);
+    }
+    float* prow = a.partial + ((size_t)d * a.max_chunks + c) * (NA * D);
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+      for (int m = 0; m < CPL; ++m)
+        if (cv[m]) vstore<VEC>(prow + (size_t)i * D + col[m], acc[i][m]);
+  }
+}
 
-    // MODE_TYPE sums both directions of node n; a node heavy in both directions appears in both
-    // lists, so only the lower-numbered heavy direction finishes it.
-    bool mine = true;
-    if constexpr (MODE == MODE_TYPE) {
-      if (d == 1) {
-        const int l0 = a.row_ptr[0][n + 1] - a.row_ptr[0][n];
-        if (l0 > a.heavy_deg) mine = false;
+// ---- heavy rows, pass 2: one wave per heavy row sums its chunks in chunk order -----------------
+// REASON writes its own (i, d) output slots (grid.y = direction).  TYPE/FUSED add into the row the
+// light kernel left (one launch per direction, a.dir, so two lists never touch a row concurrently).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_heavy_reduce(const WalkArgs a, int na) {
+  const int d = (MODE == MODE_REASON) ? (int)blockIdx.y : a.dir;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int D = a.D;
+  const int cnt = min(a.n_heavy[d], a.heavy_cap);
+  const int32_t* off = a.chunk_off[d];
+  for (int e = blockIdx.x * 4 + wave; e < cnt; e += gridDim.x * 4) {
+    const int n = a.heavy[d][e];
+    const int c0 = off[e], c1 = min(off[e + 1], a.max_chunks);
+    bool relu = false;
+    if (MODE == MODE_TYPE) {
+      // the last pass touching node n applies the ReLU: direction 1 if n is heavy there, else 0
+      const int l1 = a.row_ptr[1][n + 1] - a.row_ptr[1][n];
+      relu = (d == 1) || !(l1 > a.heavy_deg);
+    }
+    for (int x = lane; x < na * D; x += 64) {
+      float s = 0.f;
+      for (int c = c0; c < c1; ++c) s += a.partial[((size_t)d * a.max_chunks + c) * (na * D) + x];
+      if (MODE == MODE_REASON) {
+        const int i = x / D, cc = x - i * D;
+        a.out[(size_t)n * (2 * a.I) * D + (size_t)(2 * (a.i0 + i) + d) * D + cc] = s;
+      } else {
+        float v = a.out[(size_t)n * D + x] + s;
+        if (relu) v = fmaxf(v, 0.f);
+        a.out[(size_t)n * D + x] = v;
       }
     }
-    if (mine) {
-      const int ndir = (MODE == MODE_TYPE) ? 2 : 1;
-      for (int dd = 0; dd < ndir; ++dd) {
-        const int dir = (MODE == MODE_TYPE) ? dd : d;
-        const int beg = a.row_ptr[dir][n];
-        const int len = a.row_ptr[dir][n + 1] - beg;
-        int per = (len + 15) / 16;
-        per = (per + 63) & ~63;                      // whole 64-fact batches per wave
-        const int wbeg = min(len, wave * per);
-        const int wlen = min(len, wbeg + per) - wbeg;
-        walk_row<MODE, VEC, 64, CPL, NI>(a.edge[dir], a.w[dir], a.dist, a.T[dir], D, beg + wbeg, wlen, wlen,
-                                         sub, col, cv, q, acc);
-      }
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int m = 0; m < CPL; ++m)
-          if (cv[m]) vstore<VEC>(red + ((size_t)wave * NI + i) * D + col[m], acc[i][m]);
-    }
-    __syncthreads();
-    if (mine) {
-      for (int e = threadIdx.x; e < NI * D; e += 1024) {
-        float s = 0.f;
-#pragma unroll
-        for (int wv = 0; wv < 16; ++wv) s += red[(size_t)wv * NI * D + e];
-        const int i = e / D, c = e - i * D;
-        if constexpr (MODE == MODE_REASON)
-          a.out[(size_t)n * (2 * a.I) * D + (size_t)(2 * (a.i0 + i) + d) * D + c] = s;
-        else
-          a.out[(size_t)n * D + c] = fmaxf(s, 0.f);
-      }
-    }
-    __syncthreads();
   }
 }
 
@@ -343,21 +404,36 @@ static bool pick_shape(int D, Shape* s) {
 }
 
 template <int MODE, int VEC, int LPN, int CPL, int NI>
-static int launch_one(const WalkArgs& a, hipStream_t stream) {
+static int launch_one(WalkArgs a, hipStream_t stream) {
   const int groups_per_block = 256 / LPN;
-  const int nblk = (a.BN + groups_per_block - 1) / groups_per_block;
+  int nblk = (a.BN + groups_per_block - 1) / groups_per_block;
+  a.bpg = 0;
+  if (MODE == MODE_FUSED && a.N % groups_per_block == 0) {
+    a.bpg = a.N / groups_per_block;
+    nblk = 8 * ((a.B + 7) / 8) * a.bpg;
+  }
   hipLaunchKernelGGL((k_walk_light<MODE, VEC, LPN, CPL, NI>), dim3(nblk), dim3(256), 0, stream, a);
   GNNRAG_LAUNCH_CHECK();
-  const size_t lds = (size_t)16 * NI * a.D * sizeof(float);
-  if (lds > 160 * 1024) return GNNRAG_E_UNSUPPORTED;
-  hipLaunchKernelGGL((k_walk_heavy<MODE, VEC, CPL, NI>), dim3(128, 2), dim3(1024), lds, stream, a);
+  // heavy rows (count lives on the device: fixed grids, grid-stride loops, no host sync)
+  hipLaunchKernelGGL((k_heavy_partial<MODE, VEC, CPL, NI>), dim3(512, 2), dim3(256), 0, stream, a);
   GNNRAG_LAUNCH_CHECK();
+  const int na = AccN<MODE, NI>::n;
+  if (MODE == MODE_REASON) {
+    hipLaunchKernelGGL((k_heavy_reduce<MODE>), dim3(64, 2), dim3(256), 0, stream, a, na);
+    GNNRAG_LAUNCH_CHECK();
+  } else {
+    for (int d = 0; d < 2; ++d) {
+      a.dir = d;
+      hipLaunchKernelGGL((k_heavy_reduce<MODE>), dim3(64, 1), dim3(256), 0, stream, a, na);
+      GNNRAG_LAUNCH_CHECK();
+    }
+  }
   return 0;
 }
 
 template <int MODE, int VEC, int LPN, int CPL>
 static int launch_ni(const WalkArgs& a, int ni, hipStream_t stream) {
-  if constexpr (MODE == MODE_TYPE) {
+  if constexpr (MODE != MODE_REASON) {
     return launch_one<MODE, VEC, LPN, CPL, 1>(a, stream);
   } else {
     switch (ni) {
@@ -387,31 +463,49 @@ static int launch_walk(const WalkArgs& a, int ni, hipStream_t stream) {
   return launch_shape<MODE, 1>(a, s, ni, stream);
 }
 
-static void fill_common(WalkArgs& a, const gnnrag_csr* csr, int D) {
+static size_t partial_bytes(const gnnrag_csr* csr, int D, int na) {
+  return align_up((size_t)2 * (size_t)csr->max_chunks * (size_t)na * (size_t)D * sizeof(float), 256);
+}
+
+static int fill_common(WalkArgs& a, const gnnrag_csr* csr, int D, void* ws, size_t ws_bytes, int na) {
   for (int d = 0; d < 2; ++d) {
     a.row_ptr[d] = csr->row_ptr[d];
     a.edge[d] = (const int2*)csr->edge[d];
     a.heavy[d] = csr->heavy[d];
+    a.chunk_off[d] = csr->chunk_off[d];
   }
   a.n_heavy = csr->n_heavy;
+  a.n_chunks = csr->n_chunks;
+  a.max_chunks = csr->max_chunks;
   a.heavy_cap = csr->heavy_cap;
   a.heavy_deg = csr->heavy_deg;
   a.BN = csr->B * csr->N;
+  a.B = csr->B;
   a.N = csr->N;
+  a.R1 = csr->R1;
   a.D = D;
+  if (!ws || ws_bytes < partial_bytes(csr, D, na)) return GNNRAG_E_WORKSPACE;
+  a.partial = (float*)ws;
+  return 0;
 }
 
 }  // namespace gnnrag
 
 using namespace gnnrag;
 
+extern "C" size_t gnnrag_aggregate_workspace_bytes(const gnnrag_csr* csr, int32_t D, int32_t I) {
+  if (!csr || D <= 0 || I <= 0) return 0;
+  return partial_bytes(csr, D, I < 3 ? I : 3);
+}
+
 extern "C" int gnnrag_aggregate(const gnnrag_csr* csr, const float* dist, const float* ins,
                                 const float* T_fwd, const float* T_inv, float* agg, int32_t D, int32_t I,
-                                gnnrag_stream_t stream) {
+                                void* workspace, size_t workspace_bytes, gnnrag_stream_t stream) {
   if (!csr || !dist || !ins || !T_fwd || !T_inv || !agg || D <= 0 || I <= 0) return GNNRAG_E_BADARG;
   WalkArgs a;
   memset(&a, 0, sizeof(a));
-  fill_common(a, csr, D);
+  int rc = fill_common(a, csr, D, workspace, workspace_bytes, I < 3 ? I : 3);
+  if (rc) return rc;
   a.w[0] = csr->w_gnn[0];
   a.w[1] = csr->w_gnn[1];
   a.T[0] = T_fwd;
@@ -424,25 +518,43 @@ extern "C" int gnnrag_aggregate(const gnnrag_csr* csr, const float* dist, const 
   for (int i0 = 0; i0 < I; i0 += 3) {
     a.i0 = i0;
     const int ni = (I - i0) < 3 ? (I - i0) : 3;
-    const int rc = launch_walk<MODE_REASON>(a, ni, (hipStream_t)stream);
+    rc = launch_walk<MODE_REASON>(a, ni, (hipStream_t)stream);
     if (rc) return rc;
   }
   return 0;
 }
 
+extern "C" int gnnrag_aggregate_fused(const gnnrag_csr* csr, const float* dist, const float* P, float* out,
+                                      int32_t D, void* workspace, size_t workspace_bytes,
+                                      gnnrag_stream_t stream) {
+  if (!csr || !dist || !P || !out || D <= 0) return GNNRAG_E_BADARG;
+  WalkArgs a;
+  memset(&a, 0, sizeof(a));
+  const int rc = fill_common(a, csr, D, workspace, workspace_bytes, 1);
+  if (rc) return rc;
+  a.w[0] = csr->w_gnn[0];
+  a.w[1] = csr->w_gnn[1];
+  a.T[0] = P;
+  a.T[1] = P + (size_t)csr->B * csr->R1 * D;
+  a.dist = dist;
+  a.out = out;
+  a.I = 1;
+  return launch_walk<MODE_FUSED>(a, 1, (hipStream_t)stream);
+}
+
 extern "C" int gnnrag_typelayer(const gnnrag_csr* csr, const float* T, int use_w_rel, float* h0, int32_t D,
-                                gnnrag_stream_t stream) {
+                                void* workspace, size_t workspace_bytes, gnnrag_stream_t stream) {
   if (!csr || !T || !h0 || D <= 0) return GNNRAG_E_BADARG;
   if (use_w_rel && (!csr->w_rel[0] || !csr->w_rel[1])) return GNNRAG_E_BADARG;
   WalkArgs a;
   memset(&a, 0, sizeof(a));
-  fill_common(a, csr, D);
+  const int rc = fill_common(a, csr, D, workspace, workspace_bytes, 1);
+  if (rc) return rc;
   a.w[0] = use_w_rel ? csr->w_rel[0] : nullptr;
   a.w[1] = use_w_rel ? csr->w_rel[1] : nullptr;
   a.T[0] = T;
   a.T[1] = T;
   a.out = h0;
   a.I = 1;
-  a.i0 = 0;
   return launch_walk<MODE_TYPE>(a, 1, (hipStream_t)stream);
 }

@@ -19,7 +19,7 @@
 namespace gnnrag {
 
 struct CsrLayout {
-  size_t row_ptr[2], edge[2], perm[2], w_gnn[2], w_rel[2], heavy[2], n_heavy, total;
+  size_t row_ptr[2], edge[2], perm[2], w_gnn[2], w_rel[2], heavy[2], chunk_off[2], n_heavy, total;
   int32_t heavy_cap;
 };
 
@@ -40,7 +40,8 @@ static CsrLayout csr_layout(int64_t F, int32_t B, int32_t N, int has_w_gnn, int 
   for (int d = 0; d < 2; ++d) L.w_gnn[d] = has_w_gnn ? take(Fp * sizeof(float)) : 0;
   for (int d = 0; d < 2; ++d) L.w_rel[d] = has_w_rel ? take(Fp * sizeof(float)) : 0;
   for (int d = 0; d < 2; ++d) L.heavy[d] = take((size_t)L.heavy_cap * sizeof(int32_t));
-  L.n_heavy = take(2 * sizeof(int32_t));
+  for (int d = 0; d < 2; ++d) L.chunk_off[d] = take(((size_t)L.heavy_cap + 1) * sizeof(int32_t));
+  L.n_heavy = take(4 * sizeof(int32_t));   // n_heavy[2], n_chunks[2]
   L.total = off;
   return L;
 }
@@ -110,6 +111,58 @@ __global__ __launch_bounds__(256) void k_csr_heavy(const int32_t* __restrict__ r
   }
 }
 
+// Heavy rows are walked in chunks of kHeavyDeg facts: chunk_off[e] = first chunk of heavy entry e
+// (exclusive prefix over ceil(deg/kHeavyDeg)), one 1024-thread workgroup per direction.
+__global__ __launch_bounds__(1024) void k_csr_heavy_chunks(const int32_t* __restrict__ rp0,
+                                                           const int32_t* __restrict__ rp1,
+                                                           const int32_t* __restrict__ list0,
+                                                           const int32_t* __restrict__ list1,
+                                                           const int32_t* __restrict__ n_heavy, int32_t cap,
+                                                           int32_t* __restrict__ off0, int32_t* __restrict__ off1,
+                                                           int32_t* __restrict__ n_chunks) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int d = blockIdx.x;
+  const int32_t* rp = d ? rp1 : rp0;
+  const int32_t* list = d ? list1 : list0;
+  int32_t* off = d ? off1 : off0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cnt = min(n_heavy[d], cap);
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < cnt; base += 1024) {
+    const int i = base + tid;
+    int v = 0;
+    if (i < cnt) {
+      const int n = list[i];
+      v = (rp[n + 1] - rp[n] + kHeavyDeg - 1) / kHeavyDeg;
+    }
+    int x = v;                                   // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int wp = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      if (w < wave) wp += wsum[w];
+      total += wsum[w];
+    }
+    const int carry = carry_s;
+    if (i < cnt) off[i] = carry + wp + x - v;
+    __syncthreads();
+    if (tid == 0) carry_s = carry + total;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    off[cnt] = carry_s;
+    n_chunks[d] = carry_s;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_csr_permute_weight(const int32_t* __restrict__ perm,
                                                             const float* __restrict__ w, int64_t F, int square,
                                                             float* __restrict__ out) {
@@ -173,9 +226,12 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
     out->w_gnn[d] = w_gnn ? (float*)(base + L.w_gnn[d]) : nullptr;
     out->w_rel[d] = w_rel ? (float*)(base + L.w_rel[d]) : nullptr;
     out->heavy[d] = (int32_t*)(base + L.heavy[d]);
+    out->chunk_off[d] = (int32_t*)(base + L.chunk_off[d]);
   }
   out->n_heavy = (int32_t*)(base + L.n_heavy);
-  GNNRAG_HIP(hipMemsetAsync(out->n_heavy, 0, 2 * sizeof(int32_t), stream));
+  out->n_chunks = out->n_heavy + 2;
+  out->max_chunks = 2 * L.heavy_cap;   // sum ceil(deg/256) over rows with deg > 256 < F/256 + F/257
+  GNNRAG_HIP(hipMemsetAsync(out->n_heavy, 0, 4 * sizeof(int32_t), stream));
 
   const unsigned bits = key_bits((size_t)BN);
   const size_t keys_bytes = align_up((size_t)(F > 0 ? F : 1) * sizeof(uint32_t), 256);
@@ -209,5 +265,9 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
                        out->n_heavy + d);
     GNNRAG_LAUNCH_CHECK();
   }
+  hipLaunchKernelGGL(k_csr_heavy_chunks, dim3(2), dim3(1024), 0, stream, out->row_ptr[0], out->row_ptr[1],
+                     out->heavy[0], out->heavy[1], out->n_heavy, out->heavy_cap, out->chunk_off[0],
+                     out->chunk_off[1], out->n_chunks);
+  GNNRAG_LAUNCH_CHECK();
   return 0;
 }

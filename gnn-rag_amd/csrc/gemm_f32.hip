@@ -44,14 +44,43 @@ struct GemmArgs {
   float* score;         // EPI_UPDATE: [M]
   int32_t M, K, K0, Nout, add_rows, relu;
   int32_t n0;           // first output column of this launch's column block (EPI_LINEAR, Nout > 208)
+  int32_t ldw;          // row stride of W in floats (>= K; e2e_linear column blocks are used in place)
+  int32_t wc0;          // first column of W used (AMODE_PLAIN)
+  // AMODE_GEN (per-question relation tables): row m = (b, r), column k = (i, kk):
+  //   A[m,k] = relu(A0[r*D + kk] * A1[(b*I + i)*D + kk]),  W column = (1 + 2i + gen_dir)*D + kk
+  int32_t gen_R1, gen_D, gen_I, gen_dir;
 };
 
-// 4 consecutive k of logical row m of A (= [A0 | A1]); zero beyond M / K.
-template <bool V4>
+enum { AMODE_PLAIN = 0, AMODE_GEN = 1 };
+
+// 4 consecutive k of logical row m of A (= [A0 | A1], or generated); zero beyond M / K.
+template <bool V4, int AMODE>
 __device__ __forceinline__ f32x4 load_a4(const GemmArgs& g, int m, int k) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   if (m >= g.M) return v;
-  if constexpr (V4) {
+  if constexpr (AMODE == AMODE_GEN) {
+    // relu(T_d[r,:] * ins[b,i,:]) generated on the fly: the [B*R1, I*D] operand never exists in HBM
+    if (k >= g.K) return v;
+    const int b = m / g.gen_R1, r = m - b * g.gen_R1;
+    const int i = k / g.gen_D, kk = k - i * g.gen_D;
+    const float* tp = g.A0 + (size_t)r * g.gen_D + kk;
+    const float* qp = g.A1 + ((size_t)b * g.gen_I + i) * g.gen_D + kk;
+    if constexpr (V4) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(tp);
+      const f32x4 q = *reinterpret_cast<const f32x4*>(qp);
+      v = __builtin_elementwise_max(t * q, v);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k2 = k + j;
+        if (k2 < g.K) {
+          const int i2 = k2 / g.gen_D, kk2 = k2 - i2 * g.gen_D;
+          v[j] = fmaxf(g.A0[(size_t)r * g.gen_D + kk2] * g.A1[((size_t)b * g.gen_I + i2) * g.gen_D + kk2], 0.f);
+        }
+      }
+    }
+    return v;
+  } else if constexpr (V4) {
     // K0, K-K0 multiples of 4 and 16-byte aligned bases: a float4 never straddles the split
     if (k < g.K0) v = *reinterpret_cast<const f32x4*>(g.A0 + (size_t)m * g.K0 + k);
     else if (k < g.K) v = *reinterpret_cast<const f32x4*>(g.A1 + (size_t)m * (g.K - g.K0) + (k - g.K0));
@@ -66,21 +95,32 @@ __device__ __forceinline__ f32x4 load_a4(const GemmArgs& g, int m, int k) {
   return v;
 }
 
-template <bool V4>
+// column of W that multiplies logical k
+template <int AMODE>
+__device__ __forceinline__ int w_col(const GemmArgs& g, int k) {
+  if constexpr (AMODE == AMODE_GEN) {
+    const int i = k / g.gen_D;
+    return (1 + 2 * i + g.gen_dir) * g.gen_D + (k - i * g.gen_D);
+  } else {
+    return g.wc0 + k;
+  }
+}
+
+template <bool V4, int AMODE>
 __device__ __forceinline__ f32x4 load_w4(const GemmArgs& g, int j, int k) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   if (j >= g.Nout) return v;
   if constexpr (V4) {
-    if (k < g.K) v = *reinterpret_cast<const f32x4*>(g.W + (size_t)j * g.K + k);
+    if (k < g.K) v = *reinterpret_cast<const f32x4*>(g.W + (size_t)j * g.ldw + w_col<AMODE>(g, k));
   } else {
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
-      if (k + jj < g.K) v[jj] = g.W[(size_t)j * g.K + k + jj];
+      if (k + jj < g.K) v[jj] = g.W[(size_t)j * g.ldw + w_col<AMODE>(g, k + jj)];
   }
   return v;
 }
 
-template <int NT, bool V4, int EPI>
+template <int NT, bool V4, int EPI, int AMODE>
 __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs g) {
   constexpr int WR = (NT * 16 + 31) / 32;  // W staging rounds (32 rows per round)
   __shared__ __attribute__((aligned(16))) float As[kBM * kLS];
@@ -106,11 +146,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs g) {
   auto gload = [&](int t) {
     const int k = t * kBK + kq * 4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ra[r] = load_a4<V4>(g, m0 + lr + 32 * r, k);
+    for (int r = 0; r < 4; ++r) ra[r] = load_a4<V4, AMODE>(g, m0 + lr + 32 * r, k);
 #pragma unroll
     for (int r = 0; r < WR; ++r) {
       const int j = lr + 32 * r;
-      rw[r] = (j < NT * 16) ? load_w4<V4>(g, n0 + j, k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      rw[r] = (j < NT * 16) ? load_w4<V4, AMODE>(g, n0 + j, k) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   };
   auto sstore = [&]() {
@@ -173,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs g) {
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wave * 32 + mt * 16 + fg * 4 + r;
         float v = acc[mt][nt][r] + bia;
-        if (EPI == EPI_LINEAR && g.add && cok && row < g.add_rows) v += g.add[(size_t)row * g.Nout + col];
+        if (g.add && cok && row < g.add_rows) v += g.add[(size_t)row * g.Nout + col];
         if (EPI == EPI_UPDATE || g.relu) v = fmaxf(v, 0.f);
         if (cok && row < g.M) g.C[(size_t)row * g.Nout + col] = v;
         if (EPI == EPI_UPDATE) part[mt][r] += v * ws;
@@ -217,17 +257,73 @@ __global__ __launch_bounds__(256) void k_score_rows(const float* __restrict__ h,
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-template <int EPI>
+// ---- skinny problems (M up to a few thousand rows, e.g. the [R1,D] relation transforms) ------
+// The tiled kernel would run them on M/128 workgroups (5 for R1 = 602) and be latency bound.
+// Here one wave owns a 16 x 64 output tile and reads its MFMA fragments straight from global
+// memory (the operands are L2 resident), so a 602 x 200 problem spreads over ~150 waves.
+template <bool V4>
+__global__ __launch_bounds__(256) void k_gemm_skinny(const GemmArgs g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int m0 = blockIdx.x * 16;
+  const int c0 = (blockIdx.y * 4 + wave) * 64;
+  if (c0 >= g.Nout) return;
+  f32x4 acc[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < g.K; k0 += 32) {
+    f32x4 a[2], b[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int k = k0 + c * 16 + fg * 4;
+      a[c] = load_a4<V4, AMODE_PLAIN>(g, m0 + fr, k);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) b[c][nt] = load_w4<V4, AMODE_PLAIN>(g, c0 + nt * 16 + fr, k);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][s], b[c][nt][s], acc[nt], 0, 0, 0);
+  }
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int col = c0 + nt * 16 + fr;
+    if (col >= g.Nout) continue;
+    const float bia = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + fg * 4 + r;
+      if (row >= g.M) continue;
+      float v = acc[nt][r] + bia;
+      if (g.add && row < g.add_rows) v += g.add[(size_t)row * g.Nout + col];
+      if (g.relu) v = fmaxf(v, 0.f);
+      g.C[(size_t)row * g.Nout + col] = v;
+    }
+  }
+}
+
+template <int EPI, int AMODE>
 static int launch_gemm(GemmArgs g, hipStream_t stream) {
   if (g.M <= 0) return 0;
-  const bool v4 = (g.K % 4 == 0) && (g.K0 % 4 == 0) && aligned16(g.A0) && aligned16(g.W) &&
-                  (g.A1 == nullptr || aligned16(g.A1));
+  const bool v4 = (g.K % 4 == 0) && (g.K0 % 4 == 0) && (g.ldw % 4 == 0) && (g.wc0 % 4 == 0) &&
+                  aligned16(g.A0) && aligned16(g.W) && (g.A1 == nullptr || aligned16(g.A1)) &&
+                  (AMODE != AMODE_GEN || g.gen_D % 4 == 0);
+  if (EPI == EPI_LINEAR && AMODE == AMODE_PLAIN && g.M <= 4096 && g.n0 == 0) {
+    const dim3 grid((g.M + 15) / 16, (g.Nout + 255) / 256);
+    if (v4) hipLaunchKernelGGL((k_gemm_skinny<true>), grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((k_gemm_skinny<false>), grid, dim3(256), 0, stream, g);
+    GNNRAG_LAUNCH_CHECK();
+    return 1 << 30;   // "all columns done" marker for the column-block loop of the caller
+  }
   const int nblk = (g.M + kBM - 1) / kBM;
   const int ncol = g.Nout - g.n0;
-#define GNNRAG_GEMM_CASE(NT)                                                                          \
-  do {                                                                                                \
-    if (v4) hipLaunchKernelGGL((k_gemm_f32<NT, true, EPI>), dim3(nblk), dim3(256), 0, stream, g);     \
-    else hipLaunchKernelGGL((k_gemm_f32<NT, false, EPI>), dim3(nblk), dim3(256), 0, stream, g);       \
+#define GNNRAG_GEMM_CASE(NT)                                                                                \
+  do {                                                                                                      \
+    if (v4) hipLaunchKernelGGL((k_gemm_f32<NT, true, EPI, AMODE>), dim3(nblk), dim3(256), 0, stream, g);    \
+    else hipLaunchKernelGGL((k_gemm_f32<NT, false, EPI, AMODE>), dim3(nblk), dim3(256), 0, stream, g);      \
   } while (0)
   if (ncol <= 64) GNNRAG_GEMM_CASE(4);
   else if (ncol <= 128) GNNRAG_GEMM_CASE(8);
@@ -249,14 +345,35 @@ extern "C" int gnnrag_linear(const float* A, int64_t M, int32_t K, const float* 
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.A0 = A; g.W = W; g.bias = bias; g.add = add; g.C = C;
-  g.M = (int32_t)M; g.K = K; g.K0 = K; g.Nout = Nout;
+  g.M = (int32_t)M; g.K = K; g.K0 = K; g.Nout = Nout; g.ldw = K;
   g.add_rows = add ? (int32_t)(add_rows < M ? add_rows : M) : 0;
   g.relu = relu;
   for (int n0 = 0; n0 < Nout; n0 += 208) {
     g.n0 = n0;
-    const int rc = launch_gemm<EPI_LINEAR>(g, (hipStream_t)stream);
+    const int rc = launch_gemm<EPI_LINEAR, AMODE_PLAIN>(g, (hipStream_t)stream);
+    if (rc == (1 << 30)) break;
     if (rc) return rc;
   }
+  return 0;
+}
+
+// shared by the two update entry points: h' = relu(A.W^T + b (+ add)), score = score_func(h') + mask term
+static int update_common(GemmArgs g, int64_t BN, int32_t D, hipStream_t stream) {
+  if (D <= 208) {
+    g.n0 = 0;
+    return launch_gemm<EPI_UPDATE, AMODE_PLAIN>(g, stream);
+  }
+  // wide hidden sizes: column blocks of 208 with bias(+add)+ReLU epilogue, then a row-dot for the score
+  g.relu = 1;
+  for (int n0 = 0; n0 < D; n0 += 208) {
+    g.n0 = n0;
+    const int rc = launch_gemm<EPI_LINEAR, AMODE_PLAIN>(g, stream);
+    if (rc == (1 << 30)) break;
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_score_rows, dim3((int)((BN + 3) / 4)), dim3(256), 0, stream, g.C, g.w_s, g.b_s, g.mask,
+                     g.score, (int)BN, D);
+  GNNRAG_LAUNCH_CHECK();
   return 0;
 }
 
@@ -270,20 +387,48 @@ extern "C" int gnnrag_update_score(const float* h, const float* agg, const float
   memset(&g, 0, sizeof(g));
   g.A0 = h; g.A1 = agg; g.W = W; g.bias = b; g.C = h_out;
   g.w_s = w_s; g.b_s = b_s; g.mask = mask; g.score = score;
-  g.M = (int32_t)BN; g.K = (2 * I + 1) * D; g.K0 = D; g.Nout = D;
+  g.M = (int32_t)BN; g.K = (2 * I + 1) * D; g.K0 = D; g.Nout = D; g.ldw = g.K;
   g.relu = 1;
-  if (D <= 208) {
-    g.n0 = 0;
-    return launch_gemm<EPI_UPDATE>(g, (hipStream_t)stream);
+  return update_common(g, BN, D, (hipStream_t)stream);
+}
+
+extern "C" int gnnrag_update_score_fused(const float* h, const float* nbr, const float* W, const float* b,
+                                         const float* w_s, const float* b_s, const float* mask, float* h_out,
+                                         float* score, int64_t BN, int32_t D, int32_t I,
+                                         gnnrag_stream_t stream) {
+  if (!h || !nbr || !W || !b || !w_s || !b_s || !mask || !h_out || !score || BN < 0 || D <= 0 || I <= 0)
+    return GNNRAG_E_BADARG;
+  if (BN >= ((int64_t)1 << 31)) return GNNRAG_E_UNSUPPORTED;
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  // only the self block W[:, 0:D] of e2e_linear is multiplied here; the neighbour blocks were
+  // pushed into the relation tables and arrive already reduced in `nbr`
+  g.A0 = h; g.W = W; g.bias = b; g.add = nbr; g.add_rows = (int32_t)BN; g.C = h_out;
+  g.w_s = w_s; g.b_s = b_s; g.mask = mask; g.score = score;
+  g.M = (int32_t)BN; g.K = D; g.K0 = D; g.Nout = D; g.ldw = (2 * I + 1) * D; g.wc0 = 0;
+  g.relu = 1;
+  return update_common(g, BN, D, (hipStream_t)stream);
+}
+
+extern "C" int gnnrag_relation_tables(const float* T_fwd, const float* T_inv, const float* ins, const float* W,
+                                      float* P, int32_t B, int32_t R1, int32_t D, int32_t I,
+                                      gnnrag_stream_t stream) {
+  if (!T_fwd || !T_inv || !ins || !W || !P || B <= 0 || R1 <= 0 || D <= 0 || I <= 0) return GNNRAG_E_BADARG;
+  if ((int64_t)B * R1 >= ((int64_t)1 << 31)) return GNNRAG_E_UNSUPPORTED;
+  for (int d = 0; d < 2; ++d) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A0 = d ? T_inv : T_fwd;
+    g.A1 = ins;
+    g.W = W;
+    g.C = P + (size_t)d * B * R1 * D;
+    g.M = B * R1; g.K = I * D; g.K0 = g.K; g.Nout = D; g.ldw = (2 * I + 1) * D;
+    g.gen_R1 = R1; g.gen_D = D; g.gen_I = I; g.gen_dir = d;
+    for (int n0 = 0; n0 < D; n0 += 208) {
+      g.n0 = n0;
+      const int rc = launch_gemm<EPI_LINEAR, AMODE_GEN>(g, (hipStream_t)stream);
+      if (rc) return rc;
+    }
   }
-  // wide hidden sizes: column blocks of 208 with plain bias+ReLU epilogue, then a row-dot for the score
-  for (int n0 = 0; n0 < D; n0 += 208) {
-    g.n0 = n0;
-    const int rc = launch_gemm<EPI_LINEAR>(g, (hipStream_t)stream);
-    if (rc) return rc;
-  }
-  hipLaunchKernelGGL(k_score_rows, dim3((int)((BN + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h_out, w_s,
-                     b_s, mask, score, (int)BN, D);
-  GNNRAG_LAUNCH_CHECK();
   return 0;
 }

@@ -53,14 +53,33 @@ __global__ __launch_bounds__(256) void k_stream_copy(const f32x4* __restrict__ s
   for (; i < n4; i += stride) dst[i] = src[i];
 }
 
-struct LayerWs { size_t T_fwd, T_inv, agg, total; };
-static LayerWs layer_ws(int32_t B, int32_t N, int32_t R1, int32_t D, int32_t I) {
+struct LayerWs { size_t T_fwd, T_inv, agg, P, nbr, partial, partial_bytes, total; };
+
+// flops of the dense part per layer call: unfused = one [BN,(2I+1)D]x[(2I+1)D,D] GEMM; fused = the
+// per-question relation tables [2*B*R1, I*D]x[I*D, D] plus the self block [BN,D]x[D,D]
+static bool fused_is_cheaper(int64_t B, int64_t N, int64_t R1, int64_t D, int64_t I) {
+  const double unfused = (double)B * N * (2 * I + 1) * D * D;
+  const double fused = 2.0 * B * R1 * I * D * D + (double)B * N * D * D;
+  return fused < 0.8 * unfused;
+}
+
+static LayerWs layer_ws(const gnnrag_csr* csr, int32_t D, int32_t I) {
   LayerWs w;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-  w.T_fwd = take((size_t)R1 * D * sizeof(float));
-  w.T_inv = take((size_t)R1 * D * sizeof(float));
-  w.agg = take((size_t)B * N * 2 * I * D * sizeof(float));
+  const size_t BN = (size_t)csr->B * csr->N;
+  w.T_fwd = take((size_t)csr->R1 * D * sizeof(float));
+  w.T_inv = take((size_t)csr->R1 * D * sizeof(float));
+  // the two paths never run in the same call: their big buffers share one region
+  const size_t a_bytes = BN * 2 * I * D * sizeof(float);
+  const size_t p_bytes = align_up((size_t)2 * csr->B * csr->R1 * D * sizeof(float), 256);
+  const size_t n_bytes = BN * D * sizeof(float);
+  const size_t big = take(a_bytes > p_bytes + n_bytes ? a_bytes : p_bytes + n_bytes);
+  w.agg = big;
+  w.P = big;
+  w.nbr = big + p_bytes;
+  w.partial_bytes = gnnrag_aggregate_workspace_bytes(csr, D, I);
+  w.partial = take(w.partial_bytes);
   w.total = off;
   return w;
 }
@@ -86,9 +105,9 @@ extern "C" int gnnrag_stream_copy(const float* src, float* dst, int64_t n, gnnra
   return 0;
 }
 
-extern "C" size_t gnnrag_layer_workspace_bytes(int32_t B, int32_t N, int32_t R1, int32_t D, int32_t I) {
-  if (B <= 0 || N <= 0 || R1 <= 0 || D <= 0 || I <= 0) return 0;
-  return layer_ws(B, N, R1, D, I).total;
+extern "C" size_t gnnrag_layer_workspace_bytes(const gnnrag_csr* csr, int32_t D, int32_t I) {
+  if (!csr || D <= 0 || I <= 0) return 0;
+  return layer_ws(csr, D, I).total;
 }
 
 extern "C" int gnnrag_reason_layer(const gnnrag_csr* csr, const float* h, const float* dist, const float* ins,
@@ -97,27 +116,43 @@ extern "C" int gnnrag_reason_layer(const gnnrag_csr* csr, const float* h, const 
                                    int32_t pos_rows, const float* W_e2e, const float* b_e2e,
                                    const float* w_score, const float* b_score, const float* mask,
                                    float* h_out, float* score_out, float* dist_out, void* workspace,
-                                   size_t workspace_bytes, int32_t D, int32_t I, gnnrag_stream_t stream) {
+                                   size_t workspace_bytes, int32_t D, int32_t I, int32_t path,
+                                   gnnrag_stream_t stream) {
   if (!csr || !h || !dist || !ins || !relfeat_fwd || !relfeat_inv || !W_rel || !b_rel || !W_e2e || !b_e2e ||
-      !w_score || !b_score || !mask || !h_out || !score_out || !dist_out || !workspace)
+      !w_score || !b_score || !mask || !h_out || !score_out || !dist_out || !workspace || D <= 0 || I <= 0)
     return GNNRAG_E_BADARG;
-  const LayerWs w = layer_ws(csr->B, csr->N, csr->R1, D, I);
+  if (path < GNNRAG_PATH_AUTO || path > GNNRAG_PATH_FUSED) return GNNRAG_E_BADARG;
+  const LayerWs w = layer_ws(csr, D, I);
   if (workspace_bytes < w.total) return GNNRAG_E_WORKSPACE;
   char* base = (char*)workspace;
   float* T_fwd = (float*)(base + w.T_fwd);
   float* T_inv = (float*)(base + w.T_inv);
-  float* agg = (float*)(base + w.agg);
+  const int64_t BN = (int64_t)csr->B * csr->N;
   int rc;
   // T_d = rel_linear(rel_features_d) (+ pos_emb_d): once per relation row, not once per fact
   rc = gnnrag_linear(relfeat_fwd, csr->R1, D, W_rel, b_rel, pos_fwd, pos_fwd ? pos_rows : 0, 0, T_fwd, D, stream);
   if (rc) return rc;
   rc = gnnrag_linear(relfeat_inv, csr->R1, D, W_rel, b_rel, pos_inv, pos_inv ? pos_rows : 0, 0, T_inv, D, stream);
   if (rc) return rc;
-  rc = gnnrag_aggregate(csr, dist, ins, T_fwd, T_inv, agg, D, I, stream);
-  if (rc) return rc;
-  rc = gnnrag_update_score(h, agg, W_e2e, b_e2e, w_score, b_score, mask, h_out, score_out,
-                           (int64_t)csr->B * csr->N, D, I, stream);
-  if (rc) return rc;
+  if (path == GNNRAG_PATH_AUTO)
+    path = fused_is_cheaper(csr->B, csr->N, csr->R1, D, I) ? GNNRAG_PATH_FUSED : GNNRAG_PATH_UNFUSED;
+  if (path == GNNRAG_PATH_FUSED) {
+    float* P = (float*)(base + w.P);
+    float* nbr = (float*)(base + w.nbr);
+    rc = gnnrag_relation_tables(T_fwd, T_inv, ins, W_e2e, P, csr->B, csr->R1, D, I, stream);
+    if (rc) return rc;
+    rc = gnnrag_aggregate_fused(csr, dist, P, nbr, D, base + w.partial, w.partial_bytes, stream);
+    if (rc) return rc;
+    rc = gnnrag_update_score_fused(h, nbr, W_e2e, b_e2e, w_score, b_score, mask, h_out, score_out, BN, D, I,
+                                   stream);
+    if (rc) return rc;
+  } else {
+    float* agg = (float*)(base + w.agg);
+    rc = gnnrag_aggregate(csr, dist, ins, T_fwd, T_inv, agg, D, I, base + w.partial, w.partial_bytes, stream);
+    if (rc) return rc;
+    rc = gnnrag_update_score(h, agg, W_e2e, b_e2e, w_score, b_score, mask, h_out, score_out, BN, D, I, stream);
+    if (rc) return rc;
+  }
   return gnnrag_masked_softmax(score_out, dist_out, csr->B, csr->N, stream);
 }
 

@@ -12,6 +12,8 @@ it with autograd enabled raises instead of silently computing without a graph.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -36,6 +38,8 @@ class ReasonGNNLayer(BaseGNNLayer):
         self.use_posemb = args["pos_emb"]
         self.init_layers(args)
         self._ws = ops.LayerWorkspace()
+        # kernel path of the library (0 auto / 1 unfused / 2 fused); GNNRAG_PATH overrides for A/B runs
+        self.path = int(os.environ.get("GNNRAG_PATH", "0"))
 
     def init_layers(self, args):
         D = self.entity_dim
@@ -91,7 +95,7 @@ class ReasonGNNLayer(BaseGNNLayer):
             relational_ins.detach().float(), self.rel_features.detach(), self.rel_features_inv.detach(),
             rel_linear.weight, rel_linear.bias, e2e_linear.weight, e2e_linear.bias,
             self.score_func.weight, self.score_func.bias, self.local_entity_mask,
-            pos=pos, pos_inv=pos_inv, ws=self._ws)
+            pos=pos, pos_inv=pos_inv, ws=self._ws, path=self.path)
         self.local_entity_emb = h_out
         self.possible_cand.append(self.local_entity_mask)
         if return_score:

@@ -79,6 +79,14 @@ class CsrPlan:
             # allocator re-issues it to later work on the same stream only, so dropping it is safe
         self._w = {}
 
+    def walk_workspace(self, D: int, I: int) -> torch.Tensor:
+        """Scratch for the heavy-row partial sums of the walk kernels (cached per (D, I))."""
+        key = ("ws", D, min(I, 3))
+        if key not in self._w:
+            nbytes = _lib.load().gnnrag_aggregate_workspace_bytes(C.byref(self.c), D, I)
+            self._w[key] = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+        return self._w[key]
+
     # -- lazily attached per-fact weights ----------------------------------------------------
     def _attach(self, key: str, w_per_fact, square: bool):
         if key in self._w:
@@ -128,7 +136,10 @@ class CsrPlan:
             out["heavy%d" % d] = np.sort(self._view(self.c.heavy[d], int(min(nh[d], self.c.heavy_cap)),
                                                     torch.int32).numpy())
         for key, t in self._w.items():
-            out[key] = t.cpu().numpy()
+            if isinstance(key, str):
+                out[key] = t.cpu().numpy()
+        nc = self._view(self.c.n_chunks, 2, torch.int32).numpy()
+        out["n_chunks"] = nc
         return out
 
 
@@ -168,10 +179,63 @@ def aggregate(plan: CsrPlan, dist: torch.Tensor, ins: torch.Tensor, T_fwd: torch
     T_fwd = _chk(T_fwd, "T_fwd", shape=(plan.R1, D))
     T_inv = _chk(T_inv, "T_inv", shape=(plan.R1, D))
     agg = torch.empty((B * N, 2 * I * D), dtype=torch.float32, device=dist.device)
+    ws = plan.walk_workspace(D, I)
     with torch.cuda.device(dist.device):
         _lib.check(lib.gnnrag_aggregate(C.byref(plan.c), dist.data_ptr(), ins.data_ptr(), T_fwd.data_ptr(),
-                                        T_inv.data_ptr(), agg.data_ptr(), D, I, _stream()), "gnnrag_aggregate")
+                                        T_inv.data_ptr(), agg.data_ptr(), D, I, ws.data_ptr(), ws.numel(),
+                                        _stream()), "gnnrag_aggregate")
     return agg
+
+
+def relation_tables(T_fwd: torch.Tensor, T_inv: torch.Tensor, ins: torch.Tensor, W_e2e: torch.Tensor) -> torch.Tensor:
+    """P[d,b,r,:] = sum_i W_e2e[:, block(i,d)] relu(T_d[r,:] * ins[b,i,:])  ->  [2,B,R1,D]."""
+    lib = _lib.load()
+    ins = _chk(ins, "ins")
+    B, I, D = ins.shape
+    T_fwd = _chk(T_fwd, "T_fwd")
+    R1 = T_fwd.shape[0]
+    T_inv = _chk(T_inv, "T_inv", shape=(R1, D))
+    W_e2e = _chk(W_e2e, "e2e_linear.weight", shape=(D, (2 * I + 1) * D))
+    P = torch.empty((2, B, R1, D), dtype=torch.float32, device=ins.device)
+    with torch.cuda.device(ins.device):
+        _lib.check(lib.gnnrag_relation_tables(T_fwd.data_ptr(), T_inv.data_ptr(), ins.data_ptr(), W_e2e.data_ptr(),
+                                              P.data_ptr(), B, R1, D, I, _stream()), "gnnrag_relation_tables")
+    return P
+
+
+def aggregate_fused(plan: CsrPlan, dist: torch.Tensor, P: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    B, N = plan.B, plan.N
+    P = _chk(P, "P")
+    D = P.shape[-1]
+    if tuple(P.shape) != (2, B, plan.R1, D):
+        raise ValueError("P must be [2,B,R1,D]")
+    dist = _chk(dist, "dist").reshape(-1)
+    out = torch.empty((B * N, D), dtype=torch.float32, device=dist.device)
+    ws = plan.walk_workspace(D, 1)
+    with torch.cuda.device(dist.device):
+        _lib.check(lib.gnnrag_aggregate_fused(C.byref(plan.c), dist.data_ptr(), P.data_ptr(), out.data_ptr(), D,
+                                              ws.data_ptr(), ws.numel(), _stream()), "gnnrag_aggregate_fused")
+    return out
+
+
+def update_score_fused(h, nbr, W, b, w_s, b_s, mask, I: int):
+    lib = _lib.load()
+    h = _chk(h, "h")
+    BN, D = h.shape
+    nbr = _chk(nbr, "nbr", shape=(BN, D))
+    W = _chk(W, "W", shape=(D, (2 * I + 1) * D))
+    b = _chk(b, "b", shape=(D,))
+    w_s = _chk(w_s, "w_s").reshape(-1)
+    b_s = _chk(b_s, "b_s").reshape(-1)
+    mask = _chk(mask, "mask").reshape(-1)
+    h_out = torch.empty_like(h)
+    score = torch.empty(BN, dtype=torch.float32, device=h.device)
+    with torch.cuda.device(h.device):
+        _lib.check(lib.gnnrag_update_score_fused(h.data_ptr(), nbr.data_ptr(), W.data_ptr(), b.data_ptr(),
+                                                 w_s.data_ptr(), b_s.data_ptr(), mask.data_ptr(), h_out.data_ptr(),
+                                                 score.data_ptr(), BN, D, I, _stream()), "gnnrag_update_score_fused")
+    return h_out, score
 
 
 def update_score(h, agg, W, b, w_s, b_s, mask, I: int):
@@ -214,9 +278,10 @@ def typelayer(plan: CsrPlan, T: torch.Tensor, use_w_rel: bool) -> torch.Tensor:
     if T.shape[0] != plan.R1:
         raise ValueError("T has %d rows, plan has R1=%d" % (T.shape[0], plan.R1))
     h0 = torch.empty((plan.B * plan.N, D), dtype=torch.float32, device=T.device)
+    ws = plan.walk_workspace(D, 1)
     with torch.cuda.device(T.device):
         _lib.check(lib.gnnrag_typelayer(C.byref(plan.c), T.data_ptr(), int(use_w_rel), h0.data_ptr(), D,
-                                        _stream()), "gnnrag_typelayer")
+                                        ws.data_ptr(), ws.numel(), _stream()), "gnnrag_typelayer")
     return h0
 
 
@@ -227,17 +292,19 @@ class LayerWorkspace:
         self.key = None
         self.buf = None
 
-    def get(self, B, N, R1, D, I, device) -> torch.Tensor:
-        key = (B, N, R1, D, I, str(device))
+    def get(self, plan: "CsrPlan", D, I, device) -> torch.Tensor:
+        key = (plan.B, plan.N, plan.R1, plan.F, D, I, str(device))
         if key != self.key:
-            nbytes = _lib.load().gnnrag_layer_workspace_bytes(B, N, R1, D, I)
+            nbytes = _lib.load().gnnrag_layer_workspace_bytes(C.byref(plan.c), D, I)
+            self.buf = None                      # release the old buffer before taking the new one
             self.buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
             self.key = key
         return self.buf
 
 
 def reason_layer(plan: CsrPlan, h, dist, ins, relfeat, relfeat_inv, W_rel, b_rel, W_e2e, b_e2e, w_score,
-                 b_score, mask, pos=None, pos_inv=None, ws: Optional[LayerWorkspace] = None):
+                 b_score, mask, pos=None, pos_inv=None, ws: Optional[LayerWorkspace] = None,
+                 path: int = _lib.PATH_AUTO):
     """One ReasonGNNLayer.forward (reasongnn.py:134-174) = ONE call into the library.
     Returns (h_out [B,N,D], score [B,N], dist_out [B,N])."""
     lib = _lib.load()
@@ -265,7 +332,7 @@ def reason_layer(plan: CsrPlan, h, dist, ins, relfeat, relfeat_inv, W_rel, b_rel
         if pos.shape[1] != D or pos_rows > R1:
             raise ValueError("pos_emb must be [<=R1, D]")
     ws = ws or LayerWorkspace()
-    wbuf = ws.get(B, N, R1, D, I, h.device)
+    wbuf = ws.get(plan, D, I, h.device)
     h_out = torch.empty((B, N, D), dtype=torch.float32, device=h.device)
     score = torch.empty((B, N), dtype=torch.float32, device=h.device)
     dist_out = torch.empty((B, N), dtype=torch.float32, device=h.device)
@@ -275,7 +342,7 @@ def reason_layer(plan: CsrPlan, h, dist, ins, relfeat, relfeat_inv, W_rel, b_rel
             relfeat_inv.data_ptr(), W_rel.data_ptr(), b_rel.data_ptr(), _ptr(pos), _ptr(pos_inv), pos_rows,
             W_e2e.data_ptr(), b_e2e.data_ptr(), w_score.data_ptr(), b_score.data_ptr(), mask.data_ptr(),
             h_out.data_ptr(), score.data_ptr(), dist_out.data_ptr(), wbuf.data_ptr(), wbuf.numel(), D, I,
-            _stream()), "gnnrag_reason_layer")
+            int(path), _stream()), "gnnrag_reason_layer")
     return h_out, score, dist_out
 
 

@@ -17,8 +17,10 @@ def layer_args(cfg, use_cuda=True) -> dict:
                 pos_emb=cfg.pos_emb, linear_dropout=0.0)
 
 
-def build_layer(cfg, batch, params: dict, device) -> ReasonGNNLayer:
+def build_layer(cfg, batch, params: dict, device, path: int = None) -> ReasonGNNLayer:
     layer = ReasonGNNLayer(layer_args(cfg), batch.num_entity, cfg.num_kb_relation, cfg.D, "bfs")
+    if path is not None:
+        layer.path = path
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in params.items() if not k.startswith("type_layer.")}
     layer.load_state_dict(sd, strict=True)
     return layer.to(device).eval()
@@ -72,11 +74,12 @@ def run_layers(layer: ReasonGNNLayer, cfg, dev: DeviceInputs, record: bool = Fal
 
 
 @torch.no_grad()
-def run_stack(batch, feats: dict, params: dict, device, *, use_type_layer=False, norm_rel=False):
+def run_stack(batch, feats: dict, params: dict, device, *, use_type_layer=False, norm_rel=False,
+              path: int = None):
     """Mirror of ``oracle.*.run_stack`` on the HIP path."""
     cfg = batch.cfg
     dev = DeviceInputs(batch, feats, device)
-    layer = build_layer(cfg, batch, params, device)
+    layer = build_layer(cfg, batch, params, device, path)
     out = {}
     if use_type_layer:
         tl = build_type_layer(cfg, params, device, norm_rel)

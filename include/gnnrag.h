@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GNNRAG_ABI_VERSION 1
+#define GNNRAG_ABI_VERSION 2
 
 #define GNNRAG_E_BADARG      (-1)  /* null pointer / negative size / inconsistent sizes   */
 #define GNNRAG_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set (see DESIGN)  */
@@ -57,9 +57,11 @@ typedef struct gnnrag_csr {
   float*   w_rel[2];    /* [F] weight_rel_list (TypeLayer norm_rel, layer_init.py:39-40)
                                       or NULL                                              */
   int32_t* heavy[2];    /* [heavy_cap] list of heavy destination nodes                     */
-  int32_t* n_heavy;     /* [2] device counters                                             */
+  int32_t* chunk_off[2];/* [heavy_cap+1] first 256-fact chunk of each heavy node (prefix)  */
+  int32_t* n_heavy;     /* [2] device counters: heavy nodes per direction                  */
+  int32_t* n_chunks;    /* [2] device counters: heavy chunks per direction                 */
   int32_t  heavy_cap;
-  int32_t  reserved_;
+  int32_t  max_chunks;  /* upper bound of n_chunks[d] (sizes the partial-sum workspace)    */
 } gnnrag_csr;
 
 /* Bytes of caller-owned device memory a gnnrag_csr needs (persistent part / build scratch). */
@@ -96,9 +98,20 @@ int gnnrag_linear(const float* A, int64_t M, int32_t K, const float* W, const fl
  * = reason_layer (reasongnn.py:61-89, d=0) and reason_layer_inv (reasongnn.py:91-116, d=1)
  * for every instruction i, in the concat order of reasongnn.py:150-158.
  * dist [B*N], ins [B,I,D], T_fwd/T_inv [R1,D], agg [B*N, 2*I*D]. */
+size_t gnnrag_aggregate_workspace_bytes(const gnnrag_csr* csr, int32_t D, int32_t I);
 int gnnrag_aggregate(const gnnrag_csr* csr, const float* dist, const float* ins,
                      const float* T_fwd, const float* T_inv, float* agg,
-                     int32_t D, int32_t I, gnnrag_stream_t stream);
+                     int32_t D, int32_t I, void* workspace, size_t workspace_bytes,
+                     gnnrag_stream_t stream);
+
+/* Fused form of the same aggregation: e2e_linear is linear over the concatenated blocks, so it is
+ * applied to the per-question relation tables first (gnnrag_relation_tables) and the walk emits
+ *   out[n,:] = sum_d sum_{f: dst_d(f)=n} w_f * dist[src_d(f)] * P[d, n/N, rel_f, :]      [B*N, D]
+ * = sum_k W_e2e[:, block k] . agg[n,k,:], i.e. the neighbour part of reasongnn.py:161-163 without
+ * ever writing agg.  P [2,B,R1,D].  workspace: gnnrag_aggregate_workspace_bytes(csr, D, 1). */
+int gnnrag_aggregate_fused(const gnnrag_csr* csr, const float* dist, const float* P, float* out,
+                           int32_t D, void* workspace, size_t workspace_bytes,
+                           gnnrag_stream_t stream);
 
 /* h_out = relu(e2e_linear(cat(h, agg)))            (reasongnn.py:161-163)
  * score = score_func(h_out) + (1 - mask) * -1e11   (reasongnn.py:165-168), mask add in fp32.
@@ -114,15 +127,37 @@ int gnnrag_masked_softmax(const float* score, float* dist, int32_t B, int32_t N,
 
 /* h0[n,:] = relu( sum_{tail_f=n} v_f T[rel_f,:] + sum_{head_f=n} v_f T[rel_f,:] ),
  * v_f = w_rel if use_w_rel else 1   (TypeLayer.forward, layer_init.py:53-57);
- * T [R1,D] = kb_self_linear(rel_features) from gnnrag_linear. */
+ * T [R1,D] = kb_self_linear(rel_features) from gnnrag_linear.
+ * workspace: gnnrag_aggregate_workspace_bytes(csr, D, 1). */
 int gnnrag_typelayer(const gnnrag_csr* csr, const float* T, int use_w_rel, float* h0,
-                     int32_t D, gnnrag_stream_t stream);
+                     int32_t D, void* workspace, size_t workspace_bytes, gnnrag_stream_t stream);
+
+/* Per-question relation tables of the fused path:
+ *   P[d,b,r,:] = sum_i W_e2e[:, (1+2i+d)D : (2+2i+d)D] . relu(T_d[r,:] * ins[b,i,:])      [2,B,R1,D]
+ * (the e2e_linear column blocks in the concat order of reasongnn.py:150-161).  The operand
+ * relu(T_d * ins) is generated inside the GEMM's tile loader and never stored. */
+int gnnrag_relation_tables(const float* T_fwd, const float* T_inv, const float* ins, const float* W_e2e,
+                           float* P, int32_t B, int32_t R1, int32_t D, int32_t I, gnnrag_stream_t stream);
+
+/* h_out = relu(h . W_e2e[:, 0:D]^T + b + nbr), nbr [BN,D] from gnnrag_aggregate_fused; score as in
+ * gnnrag_update_score.  Together: reasongnn.py:161-168. */
+int gnnrag_update_score_fused(const float* h, const float* nbr, const float* W_e2e, const float* b,
+                              const float* w_s, const float* b_s, const float* mask,
+                              float* h_out, float* score, int64_t BN, int32_t D, int32_t I,
+                              gnnrag_stream_t stream);
 
 /* One whole ReasonGNNLayer.forward (reasongnn.py:134-174) enqueued with a single call:
- * rel transform (both directions) -> aggregate -> update+score -> softmax.
+ * rel transform (both directions) -> aggregation -> update+score -> softmax.
+ * path: GNNRAG_PATH_UNFUSED = aggregate [BN,2I*D] then one [(2I+1)D -> D] GEMM (the reference's
+ * operator boundaries); GNNRAG_PATH_FUSED = relation tables -> fused aggregation -> self-block
+ * GEMM (2.3x fewer flops and 4x less aggregation traffic when 2*B*R1*I < ~0.8*B*N*2I);
+ * GNNRAG_PATH_AUTO picks by that flop model.  Results agree to fp32 rounding (re-association).
  * pos_fwd/pos_inv: pos_emb{step}.weight / pos_emb_inv{step}.weight [pos_rows,D] or NULL.
  * workspace: gnnrag_layer_workspace_bytes() bytes of device scratch. */
-size_t gnnrag_layer_workspace_bytes(int32_t B, int32_t N, int32_t R1, int32_t D, int32_t I);
+#define GNNRAG_PATH_AUTO    0
+#define GNNRAG_PATH_UNFUSED 1
+#define GNNRAG_PATH_FUSED   2
+size_t gnnrag_layer_workspace_bytes(const gnnrag_csr* csr, int32_t D, int32_t I);
 int gnnrag_reason_layer(const gnnrag_csr* csr,
                         const float* h, const float* dist, const float* ins,
                         const float* relfeat_fwd, const float* relfeat_inv,
@@ -132,7 +167,7 @@ int gnnrag_reason_layer(const gnnrag_csr* csr,
                         const float* w_score, const float* b_score, const float* mask,
                         float* h_out, float* score_out, float* dist_out,
                         void* workspace, size_t workspace_bytes,
-                        int32_t D, int32_t I, gnnrag_stream_t stream);
+                        int32_t D, int32_t I, int32_t path, gnnrag_stream_t stream);
 
 /* Plain HBM copy kernel (float4 per lane) used by bench.py to measure the achievable
  * streaming ceiling next to the 8 TB/s spec.  n = number of floats (multiple of 4). */

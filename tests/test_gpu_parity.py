@@ -56,6 +56,7 @@ def test_csr_plan_bit_exact(dev, name):
         np.testing.assert_array_equal(got["w_rel"][d], wrl[want["perm%d" % d]])
         deg = np.diff(want["row_ptr%d" % d])
         np.testing.assert_array_equal(got["heavy%d" % d], np.flatnonzero(deg > 256).astype(np.int32))
+        assert got["n_chunks"][d] == int(np.ceil(deg[deg > 256] / 256).sum())
     if name == "mid":
         assert got["n_heavy"].sum() > 0, "the Zipf hub must exercise the heavy-row path"
 
@@ -148,11 +149,12 @@ def test_aggregate_and_update_vs_np64(dev, cfgname):
         np.testing.assert_allclose(got_dist, nd, rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("path", [1, 2], ids=["unfused", "fused"])
 @pytest.mark.parametrize("name", ["layer_d200.npz", "layer_d50.npz"])
-def test_layer_stack_matches_reference_fixture(dev, name):
+def test_layer_stack_matches_reference_fixture(dev, name, path):
     from gnnrag_amd import stack
     cfg, batch, feats, params, ref = load_golden(name)
-    out = stack.run_stack(batch, feats, params, dev)
+    out = stack.run_stack(batch, feats, params, dev, path=path)
     mask = batch.local_entity != batch.num_entity
     for c in range(cfg.T * cfg.L):
         dh = np.abs(out["h"][c] - ref["h"][c]).max()
@@ -215,7 +217,69 @@ def test_rearev_call_site_fixture(dev):
     assert (dist.cpu().numpy().argmax(1) == z["pred"]).all()          # Hits@1 decisions identical
 
 
-def test_mid_size_vs_torch_cpu_oracle(dev):
+@pytest.mark.parametrize("cfgname", ["tiny", "tiny50", "hub"])
+def test_fused_kernels_vs_np64(dev, cfgname):
+    """The fused path's own kernels (relation tables, fused walk incl. heavy chunks and the
+    XCD-aware order, self-block update) against the float64 oracle."""
+    import oracle.rearev_np64 as onp
+    from gnnrag_amd import ops, synth
+    if cfgname == "hub":
+        cfg = synth.GraphConfig(name="hub", B=3, N=600, E=4000, R=20, D=200, I=2, L=1, seed=3)
+    else:
+        cfg = synth.CONFIGS[cfgname]
+    batch = synth.make_batch(cfg)
+    feats = synth.make_features(cfg)
+    params = synth.make_layer_params(cfg)
+    B, N, D, I = cfg.B, cfg.N, cfg.D, cfg.I
+    mask = (batch.local_entity != batch.num_entity).astype(np.float32)
+    rng = np.random.default_rng(0)
+    dense = rng.random((B, N)).astype(np.float32)
+    dense /= dense.sum(1, keepdims=True)
+    et = batch.edge_tuple
+    plan = ops.CsrPlan(et[0], et[1], et[2], B, N, cfg.R1, dev)
+    if cfg.normalized_gnn:
+        plan.attach_w_gnn(et[5])
+    W_e = params["e2e_linear0.weight"].astype(np.float64)
+    for prior in (batch.seed_dist.astype(np.float32), dense):
+        score, nd, hn, agg = onp.layer_call(et, B, N, feats["h0"], mask, prior, feats["ins"][0], params, 0,
+                                            feats["rel_features"], feats["rel_features_inv"],
+                                            normalized_gnn=cfg.normalized_gnn, use_posemb=cfg.pos_emb)
+        want_nbr = agg.reshape(B * N, 2 * I * D) @ W_e[:, D:].T
+        rf, rfi, Wd, bd = _to_dev(dev, feats["rel_features"], feats["rel_features_inv"],
+                                  params["rel_linear0.weight"], params["rel_linear0.bias"])
+        pos = posi = None
+        if cfg.pos_emb:
+            pos, posi = _to_dev(dev, params["pos_emb0.weight"], params["pos_emb_inv0.weight"])
+        T_f = ops.linear(rf, Wd, bd, pos)
+        T_i = ops.linear(rfi, Wd, bd, posi)
+        dist_d, ins_d, We = _to_dev(dev, prior, feats["ins"][0], params["e2e_linear0.weight"])
+        P = ops.relation_tables(T_f, T_i, ins_d, We)
+        # tables vs fp64
+        Tn = [feats["rel_features"].astype(np.float64) @ params["rel_linear0.weight"].astype(np.float64).T
+              + params["rel_linear0.bias"], feats["rel_features_inv"].astype(np.float64)
+              @ params["rel_linear0.weight"].astype(np.float64).T + params["rel_linear0.bias"]]
+        if cfg.pos_emb:
+            Tn[0][: cfg.num_kb_relation] += params["pos_emb0.weight"]
+            Tn[1][: cfg.num_kb_relation] += params["pos_emb_inv0.weight"]
+        Pw = np.zeros((2, B, cfg.R1, D))
+        for d in range(2):
+            for i in range(I):
+                blk = W_e[:, (1 + 2 * i + d) * D:(2 + 2 * i + d) * D]
+                Pw[d] += np.maximum(Tn[d][None] * feats["ins"][0][:, i, None, :].astype(np.float64), 0) @ blk.T
+        np.testing.assert_allclose(P.cpu().numpy(), Pw, rtol=0, atol=TOL_INTERNAL * max(1.0, np.abs(Pw).max()))
+        nbr = ops.aggregate_fused(plan, dist_d, P)
+        np.testing.assert_allclose(nbr.cpu().numpy(), want_nbr, rtol=0,
+                                   atol=TOL_INTERNAL * max(1.0, np.abs(want_nbr).max()))
+        h_d, be, ws, bs, mk = _to_dev(dev, feats["h0"].reshape(B * N, D), params["e2e_linear0.bias"],
+                                      params["score_func.weight"], params["score_func.bias"], mask)
+        h_out, sc = ops.update_score_fused(h_d, nbr, We, be, ws, bs, mk, I)
+        np.testing.assert_allclose(h_out.cpu().numpy(), hn.reshape(B * N, D), rtol=0, atol=TOL_INTERNAL)
+        valid = mask.reshape(-1) > 0
+        np.testing.assert_allclose(sc.cpu().numpy()[valid], score.reshape(-1)[valid], rtol=0, atol=TOL_INTERNAL)
+
+
+@pytest.mark.parametrize("path", [1, 2], ids=["unfused", "fused"])
+def test_mid_size_vs_torch_cpu_oracle(dev, path):
     """C2-shaped questions (N=2000, E=10000 Zipf, hubs > 256 in-degree) at a batch the CPU
     restatement finishes in seconds."""
     import oracle.rearev_torch_cpu as otorch
@@ -225,14 +289,15 @@ def test_mid_size_vs_torch_cpu_oracle(dev):
     feats = synth.make_features(cfg)
     params = synth.make_layer_params(cfg)
     want = otorch.run_stack(batch, feats, params)
-    got = stack.run_stack(batch, feats, params, dev)
+    got = stack.run_stack(batch, feats, params, dev, path=path)
     for c in range(cfg.T * cfg.L):
         assert np.abs(got["h"][c] - want["h"][c]).max() <= TOL_STATED, c
         assert np.abs(got["dist"][c] - want["dist"][c]).max() <= TOL_STATED, c
         assert (got["dist"][c].argmax(1) == want["dist"][c].argmax(1)).all()
 
 
-def test_full_size_properties_c2(dev):
+@pytest.mark.parametrize("path", [1, 2], ids=["unfused", "fused"])
+def test_full_size_properties_c2(dev, path):
     """BASELINE config C2 at full size through size-independent properties: probabilities sum
     to 1 and vanish on masked slots; the aggregation is linear in the prior; two runs are
     bit-identical; a batch split into two shards reproduces the whole batch bit for bit."""
@@ -242,7 +307,7 @@ def test_full_size_properties_c2(dev):
     feats = synth.make_features(cfg)
     params = synth.make_layer_params(cfg)
     devin = stack.DeviceInputs(batch, feats, dev)
-    layer = stack.build_layer(cfg, batch, params, dev)
+    layer = stack.build_layer(cfg, batch, params, dev, path)
     stack.init_reason(layer, batch, devin, devin.h0)
     dist, _ = stack.run_layers(layer, cfg, devin)
     h_full = layer.local_entity_emb.clone()
@@ -280,7 +345,7 @@ def test_full_size_properties_c2(dev):
         sfe["h0"] = feats["h0"][lo:hi]
         sfe["ins"] = feats["ins"][:, lo:hi]
         sdev = stack.DeviceInputs(sub, sfe, dev)
-        slayer = stack.build_layer(sub.cfg, sub, params, dev)
+        slayer = stack.build_layer(sub.cfg, sub, params, dev, path)
         stack.init_reason(slayer, sub, sdev, sdev.h0)
         sd, _ = stack.run_layers(slayer, sub.cfg, sdev)
         parts.append(sd)
