@@ -72,11 +72,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("GNNRAG_LIB", LIB_PATH)     # experiment builds (tools/tune_variants.py)
+    if not os.path.exists(path):
         raise GnnragError(
             "HIP extension %s is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)           # AttributeError if the symbol is missing: fail loudly
         fn.restype = res

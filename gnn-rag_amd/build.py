@@ -48,6 +48,34 @@ def _deps():
     return d
 
 
+def build_variant(name: str, defines: dict, verbose: bool = False) -> str:
+    """Experiment builds: lib/exp_<name>.so compiled with extra -D switches (tools/tune_variants.py)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = _hipcc()
+    objdir = os.path.join(LIBDIR, "obj_" + name)
+    os.makedirs(objdir, exist_ok=True)
+    extra = ["-D%s=%s" % kv for kv in defines.items()]
+
+    def cc(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        r = subprocess.run([hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s (%s):\n%s" % (src, name, r.stderr[-4000:]))
+        return obj
+
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(cc, SOURCES))
+    out = os.path.join(LIBDIR, "exp_%s.so" % name)
+    r = subprocess.run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs,
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed (%s):\n%s" % (name, r.stderr[-4000:]))
+    if verbose:
+        print("built", out)
+    return out
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     stamp = os.path.join(LIBDIR, "build.sha256")

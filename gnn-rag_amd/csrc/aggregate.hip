@@ -33,6 +33,10 @@
 //    deterministic, no atomics, scales to hubs with 10^5 facts.
 #include "gnnrag_common.h"
 
+#ifndef GNNRAG_SLICE_ABLATE
+#define GNNRAG_SLICE_ABLATE 0   // timing experiments only (tools/tune_variants.py): 1 no staging, 2 no hubs, 4 no sets, 8 no stores
+#endif
+
 namespace gnnrag {
 
 template <int VEC> struct VecT;
@@ -82,6 +86,7 @@ struct WalkArgs {
   int32_t BN, N, D, I, i0, R1, B;
   int32_t bpg;                // FUSED: workgroups per question for the XCD-aware mapping (0 = off)
   int32_t dir;                // k_heavy_reduce in read-modify-write modes: direction of this launch
+  int32_t heavy_only;         // host side: the light rows were already walked by another kernel
 };
 
 template <int MODE, int NI> struct AccN { static constexpr int n = (MODE == MODE_REASON) ? NI : 1; };
@@ -373,7 +378,16 @@ __global__ __launch_bounds__(256) void k_heavy_reduce(const WalkArgs a, int na) 
     }
     for (int x = lane; x < na * D; x += 64) {
       float s = 0.f;
-      for (int c = c0; c < c1; ++c) s += a.partial[((size_t)d * a.max_chunks + c) * (na * D) + x];
+      const float* pp = a.partial + ((size_t)d * a.max_chunks) * (na * D) + x;
+      int c = c0;
+      for (; c + 8 <= c1; c += 8) {                  // 8 independent loads in flight, summed in chunk order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = pp[(size_t)(c + u) * (na * D)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; c < c1; ++c) s += pp[(size_t)c * (na * D)];
       if (MODE == MODE_REASON) {
         const int i = x / D, cc = x - i * D;
         a.out[(size_t)n * (2 * a.I) * D + (size_t)(2 * (a.i0 + i) + d) * D + cc] = s;
@@ -383,6 +397,220 @@ __global__ __launch_bounds__(256) void k_heavy_reduce(const WalkArgs a, int na) 
         a.out[(size_t)n * D + x] = v;
       }
     }
+  }
+}
+
+// ---- fused walk through LDS: relation-table column slices ------------------------------------
+// Gathering a D*4-byte table row per fact from L2 (1.2 GB per layer call at C2) is what bounds the
+// walk above.  When the per-question tables are small enough, they are staged in LDS instead:
+// a workgroup owns (question g, 16-column slice c): it copies P[0:2, g, :, 16c:16c+16] (2*R1*64 B,
+// 77 KB at R1 = 602) into LDS once, then walks ALL nodes of question g gathering 64-byte row
+// slices from LDS.  The priors are precomputed once per call by k_fact_prior as (p, rel) pairs
+// in sorted order, so the 13 slice workgroups of a question re-read a compact coalesced stream
+// instead of redoing the dist[src] gather.  Four lanes own one node (float4 each), 16 nodes per
+// wave; a lane group reads 4 consecutive (p, rel) pairs with one 32-byte coalesced access and
+// shares them with width-4 shuffles.  Node sets are handed out by an LDS ticket so a set with a
+// hub does not hold up its wave's other sets.  All slice workgroups of a question run on one
+// XCD (workgroup b -> XCD b % 8), so their partial-line writes to out[] merge in that L2.
+constexpr int kSliceW = 16;                 // floats per slice (4 lanes x float4)
+constexpr int kSliceThreads = 1024;
+
+__global__ __launch_bounds__(256) void k_fact_prior(const int2* __restrict__ e0, const int2* __restrict__ e1,
+                                                    const float* __restrict__ w0, const float* __restrict__ w1,
+                                                    const float* __restrict__ dist, int64_t F,
+                                                    int2* __restrict__ pr) {
+  const int d = blockIdx.y;
+  const int2* edge = d ? e1 : e0;
+  const float* w = d ? w1 : w0;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= F) return;
+  float p;
+  int r;
+  load_fact<MODE_FUSED>(edge, w, dist, 0, (int)i, (int)F, p, r);
+  pr[(size_t)d * F + i] = make_int2(__float_as_int(p), r);
+}
+
+constexpr int kSliceHubDeg = 512;   // nodes with more facts in a direction are walked by wave teams
+
+// one node's rows in both directions + its first 4 (p, rel) pairs per direction
+struct SetRows {
+  int beg[2], len[2];
+  int2 first[2];
+  int n;
+  bool valid, hub;
+};
+
+__device__ __forceinline__ void set_load_rows(SetRows& s, const WalkArgs& a, int g, int set, int nsets, int grp) {
+  const int nl = set * 16 + grp;
+  s.valid = set < nsets && nl < a.N;
+  s.n = g * a.N + (s.valid ? nl : 0);
+  s.hub = false;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    s.beg[d] = 0;
+    s.len[d] = 0;
+    if (s.valid) {
+      s.beg[d] = a.row_ptr[d][s.n];
+      s.len[d] = a.row_ptr[d][s.n + 1] - s.beg[d];
+      s.hub |= s.len[d] > kSliceHubDeg;
+    }
+  }
+}
+
+__device__ __forceinline__ void set_load_first(SetRows& s, const int2* const (&prd)[2], int sub) {
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+    s.first[d] = (s.valid && !s.hub && sub < s.len[d]) ? prd[d][s.beg[d] + sub] : make_int2(0, 0);
+}
+
+__global__ __launch_bounds__(kSliceThreads) void k_walk_slice(const WalkArgs a, const int2* __restrict__ pr,
+                                                              int64_t F, int nslice, int hcap) {
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];
+  float* Ts = s_mem;                                   // [2][R1][16]
+  int* ctl = reinterpret_cast<int*>(s_mem + (size_t)2 * a.R1 * kSliceW);   // [0] set ticket, [1] hub count
+  int* hlist = ctl + 4;                                // [hcap][5]: node, beg0, len0, beg1, len1
+  float* red = reinterpret_cast<float*>(hlist + 5 * hcap);   // [16 waves][16 floats]
+  // XCD-aware order: the nslice workgroups of question g all land on XCD g % 8
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int g = (slot / nslice) * 8 + xcd;
+  if (g >= a.B) return;
+  const int c = slot % nslice;
+  const int col0 = c * kSliceW;
+  const int D = a.D, R1 = a.R1, N = a.N;
+  const int tid = threadIdx.x;
+  if (tid < 4) ctl[tid] = 0;
+  // stage the two table slices (float4 granules; rows are D*4 bytes apart in P)
+  for (int idx = tid; idx < ((GNNRAG_SLICE_ABLATE & 1) ? 0 : 2 * R1 * 4); idx += kSliceThreads) {
+    const int d = idx / (R1 * 4);
+    const int rem = idx - d * (R1 * 4);
+    const int r = rem >> 2, k = rem & 3;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (col0 + 4 * k < D)
+      v = *reinterpret_cast<const f32x4*>(a.T[d] + ((size_t)g * R1 + r) * D + col0 + 4 * k);
+    *reinterpret_cast<f32x4*>(Ts + ((size_t)d * R1 + r) * kSliceW + 4 * k) = v;
+  }
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int grp = lane >> 2, sub = lane & 3;
+  const int nsets = (N + 15) / 16;
+  const bool col_ok = col0 + 4 * sub < D;
+  const int2* const prd[2] = {pr, pr + F};
+  const float* Td[2] = {Ts + 4 * sub, Ts + (size_t)R1 * kSliceW + 4 * sub};
+
+  // ---- ordinary nodes: 4 lanes per node, 16 nodes (a "set") per wave step, sets handed out by an
+  // LDS ticket.  The dependent chain ticket -> row pointers -> first pairs -> table slices is
+  // software pipelined over three sets: while set i is walked, the first pairs of set i+1 and the
+  // row pointers of set i+2 are already in flight.
+  auto ticket = [&]() {
+    int t = 0;
+    if (lane == 0) t = atomicAdd(&ctl[0], 1);
+    return __builtin_amdgcn_readfirstlane(t);
+  };
+  SetRows s0, s1, s2;
+  int t0 = (GNNRAG_SLICE_ABLATE & 4) ? nsets : ticket();
+  set_load_rows(s0, a, g, t0, nsets, grp);
+  int t1 = t0 < nsets ? ticket() : nsets;
+  set_load_rows(s1, a, g, t1, nsets, grp);
+  set_load_first(s0, prd, sub);
+  while (t0 < nsets) {
+    const int t2 = t1 < nsets ? ticket() : nsets;
+    set_load_rows(s2, a, g, t2, nsets, grp);
+    set_load_first(s1, prd, sub);
+
+    if (s0.valid && s0.hub) {
+      // walked by wave teams below; if the list is full the owner group walks it itself
+      int pos = hcap;
+      if (sub == 0) pos = atomicAdd(&ctl[1], 1);
+      pos = __shfl(pos, 0, 4);
+      if (pos < hcap) {
+        if (sub == 0) {
+          int* e = hlist + 5 * pos;
+          e[0] = s0.n; e[1] = s0.beg[0]; e[2] = s0.len[0]; e[3] = s0.beg[1]; e[4] = s0.len[1];
+        }
+      } else {
+        s0.hub = false;
+        set_load_first(s0, prd, sub);
+      }
+    }
+    if (s0.valid && !s0.hub) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const int beg = s0.beg[d], len = s0.len[d];
+        int2 cur = s0.first[d];
+        // 4 facts per step per node; the next step's pairs are requested before this step's are used
+        for (int j = 0; j < len; j += 4) {
+          int2 nxt = make_int2(0, 0);
+          if (j + 4 + sub < len) nxt = prd[d][beg + j + 4 + sub];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float pk = __int_as_float(__shfl(cur.x, k, 4));
+            const int rk = __shfl(cur.y, k, 4);
+            if (pk != 0.f) acc += pk * *reinterpret_cast<const f32x4*>(Td[d] + (size_t)rk * kSliceW);
+          }
+          cur = nxt;
+        }
+      }
+      if (col_ok && (!(GNNRAG_SLICE_ABLATE & 8) || acc[0] == 12345.f))
+        *reinterpret_cast<f32x4*>(a.out + (size_t)s0.n * D + col0 + 4 * sub) = acc;
+    }
+    s0 = s1; t0 = t1;
+    s1 = s2; t1 = t2;
+  }
+  __syncthreads();
+
+  // ---- hubs: a team of 4 waves per node, 4 hubs per round.  A row is cut into 64-fact steps (64
+  // consecutive pairs = 512 coalesced bytes); team wave w takes steps w, w+4, ... and requests up
+  // to 8 of them before consuming.  Inside a step lane group k owns facts 4k..4k+3.  Partial sums
+  // are combined by a fixed xor tree inside the wave and in wave order inside the team (through
+  // LDS): deterministic, no atomics.
+  const int nhub = (GNNRAG_SLICE_ABLATE & 2) ? 0 : min(ctl[1], hcap);
+  const int team = wave >> 2, tw = wave & 3;
+  for (int h0 = 0; h0 < nhub; h0 += 4) {
+    const int h = h0 + team;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int n = 0;
+    if (h < nhub) {
+      const int* e = hlist + 5 * h;
+      n = e[0];
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const int beg = e[1 + 2 * d], len = e[2 + 2 * d];
+        const int nsteps = (len + 63) >> 6;
+        for (int st = tw; st < nsteps; st += 4 * 8) {
+          int2 pairs[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int off = (st + 4 * u) * 64 + lane;
+            pairs[u] = (off < len) ? prd[d][beg + off] : make_int2(0, 0);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float pk = __int_as_float(__shfl(pairs[u].x, k, 4));
+              const int rk = __shfl(pairs[u].y, k, 4);
+              if (pk != 0.f) acc += pk * *reinterpret_cast<const f32x4*>(Td[d] + (size_t)rk * kSliceW);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 4; o < 64; o <<= 1) {
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) acc[e2] += __shfl_xor(acc[e2], o, 64);
+      }
+      if (grp == 0) *reinterpret_cast<f32x4*>(red + wave * 16 + 4 * sub) = acc;
+    }
+    __syncthreads();
+    if (h < nhub && tw == 0 && lane < 4) {
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(red + (team * 4 + w) * 16 + 4 * lane);
+      if (col0 + 4 * lane < D) *reinterpret_cast<f32x4*>(a.out + (size_t)n * D + col0 + 4 * lane) = t;
+    }
+    __syncthreads();
   }
 }
 
@@ -412,8 +640,10 @@ static int launch_one(WalkArgs a, hipStream_t stream) {
     a.bpg = a.N / groups_per_block;
     nblk = 8 * ((a.B + 7) / 8) * a.bpg;
   }
-  hipLaunchKernelGGL((k_walk_light<MODE, VEC, LPN, CPL, NI>), dim3(nblk), dim3(256), 0, stream, a);
-  GNNRAG_LAUNCH_CHECK();
+  if (!a.heavy_only) {
+    hipLaunchKernelGGL((k_walk_light<MODE, VEC, LPN, CPL, NI>), dim3(nblk), dim3(256), 0, stream, a);
+    GNNRAG_LAUNCH_CHECK();
+  }
   // heavy rows (count lives on the device: fixed grids, grid-stride loops, no host sync)
   hipLaunchKernelGGL((k_heavy_partial<MODE, VEC, CPL, NI>), dim3(512, 2), dim3(256), 0, stream, a);
   GNNRAG_LAUNCH_CHECK();
@@ -466,6 +696,17 @@ static int launch_walk(const WalkArgs& a, int ni, hipStream_t stream) {
 static size_t partial_bytes(const gnnrag_csr* csr, int D, int na) {
   return align_up((size_t)2 * (size_t)csr->max_chunks * (size_t)na * (size_t)D * sizeof(float), 256);
 }
+static size_t prior_bytes(const gnnrag_csr* csr) {
+  return align_up((size_t)2 * (size_t)(csr->F > 0 ? csr->F : 1) * sizeof(int2), 256);
+}
+constexpr int kSliceHeavyCap = 24;     // heavy nodes of one question kept in LDS (overflow: owner group walks them)
+static size_t slice_lds_bytes(int R1) {
+  return (size_t)2 * R1 * kSliceW * sizeof(float) + (4 + 5 * kSliceHeavyCap) * sizeof(int) + 16 * 16 * sizeof(float);
+}
+// the LDS variant needs the two table slices of a question in one CU's LDS (160 KB)
+static bool slice_walk_fits(const gnnrag_csr* csr, int D) {
+  return D % 4 == 0 && slice_lds_bytes(csr->R1) <= 160 * 1024 - 1024;
+}
 
 static int fill_common(WalkArgs& a, const gnnrag_csr* csr, int D, void* ws, size_t ws_bytes, int na) {
   for (int d = 0; d < 2; ++d) {
@@ -495,7 +736,7 @@ using namespace gnnrag;
 
 extern "C" size_t gnnrag_aggregate_workspace_bytes(const gnnrag_csr* csr, int32_t D, int32_t I) {
   if (!csr || D <= 0 || I <= 0) return 0;
-  return partial_bytes(csr, D, I < 3 ? I : 3);
+  return partial_bytes(csr, D, I < 3 ? I : 3) + prior_bytes(csr);
 }
 
 extern "C" int gnnrag_aggregate(const gnnrag_csr* csr, const float* dist, const float* ins,
@@ -526,8 +767,9 @@ extern "C" int gnnrag_aggregate(const gnnrag_csr* csr, const float* dist, const 
 
 extern "C" int gnnrag_aggregate_fused(const gnnrag_csr* csr, const float* dist, const float* P, float* out,
                                       int32_t D, void* workspace, size_t workspace_bytes,
-                                      gnnrag_stream_t stream) {
+                                      gnnrag_stream_t stream_) {
   if (!csr || !dist || !P || !out || D <= 0) return GNNRAG_E_BADARG;
+  hipStream_t stream = (hipStream_t)stream_;
   WalkArgs a;
   memset(&a, 0, sizeof(a));
   const int rc = fill_common(a, csr, D, workspace, workspace_bytes, 1);
@@ -539,7 +781,29 @@ extern "C" int gnnrag_aggregate_fused(const gnnrag_csr* csr, const float* dist, 
   a.dist = dist;
   a.out = out;
   a.I = 1;
-  return launch_walk<MODE_FUSED>(a, 1, (hipStream_t)stream);
+  if (!slice_walk_fits(csr, D)) return launch_walk<MODE_FUSED>(a, 1, stream);   // tables too big for LDS
+
+  if (workspace_bytes < partial_bytes(csr, D, 1) + prior_bytes(csr)) return GNNRAG_E_WORKSPACE;
+  int2* pr = (int2*)((char*)workspace + partial_bytes(csr, D, 1));
+  const int64_t F = csr->F;
+  if (F > 0) {
+    hipLaunchKernelGGL(k_fact_prior, dim3((unsigned)((F + 255) / 256), 2), dim3(256), 0, stream, a.edge[0],
+                       a.edge[1], a.w[0], a.w[1], dist, F, pr);
+    GNNRAG_LAUNCH_CHECK();
+  }
+  const int nslice = (D + kSliceW - 1) / kSliceW;
+  const size_t lds = slice_lds_bytes(csr->R1);
+  static bool attr_set = false;   // raising the dynamic-LDS cap is idempotent; do it once per process
+  if (!attr_set) {
+    GNNRAG_HIP(hipFuncSetAttribute((const void*)k_walk_slice, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+    attr_set = true;
+  }
+  const int nblk = 8 * ((csr->B + 7) / 8) * nslice;
+  hipLaunchKernelGGL(k_walk_slice, dim3(nblk), dim3(kSliceThreads), lds, stream, a, (const int2*)pr, F, nslice,
+                     (int)kSliceHeavyCap);
+  GNNRAG_LAUNCH_CHECK();
+  return 0;   // hubs were walked inside the kernel (whole-wave pass), nothing to add afterwards
 }
 
 extern "C" int gnnrag_typelayer(const gnnrag_csr* csr, const float* T, int use_w_rel, float* h0, int32_t D,

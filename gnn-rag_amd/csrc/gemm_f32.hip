@@ -23,9 +23,22 @@
 // tile t+1 are issued before the MFMAs of tile t (register prefetch), two workgroups per CU.
 #include "gnnrag_common.h"
 
+// tuning switches (A/B-tested on MI355X with tools/tune_variants.py; defaults = fastest measured)
+#ifndef GNNRAG_GEMM_BRANCHLESS
+#define GNNRAG_GEMM_BRANCHLESS 0
+#endif
+#ifndef GNNRAG_GEMM_PREFETCH
+#define GNNRAG_GEMM_PREFETCH 0
+#endif
+#ifndef GNNRAG_GEMM_EPILOGUE
+#define GNNRAG_GEMM_EPILOGUE 1   // 0 = direct stores from the MFMA layout, 1 = staged through LDS (row-wise, coalesced)
+#endif
+#ifndef GNNRAG_GEMM_MT1_WAVES
+#define GNNRAG_GEMM_MT1_WAVES 3  // min waves/SIMD requested for the 64-row-tile variant
+#endif
+
 namespace gnnrag {
 
-constexpr int kBM = 128;   // rows per workgroup
 constexpr int kBK = 32;    // k per LDS tile
 constexpr int kLS = 40;    // LDS row stride (floats)
 
@@ -34,6 +47,7 @@ enum { EPI_LINEAR = 0, EPI_UPDATE = 1 };
 struct GemmArgs {
   const float* A0;      // [M, K0]  (plain: K0 = K; update: h, K0 = D)
   const float* A1;      // [M, K-K0] or nullptr (update: agg)
+  const float* A0b;     // AMODE_GEN: table of direction 1 (A0 = direction 0)
   const float* W;       // [Nout, K]
   const float* bias;    // [Nout] or nullptr
   const float* add;     // [add_rows, Nout] or nullptr
@@ -49,6 +63,7 @@ struct GemmArgs {
   // AMODE_GEN (per-question relation tables): row m = (b, r), column k = (i, kk):
   //   A[m,k] = relu(A0[r*D + kk] * A1[(b*I + i)*D + kk]),  W column = (1 + 2i + gen_dir)*D + kk
   int32_t gen_R1, gen_D, gen_I, gen_dir;
+  int32_t v4out;        // rows of C/add are 16-byte aligned and Nout % 4 == 0: float4 epilogue
 };
 
 enum { AMODE_PLAIN = 0, AMODE_GEN = 1 };
@@ -57,7 +72,15 @@ enum { AMODE_PLAIN = 0, AMODE_GEN = 1 };
 template <bool V4, int AMODE>
 __device__ __forceinline__ f32x4 load_a4(const GemmArgs& g, int m, int k) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#if GNNRAG_GEMM_BRANCHLESS
+  if constexpr (V4 && AMODE == AMODE_PLAIN) {
+    if (m >= g.M) { m = g.M - 1; k = g.K; }     // clamp the row, force the zero select below
+  } else {
+    if (m >= g.M) return v;
+  }
+#else
   if (m >= g.M) return v;
+#endif
   if constexpr (AMODE == AMODE_GEN) {
     // relu(T_d[r,:] * ins[b,i,:]) generated on the fly: the [B*R1, I*D] operand never exists in HBM
     if (k >= g.K) return v;
@@ -81,9 +104,20 @@ __device__ __forceinline__ f32x4 load_a4(const GemmArgs& g, int m, int k) {
     }
     return v;
   } else if constexpr (V4) {
-    // K0, K-K0 multiples of 4 and 16-byte aligned bases: a float4 never straddles the split
+    // K0, K-K0 multiples of 4 and 16-byte aligned bases: a float4 never straddles the split.
+#if GNNRAG_GEMM_BRANCHLESS
+    // Branch-free: out-of-range lanes read a clamped (valid) address and are zeroed afterwards,
+    // so the tile's loads issue back to back instead of one basic block each.
+    const bool in0 = k < g.K0;
+    const bool ok = k < g.K;
+    const float* p0 = g.A0 + (size_t)m * g.K0 + (in0 ? k : 0);
+    const float* p1 = g.A1 ? g.A1 + (size_t)m * (g.K - g.K0) + ((ok && !in0) ? k - g.K0 : 0) : p0;
+    const f32x4 x = *reinterpret_cast<const f32x4*>(in0 ? p0 : p1);
+    v = ok ? x : v;
+#else
     if (k < g.K0) v = *reinterpret_cast<const f32x4*>(g.A0 + (size_t)m * g.K0 + k);
     else if (k < g.K) v = *reinterpret_cast<const f32x4*>(g.A1 + (size_t)m * (g.K - g.K0) + (k - g.K0));
+#endif
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -109,53 +143,132 @@ __device__ __forceinline__ int w_col(const GemmArgs& g, int k) {
 template <bool V4, int AMODE>
 __device__ __forceinline__ f32x4 load_w4(const GemmArgs& g, int j, int k) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (j >= g.Nout) return v;
   if constexpr (V4) {
-    if (k < g.K) v = *reinterpret_cast<const f32x4*>(g.W + (size_t)j * g.ldw + w_col<AMODE>(g, k));
+#if GNNRAG_GEMM_BRANCHLESS
+    const bool ok = j < g.Nout && k < g.K;
+    const f32x4 x = *reinterpret_cast<const f32x4*>(g.W + (size_t)(ok ? j : 0) * g.ldw + w_col<AMODE>(g, ok ? k : 0));
+    v = ok ? x : v;
+#else
+    if (j < g.Nout && k < g.K) v = *reinterpret_cast<const f32x4*>(g.W + (size_t)j * g.ldw + w_col<AMODE>(g, k));
+#endif
   } else {
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
-      if (k + jj < g.K) v[jj] = g.W[(size_t)j * g.ldw + w_col<AMODE>(g, k + jj)];
+      if (j < g.Nout && k + jj < g.K) v[jj] = g.W[(size_t)j * g.ldw + w_col<AMODE>(g, k + jj)];
   }
   return v;
 }
 
-template <int NT, bool V4, int EPI, int AMODE>
-__global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs g) {
-  constexpr int WR = (NT * 16 + 31) / 32;  // W staging rounds (32 rows per round)
-  __shared__ __attribute__((aligned(16))) float As[kBM * kLS];
-  __shared__ __attribute__((aligned(16))) float Ws[NT * 16 * kLS];
+template <int NT, int MT, bool V4, int EPI, int AMODE>
+__global__ __launch_bounds__(256, (MT == 1 ? GNNRAG_GEMM_MT1_WAVES : 2)) void k_gemm_f32(GemmArgs g) {
+  constexpr int BM = 64 * MT;                 // rows per workgroup: 4 waves x MT accumulator row-tiles of 16
+  constexpr int AR = BM / 32;                 // A staging rounds (32 rows per round)
+  constexpr int WR = (NT * 16 + 31) / 32;     // W staging rounds (32 rows per round)
+  constexpr int LD = NT * 16 + 4;             // epilogue staging row stride (floats)
+  constexpr int kTileFloats = (BM + NT * 16) * kLS;
+  constexpr int kStageFloats = 4 * 8 * LD;     // epilogue: 8 rows per wave at a time
+  constexpr int kSmemFloats = kTileFloats > kStageFloats ? kTileFloats : kStageFloats;
+  __shared__ __attribute__((aligned(16))) float smem[kSmemFloats];
+  float* As = smem;
+  float* Ws = smem + BM * kLS;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int lr = tid >> 3;   // staging row 0..31
   const int kq = tid & 7;    // staging float4 within the 32-wide k tile
-  const int m0 = blockIdx.x * kBM;
+  const int m0 = blockIdx.x * BM;
   const int n0 = g.n0;
 
-  f32x4 acc[2][NT];
+  // AMODE_GEN: blockIdx.y = direction; per-thread row bases are fixed for the whole K loop and the
+  // (instruction i, column kk) of the thread's k position advances incrementally - no divisions
+  // in the loop.
+  const float* gen_t[AR];
+  const float* gen_q[AR];
+  int gen_i = 0, gen_kk = 0;
+  if constexpr (AMODE == AMODE_GEN) {
+    const int dir = blockIdx.y;
+    g.gen_dir = dir;
+    if (dir) g.A0 = g.A0b;
+    g.C += (size_t)dir * g.M * g.Nout;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+    for (int r = 0; r < AR; ++r) {
+      const int m = m0 + lr + 32 * r;
+      const int mm = m < g.M ? m : 0;
+      const int b = mm / g.gen_R1, rr = mm - b * g.gen_R1;
+      gen_t[r] = (m < g.M) ? g.A0 + (size_t)rr * g.gen_D : nullptr;
+      gen_q[r] = g.A1 + (size_t)b * g.gen_I * g.gen_D;
+    }
+    gen_i = (kq * 4) / g.gen_D;
+    gen_kk = kq * 4 - gen_i * g.gen_D;
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  f32x4 ra[4], rw[WR];
+  f32x4 ra[AR], rw[WR];
   const int nT = (g.K + kBK - 1) / kBK;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   auto gload = [&](int t) {
     const int k = t * kBK + kq * 4;
+    if constexpr (AMODE == AMODE_GEN && V4) {
+      const bool kok = k < g.K;
+      const int wcol = (1 + 2 * gen_i + g.gen_dir) * g.gen_D + gen_kk;
+#if GNNRAG_GEMM_BRANCHLESS
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ra[r] = load_a4<V4, AMODE>(g, m0 + lr + 32 * r, k);
+      for (int r = 0; r < AR; ++r) {
+        // branch-free: rows past M read row 0 / columns past K read column 0, then select zero
+        const float* tp = gen_t[r] ? gen_t[r] : g.A0;
+        const int kk = kok ? gen_kk : 0, ii = kok ? gen_i : 0;
+        const f32x4 tv = *reinterpret_cast<const f32x4*>(tp + kk);
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(gen_q[r] + (size_t)ii * g.gen_D + kk);
+        const f32x4 x = __builtin_elementwise_max(tv * qv, zero4);
+        ra[r] = (kok && gen_t[r]) ? x : zero4;
+      }
 #pragma unroll
-    for (int r = 0; r < WR; ++r) {
-      const int j = lr + 32 * r;
-      rw[r] = (j < NT * 16) ? load_w4<V4, AMODE>(g, n0 + j, k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < WR; ++r) {
+        const int j = lr + 32 * r;
+        const bool ok = j < NT * 16 && n0 + j < g.Nout && kok;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(g.W + (size_t)(ok ? n0 + j : 0) * g.ldw + (ok ? wcol : 0));
+        rw[r] = ok ? x : zero4;
+      }
+#else
+#pragma unroll
+      for (int r = 0; r < AR; ++r) {
+        ra[r] = zero4;
+        if (kok && gen_t[r]) {
+          const f32x4 tv = *reinterpret_cast<const f32x4*>(gen_t[r] + gen_kk);
+          const f32x4 qv = *reinterpret_cast<const f32x4*>(gen_q[r] + (size_t)gen_i * g.gen_D + gen_kk);
+          ra[r] = __builtin_elementwise_max(tv * qv, zero4);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < WR; ++r) {
+        const int j = lr + 32 * r;
+        rw[r] = zero4;
+        if (j < NT * 16 && n0 + j < g.Nout && kok)
+          rw[r] = *reinterpret_cast<const f32x4*>(g.W + (size_t)(n0 + j) * g.ldw + wcol);
+      }
+#endif
+      gen_kk += kBK;                       // next tile's column state
+      while (gen_kk >= g.gen_D) { gen_kk -= g.gen_D; ++gen_i; }
+    } else {
+#pragma unroll
+      for (int r = 0; r < AR; ++r) ra[r] = load_a4<V4, AMODE>(g, m0 + lr + 32 * r, k);
+#pragma unroll
+      for (int r = 0; r < WR; ++r) {
+        const int j = lr + 32 * r;
+        rw[r] = (j < NT * 16) ? load_w4<V4, AMODE>(g, n0 + j, k) : zero4;
+      }
     }
   };
   auto sstore = [&]() {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(&As[(lr + 32 * r) * kLS + kq * 4]) = ra[r];
+    for (int r = 0; r < AR; ++r) *reinterpret_cast<f32x4*>(&As[(lr + 32 * r) * kLS + kq * 4]) = ra[r];
 #pragma unroll
     for (int r = 0; r < WR; ++r) {
       const int j = lr + 32 * r;
@@ -171,22 +284,65 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs g) {
   const int fg = lane >> 4;  // k group
   for (int t = 0; t < nT; ++t) {
     if (t + 1 < nT) gload(t + 1);
+#if GNNRAG_GEMM_PREFETCH == 0
 #pragma unroll
     for (int c = 0; c < kBK / 16; ++c) {
-      f32x4 a[2];
+      f32x4 a[MT];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-        a[mt] = *reinterpret_cast<const f32x4*>(&As[(wave * 32 + mt * 16 + fr) * kLS + c * 16 + fg * 4]);
+      for (int mt = 0; mt < MT; ++mt)
+        a[mt] = *reinterpret_cast<const f32x4*>(&As[(wave * 16 * MT + mt * 16 + fr) * kLS + c * 16 + fg * 4]);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(&Ws[(nt * 16 + fr) * kLS + c * 16 + fg * 4]);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][s], b[s], acc[0][nt], 0, 0, 0);
-          acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][s], b[s], acc[1][nt], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], b[s], acc[mt][nt], 0, 0, 0);
         }
       }
     }
+#else
+    // fragments are read one step ahead of the MFMAs that consume them (LDS latency hidden)
+    const float* a_base = &As[(wave * 16 * MT + fr) * kLS + fg * 4];
+    const float* w_base = &Ws[fr * kLS + fg * 4];
+    constexpr int NSTEP = (kBK / 16) * NT;
+    f32x4 a[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(a_base + mt * 16 * kLS);
+    f32x4 bcur = *reinterpret_cast<const f32x4*>(w_base);
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+      const int nt = st % NT;
+      f32x4 bnxt = bcur;
+      f32x4 anxt[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) anxt[mt] = a[mt];
+      if (st + 1 < NSTEP) {
+        const int c2 = (st + 1) / NT, nt2 = (st + 1) % NT;
+        bnxt = *reinterpret_cast<const f32x4*>(w_base + nt2 * 16 * kLS + c2 * 16);
+        if (nt2 == 0) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            anxt[mt] = *reinterpret_cast<const f32x4*>(a_base + mt * 16 * kLS + c2 * 16);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], bcur[s], acc[mt][nt], 0, 0, 0);
+      }
+      bcur = bnxt;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = anxt[mt];
+#if GNNRAG_GEMM_PREFETCH == 2
+      // pin the emitted order: next step's fragment read first, then this step's MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT, 0);
+#endif
+    }
+#endif
     __syncthreads();
     if (t + 1 < nT) {
       sstore();
@@ -194,50 +350,138 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs g) {
     }
   }
 
-  // C/D layout of the 16x16 tile: column = lane & 15, row = (lane >> 4) * 4 + reg.
-  float part[2][4];
+#if GNNRAG_GEMM_EPILOGUE == 0
+  // C/D layout of the 16x16 tile: column = lane & 15, row = (lane >> 4) * 4 + reg; direct stores.
+  {
+    float part[MT][4];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) part[mt][r] = 0.f;
-
+      for (int r = 0; r < 4; ++r) part[mt][r] = 0.f;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int col = n0 + nt * 16 + fr;
-    const bool cok = col < g.Nout;
-    const float bia = (cok && g.bias) ? g.bias[col] : 0.f;
-    const float ws = (EPI == EPI_UPDATE && cok) ? g.w_s[col] : 0.f;
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = n0 + nt * 16 + fr;
+      const bool cok = col < g.Nout;
+      const float bia = (cok && g.bias) ? g.bias[col] : 0.f;
+      const float ws = (EPI == EPI_UPDATE && cok) ? g.w_s[col] : 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wave * 32 + mt * 16 + fg * 4 + r;
-        float v = acc[mt][nt][r] + bia;
-        if (g.add && cok && row < g.add_rows) v += g.add[(size_t)row * g.Nout + col];
-        if (EPI == EPI_UPDATE || g.relu) v = fmaxf(v, 0.f);
-        if (cok && row < g.M) g.C[(size_t)row * g.Nout + col] = v;
-        if (EPI == EPI_UPDATE) part[mt][r] += v * ws;
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wave * 16 * MT + mt * 16 + fg * 4 + r;
+          float v = acc[mt][nt][r] + bia;
+          if (g.add && cok && row < g.add_rows) v += g.add[(size_t)row * g.Nout + col];
+          if (EPI == EPI_UPDATE || g.relu) v = fmaxf(v, 0.f);
+          if (cok && row < g.M) g.C[(size_t)row * g.Nout + col] = v;
+          if (EPI == EPI_UPDATE) part[mt][r] += v * ws;
+        }
+      }
+    }
+    if constexpr (EPI == EPI_UPDATE) {
+      const float bs = g.b_s[0];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sc = part[mt][r];
+          sc += __shfl_xor(sc, 1, 64);
+          sc += __shfl_xor(sc, 2, 64);
+          sc += __shfl_xor(sc, 4, 64);
+          sc += __shfl_xor(sc, 8, 64);
+          const int row = m0 + wave * 16 * MT + mt * 16 + fg * 4 + r;
+          if (fr == 0 && row < g.M) g.score[row] = (sc + bs) + (1.0f - g.mask[row]) * kVeryNeg;
+        }
+    }
+  }
+#else
+  // ---- epilogue -------------------------------------------------------------------------------
+  // The MFMA C layout (column = lane & 15, row = (lane >> 4) * 4 + reg) would give 64-byte global
+  // pieces.  Each wave instead transposes one 16-row tile at a time through its own LDS region
+  // (the A/W tiles are dead: every wave has passed the loop's last barrier) and finishes row by
+  // row: lane l owns columns 4l..4l+3, so bias/add/ReLU/score and the store are full-row,
+  // 16 bytes per lane, coalesced.  One wave's LDS operations complete in order, so no barrier.
+  float* stg = smem + wave * (8 * LD);
+  const int colv = n0 + 4 * lane;
+  const bool lane_cols = lane < NT * 4 && colv < g.Nout;
+  const bool v4out = g.v4out != 0;
+  f32x4 bias4 = zero4, ws4 = zero4;
+  if (lane_cols) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (colv + e < g.Nout) {
+        if (g.bias) bias4[e] = g.bias[colv + e];
+        if (EPI == EPI_UPDATE) ws4[e] = g.w_s[colv + e];
       }
     }
   }
-  if constexpr (EPI == EPI_UPDATE) {
-    const float bs = g.b_s[0];
+  const float bs = (EPI == EPI_UPDATE) ? g.b_s[0] : 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row0 = m0 + wave * 16 * MT + mt * 16;
+    float mk = 0.f;                                // mask of row row0 + lane (lanes 0..15)
+    if (EPI == EPI_UPDATE && lane < 16 && row0 + lane < g.M) mk = g.mask[row0 + lane];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s = part[mt][r];
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
-        s += __shfl_xor(s, 8, 64);
-        const int row = m0 + wave * 32 + mt * 16 + fg * 4 + r;
-        if (fr == 0 && row < g.M) {
-          // fp32 on purpose: score - 1e11 rounds to exactly -1e11, as in the reference
-          g.score[row] = (s + bs) + (1.0f - g.mask[row]) * kVeryNeg;
+    for (int rb = 0; rb < 16; rb += 8) {
+      // rows rb..rb+7 of the tile live in the lanes with (lane >> 5) == rb / 8
+      if ((fg >> 1) == (rb >> 3)) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) stg[((fg & 1) * 4 + r) * LD + nt * 16 + fr] = acc[mt][nt][r];
+      }
+      // the 8 rows' `add` operands are requested together, ahead of their use
+      f32x4 addv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int row = row0 + rb + u;
+        addv[u] = zero4;
+        if (v4out && lane_cols && g.add && row < g.add_rows && row < g.M)
+          addv[u] = *reinterpret_cast<const f32x4*>(g.add + (size_t)row * g.Nout + colv);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int rr = rb + u;
+        const int row = row0 + rr;
+        if (row < g.M) {                             // wave-uniform
+          float part = 0.f;
+          if (lane_cols) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(&stg[u * LD + 4 * lane]) + bias4;
+            float* crow = g.C + (size_t)row * g.Nout + colv;
+            if (v4out) {
+              v += addv[u];
+              if (EPI == EPI_UPDATE || g.relu) v = __builtin_elementwise_max(v, zero4);
+              *reinterpret_cast<f32x4*>(crow) = v;
+            } else {
+              const bool has_add = g.add && row < g.add_rows;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                if (colv + e < g.Nout) {
+                  float x = v[e];
+                  if (has_add) x += g.add[(size_t)row * g.Nout + colv + e];
+                  if (EPI == EPI_UPDATE || g.relu) x = fmaxf(x, 0.f);
+                  v[e] = x;
+                  crow[e] = x;
+                } else {
+                  v[e] = 0.f;
+                }
+              }
+            }
+            if (EPI == EPI_UPDATE) part = v[0] * ws4[0] + v[1] * ws4[1] + v[2] * ws4[2] + v[3] * ws4[3];
+          }
+          if constexpr (EPI == EPI_UPDATE) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+            const float mrow = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mk), rr));
+            if (lane == 0) {
+              // fp32 on purpose: score - 1e11 rounds to exactly -1e11, as in the reference
+              g.score[row] = (part + bs) + (1.0f - mrow) * kVeryNeg;
+            }
+          }
         }
       }
+    }
   }
+#endif
 }
 
 // score for Nout > 208 (column blocks): one wave per row, dot(h', w_s)
@@ -318,12 +562,24 @@ static int launch_gemm(GemmArgs g, hipStream_t stream) {
     GNNRAG_LAUNCH_CHECK();
     return 1 << 30;   // "all columns done" marker for the column-block loop of the caller
   }
-  const int nblk = (g.M + kBM - 1) / kBM;
+  const int ny = AMODE == AMODE_GEN ? 2 : 1;
+  // 128-row tiles unless they would leave the chip badly quantised (2 workgroups per CU = 512 slots):
+  // mid-size problems (a few hundred tiles) run as twice as many 64-row tiles
+  const int tiles128 = ((g.M + 127) / 128) * ny;
+  const bool small_tiles = tiles128 < 1024;
+  const int bm = small_tiles ? 64 : 128;
+  const dim3 grid((g.M + bm - 1) / bm, ny);
   const int ncol = g.Nout - g.n0;
-#define GNNRAG_GEMM_CASE(NT)                                                                                \
-  do {                                                                                                      \
-    if (v4) hipLaunchKernelGGL((k_gemm_f32<NT, true, EPI, AMODE>), dim3(nblk), dim3(256), 0, stream, g);    \
-    else hipLaunchKernelGGL((k_gemm_f32<NT, false, EPI, AMODE>), dim3(nblk), dim3(256), 0, stream, g);      \
+  g.v4out = (g.Nout % 4 == 0) && (g.n0 % 4 == 0) && aligned16(g.C) && (g.add == nullptr || aligned16(g.add));
+#define GNNRAG_GEMM_CASE(NT)                                                                               \
+  do {                                                                                                     \
+    if (small_tiles) {                                                                                     \
+      if (v4) hipLaunchKernelGGL((k_gemm_f32<NT, 1, true, EPI, AMODE>), grid, dim3(256), 0, stream, g);    \
+      else hipLaunchKernelGGL((k_gemm_f32<NT, 1, false, EPI, AMODE>), grid, dim3(256), 0, stream, g);      \
+    } else {                                                                                               \
+      if (v4) hipLaunchKernelGGL((k_gemm_f32<NT, 2, true, EPI, AMODE>), grid, dim3(256), 0, stream, g);    \
+      else hipLaunchKernelGGL((k_gemm_f32<NT, 2, false, EPI, AMODE>), grid, dim3(256), 0, stream, g);      \
+    }                                                                                                      \
   } while (0)
   if (ncol <= 64) GNNRAG_GEMM_CASE(4);
   else if (ncol <= 128) GNNRAG_GEMM_CASE(8);
@@ -415,20 +671,19 @@ extern "C" int gnnrag_relation_tables(const float* T_fwd, const float* T_inv, co
                                       gnnrag_stream_t stream) {
   if (!T_fwd || !T_inv || !ins || !W || !P || B <= 0 || R1 <= 0 || D <= 0 || I <= 0) return GNNRAG_E_BADARG;
   if ((int64_t)B * R1 >= ((int64_t)1 << 31)) return GNNRAG_E_UNSUPPORTED;
-  for (int d = 0; d < 2; ++d) {
-    GemmArgs g;
-    memset(&g, 0, sizeof(g));
-    g.A0 = d ? T_inv : T_fwd;
-    g.A1 = ins;
-    g.W = W;
-    g.C = P + (size_t)d * B * R1 * D;
-    g.M = B * R1; g.K = I * D; g.K0 = g.K; g.Nout = D; g.ldw = (2 * I + 1) * D;
-    g.gen_R1 = R1; g.gen_D = D; g.gen_I = I; g.gen_dir = d;
-    for (int n0 = 0; n0 < D; n0 += 208) {
-      g.n0 = n0;
-      const int rc = launch_gemm<EPI_LINEAR, AMODE_GEN>(g, (hipStream_t)stream);
-      if (rc) return rc;
-    }
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A0 = T_fwd;
+  g.A0b = T_inv;
+  g.A1 = ins;
+  g.W = W;
+  g.C = P;                       // direction d (blockIdx.y) writes P + d*B*R1*D
+  g.M = B * R1; g.K = I * D; g.K0 = g.K; g.Nout = D; g.ldw = (2 * I + 1) * D;
+  g.gen_R1 = R1; g.gen_D = D; g.gen_I = I;
+  for (int n0 = 0; n0 < D; n0 += 208) {
+    g.n0 = n0;
+    const int rc = launch_gemm<EPI_LINEAR, AMODE_GEN>(g, (hipStream_t)stream);
+    if (rc) return rc;
   }
   return 0;
 }

@@ -20,7 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--ops", default="rel,agg,upd,sm,layer")
+    ap.add_argument("--ops", default="rel,agg,upd,tab,aggf,updf,sm,layer")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     cfg = synth.CONFIGS[a.workload]
@@ -51,6 +51,15 @@ def main():
                                           layer.score_func.bias, layer.local_entity_mask, I)
                 if "sm" in which:
                     ops.masked_softmax(sc, B, N)
+            if "tab" in which:
+                P = ops.relation_tables(Tf, Ti, devin.ins[0], e2e.weight)
+            if "aggf" in which:
+                P = ops.relation_tables(Tf, Ti, devin.ins[0], e2e.weight) if "tab" not in which else P
+                nbr = ops.aggregate_fused(layer.plan, dist1, P)                 # dense prior
+                ops.aggregate_fused(layer.plan, devin.seed_dist, P)              # sparse (seed) prior
+                if "updf" in which:
+                    ops.update_score_fused(h, nbr, e2e.weight, e2e.bias, layer.score_func.weight,
+                                           layer.score_func.bias, layer.local_entity_mask, I)
             if "layer" in which:
                 layer.local_entity_emb = devin.h0
                 layer(dist1, devin.ins[0], step=1)
