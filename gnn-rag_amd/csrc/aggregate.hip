@@ -34,7 +34,9 @@
 #include "gnnrag_common.h"
 
 #ifndef GNNRAG_SLICE_ABLATE
-#define GNNRAG_SLICE_ABLATE 0   // timing experiments only (tools/tune_variants.py): 1 no staging, 2 no hubs, 4 no sets, 8 no stores
+#define GNNRAG_SLICE_ABLATE 0   // timing experiments only (tools/tune_variants.py): 1 no staging, 2 no medium/huge pass,
+                                // 4 no sets, 8 no stores, 16 no row walk (structure loads only), 32 no queueing of big nodes,
+                                // 64 no medium pass, 128 no huge pass
 #endif
 
 namespace gnnrag {
@@ -430,21 +432,31 @@ __global__ __launch_bounds__(256) void k_fact_prior(const int2* __restrict__ e0,
   pr[(size_t)d * F + i] = make_int2(__float_as_int(p), r);
 }
 
-constexpr int kSliceHubDeg = 512;   // nodes with more facts in a direction are walked by wave teams
+// Node classes of the LDS walk (by the larger of the two directions' fact counts):
+//   light  (<= kSliceLightDeg): a 4-lane group per node, 16 nodes per wave step;
+//   medium (<= kSliceTeamDeg) : one whole wave per node (64 facts per step, 8 steps in flight);
+//   huge                      : the whole workgroup per node.
+// A lane group walks its row with ONE outstanding 8-fact step, i.e. a row of n facts costs n/8
+// dependent L2 round trips - fine for 32 facts, ruinous for 500 (measured: medium rows walked by
+// their group held every workgroup for ~65 us).  Hence the wave-wide class.
+constexpr int kSliceLightDeg = 32;
+constexpr int kSliceTeamDeg = 4096;
+constexpr int kSliceMedCap = 96;    // medium nodes of one question kept in LDS (overflow: owner group walks them)
+constexpr int kSliceHugeCap = 8;    // huge nodes of one question kept in LDS (overflow: treated as medium)
 
-// one node's rows in both directions + its first 4 (p, rel) pairs per direction
+// one node's rows in both directions + its first 8 (p, rel) pairs per direction
 struct SetRows {
   int beg[2], len[2];
-  int2 first[2];
+  int2 first[2][2];
   int n;
-  bool valid, hub;
+  bool valid, big;
 };
 
 __device__ __forceinline__ void set_load_rows(SetRows& s, const WalkArgs& a, int g, int set, int nsets, int grp) {
   const int nl = set * 16 + grp;
   s.valid = set < nsets && nl < a.N;
   s.n = g * a.N + (s.valid ? nl : 0);
-  s.hub = false;
+  s.big = false;
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
     s.beg[d] = 0;
@@ -452,7 +464,7 @@ __device__ __forceinline__ void set_load_rows(SetRows& s, const WalkArgs& a, int
     if (s.valid) {
       s.beg[d] = a.row_ptr[d][s.n];
       s.len[d] = a.row_ptr[d][s.n + 1] - s.beg[d];
-      s.hub |= s.len[d] > kSliceHubDeg;
+      s.big |= s.len[d] > kSliceLightDeg;
     }
   }
 }
@@ -460,16 +472,64 @@ __device__ __forceinline__ void set_load_rows(SetRows& s, const WalkArgs& a, int
 __device__ __forceinline__ void set_load_first(SetRows& s, const int2* const (&prd)[2], int sub) {
 #pragma unroll
   for (int d = 0; d < 2; ++d)
-    s.first[d] = (s.valid && !s.hub && sub < s.len[d]) ? prd[d][s.beg[d] + sub] : make_int2(0, 0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      s.first[d][h] = (s.valid && !s.big && 4 * h + sub < s.len[d]) ? prd[d][s.beg[d] + 4 * h + sub]
+                                                                    : make_int2(0, 0);
+}
+
+// value of lane k of this lane's quad (DPP quad_perm broadcast: VALU speed, no LDS crossbar)
+template <int K>
+__device__ __forceinline__ int quad_bcast(int v) {
+  return __builtin_amdgcn_mov_dpp(v, K * 0x55, 0xf, 0xf, true);
+}
+
+// acc += sum over the 4 facts a lane group (one quad) holds one per lane in `pairs`
+__device__ __forceinline__ void slice_fma4(f32x4& acc, int2 pairs, const float* __restrict__ Td) {
+#define GNNRAG_SLICE_STEP(K)                                                                        \
+  {                                                                                                 \
+    const float pk = __int_as_float(quad_bcast<K>(pairs.x));                                        \
+    const int rk = quad_bcast<K>(pairs.y);                                                          \
+    if (pk != 0.f) acc += pk * *reinterpret_cast<const f32x4*>(Td + (size_t)rk * kSliceW);          \
+  }
+  GNNRAG_SLICE_STEP(0) GNNRAG_SLICE_STEP(1) GNNRAG_SLICE_STEP(2) GNNRAG_SLICE_STEP(3)
+#undef GNNRAG_SLICE_STEP
+}
+
+// one direction of one row, walked by a whole wave: 64 facts per step (lane group k owns facts
+// 4k..4k+3 of a step), steps first, first+stride, ...; up to 8 steps requested before consuming
+__device__ __forceinline__ void slice_walk_wave(f32x4& acc, const int2* __restrict__ prd, int beg, int len,
+                                                int first, int stride, int lane, const float* __restrict__ Td) {
+  const int nsteps = (len + 63) >> 6;
+  for (int st = first; st < nsteps; st += stride * 8) {
+    int2 pairs[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int off = (st + stride * u) * 64 + lane;
+      pairs[u] = (off < len) ? prd[beg + off] : make_int2(0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) slice_fma4(acc, pairs[u], Td);
+  }
+}
+
+__device__ __forceinline__ void slice_wave_reduce(f32x4& acc) {
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+  }
 }
 
 __global__ __launch_bounds__(kSliceThreads) void k_walk_slice(const WalkArgs a, const int2* __restrict__ pr,
-                                                              int64_t F, int nslice, int hcap) {
+                                                              int64_t F, int nslice) {
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
   float* Ts = s_mem;                                   // [2][R1][16]
-  int* ctl = reinterpret_cast<int*>(s_mem + (size_t)2 * a.R1 * kSliceW);   // [0] set ticket, [1] hub count
-  int* hlist = ctl + 4;                                // [hcap][5]: node, beg0, len0, beg1, len1
-  float* red = reinterpret_cast<float*>(hlist + 5 * hcap);   // [16 waves][16 floats]
+  // ctl: [0] set ticket, [1] medium count, [2] medium ticket, [3] huge count
+  int* ctl = reinterpret_cast<int*>(s_mem + (size_t)2 * a.R1 * kSliceW);
+  int* mlist = ctl + 16;                               // [kSliceMedCap][5]: node, beg0, len0, beg1, len1
+  int* hlist = mlist + 5 * kSliceMedCap;               // [kSliceHugeCap][5]
+  float* red = reinterpret_cast<float*>(hlist + 5 * kSliceHugeCap);   // [16 waves][16 floats]
   // XCD-aware order: the nslice workgroups of question g all land on XCD g % 8
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int g = (slot / nslice) * 8 + xcd;
@@ -478,7 +538,7 @@ __global__ __launch_bounds__(kSliceThreads) void k_walk_slice(const WalkArgs a, 
   const int col0 = c * kSliceW;
   const int D = a.D, R1 = a.R1, N = a.N;
   const int tid = threadIdx.x;
-  if (tid < 4) ctl[tid] = 0;
+  if (tid < 16) ctl[tid] = 0;
   // stage the two table slices (float4 granules; rows are D*4 bytes apart in P)
   for (int idx = tid; idx < ((GNNRAG_SLICE_ABLATE & 1) ? 0 : 2 * R1 * 4); idx += kSliceThreads) {
     const int d = idx / (R1 * 4);
@@ -498,58 +558,67 @@ __global__ __launch_bounds__(kSliceThreads) void k_walk_slice(const WalkArgs a, 
   const int2* const prd[2] = {pr, pr + F};
   const float* Td[2] = {Ts + 4 * sub, Ts + (size_t)R1 * kSliceW + 4 * sub};
 
-  // ---- ordinary nodes: 4 lanes per node, 16 nodes (a "set") per wave step, sets handed out by an
-  // LDS ticket.  The dependent chain ticket -> row pointers -> first pairs -> table slices is
-  // software pipelined over three sets: while set i is walked, the first pairs of set i+1 and the
-  // row pointers of set i+2 are already in flight.
-  auto ticket = [&]() {
+  // ---- light nodes: 4 lanes per node, 16 nodes (a "set") per wave step, sets handed out by an LDS
+  // ticket.  The dependent chain ticket -> row pointers -> first pairs -> table slices is software
+  // pipelined over three sets: while set i is walked, the first pairs of set i+1 and the row
+  // pointers of set i+2 are already in flight.  A row is walked 8 facts per step (two 32-byte
+  // coalesced accesses per group), the next step requested before the current one is consumed.
+  auto ticket = [&](int which) {
     int t = 0;
-    if (lane == 0) t = atomicAdd(&ctl[0], 1);
+    if (lane == 0) t = atomicAdd(&ctl[which], 1);
     return __builtin_amdgcn_readfirstlane(t);
   };
   SetRows s0, s1, s2;
-  int t0 = (GNNRAG_SLICE_ABLATE & 4) ? nsets : ticket();
+  int t0 = (GNNRAG_SLICE_ABLATE & 4) ? nsets : ticket(0);
   set_load_rows(s0, a, g, t0, nsets, grp);
-  int t1 = t0 < nsets ? ticket() : nsets;
+  int t1 = t0 < nsets ? ticket(0) : nsets;
   set_load_rows(s1, a, g, t1, nsets, grp);
   set_load_first(s0, prd, sub);
   while (t0 < nsets) {
-    const int t2 = t1 < nsets ? ticket() : nsets;
+    const int t2 = t1 < nsets ? ticket(0) : nsets;
     set_load_rows(s2, a, g, t2, nsets, grp);
     set_load_first(s1, prd, sub);
 
-    if (s0.valid && s0.hub) {
-      // walked by wave teams below; if the list is full the owner group walks it itself
-      int pos = hcap;
-      if (sub == 0) pos = atomicAdd(&ctl[1], 1);
-      pos = __shfl(pos, 0, 4);
-      if (pos < hcap) {
+    if (s0.valid && s0.big && !(GNNRAG_SLICE_ABLATE & 32)) {
+      // queue for the wave-wide / workgroup-wide passes; if both lists are full the owner group
+      // walks the node itself (slow, correct)
+      const bool huge = s0.len[0] > kSliceTeamDeg || s0.len[1] > kSliceTeamDeg;
+      int* list = nullptr;
+      if (huge) {
+        int pos = kSliceHugeCap;
+        if (sub == 0) pos = atomicAdd(&ctl[3], 1);
+        pos = __shfl(pos, 0, 4);
+        if (pos < kSliceHugeCap) list = hlist + 5 * pos;
+      }
+      if (!list) {
+        int pos = kSliceMedCap;
+        if (sub == 0) pos = atomicAdd(&ctl[1], 1);
+        pos = __shfl(pos, 0, 4);
+        if (pos < kSliceMedCap) list = mlist + 5 * pos;
+      }
+      if (list) {
         if (sub == 0) {
-          int* e = hlist + 5 * pos;
-          e[0] = s0.n; e[1] = s0.beg[0]; e[2] = s0.len[0]; e[3] = s0.beg[1]; e[4] = s0.len[1];
+          list[0] = s0.n; list[1] = s0.beg[0]; list[2] = s0.len[0]; list[3] = s0.beg[1]; list[4] = s0.len[1];
         }
       } else {
-        s0.hub = false;
+        s0.big = false;
         set_load_first(s0, prd, sub);
       }
     }
-    if (s0.valid && !s0.hub) {
+    if (s0.valid && !s0.big) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
         const int beg = s0.beg[d], len = s0.len[d];
-        int2 cur = s0.first[d];
-        // 4 facts per step per node; the next step's pairs are requested before this step's are used
-        for (int j = 0; j < len; j += 4) {
-          int2 nxt = make_int2(0, 0);
-          if (j + 4 + sub < len) nxt = prd[d][beg + j + 4 + sub];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float pk = __int_as_float(__shfl(cur.x, k, 4));
-            const int rk = __shfl(cur.y, k, 4);
-            if (pk != 0.f) acc += pk * *reinterpret_cast<const f32x4*>(Td[d] + (size_t)rk * kSliceW);
-          }
-          cur = nxt;
+        int2 c0 = s0.first[d][0], c1 = s0.first[d][1];
+        for (int j = 0; j < ((GNNRAG_SLICE_ABLATE & 16) ? 0 : len); j += 8) {
+          int2 n0 = make_int2(0, 0), n1 = make_int2(0, 0);
+          if (j + 8 + sub < len) n0 = prd[d][beg + j + 8 + sub];
+          if (j + 12 + sub < len) n1 = prd[d][beg + j + 12 + sub];
+          slice_fma4(acc, c0, Td[d]);
+          slice_fma4(acc, c1, Td[d]);
+          c0 = n0;
+          c1 = n1;
         }
       }
       if (col_ok && (!(GNNRAG_SLICE_ABLATE & 8) || acc[0] == 12345.f))
@@ -559,56 +628,38 @@ __global__ __launch_bounds__(kSliceThreads) void k_walk_slice(const WalkArgs a, 
     s1 = s2; t1 = t2;
   }
   __syncthreads();
+  if (GNNRAG_SLICE_ABLATE & 2) return;
 
-  // ---- hubs: a team of 4 waves per node, 4 hubs per round.  A row is cut into 64-fact steps (64
-  // consecutive pairs = 512 coalesced bytes); team wave w takes steps w, w+4, ... and requests up
-  // to 8 of them before consuming.  Inside a step lane group k owns facts 4k..4k+3.  Partial sums
-  // are combined by a fixed xor tree inside the wave and in wave order inside the team (through
-  // LDS): deterministic, no atomics.
-  const int nhub = (GNNRAG_SLICE_ABLATE & 2) ? 0 : min(ctl[1], hcap);
-  const int team = wave >> 2, tw = wave & 3;
-  for (int h0 = 0; h0 < nhub; h0 += 4) {
-    const int h = h0 + team;
+  // ---- medium nodes: one wave per node, handed out by a second ticket.  Partial sums of the 16
+  // lane groups are combined by a fixed xor tree: deterministic, no atomics.
+  const int nmed = (GNNRAG_SLICE_ABLATE & 64) ? 0 : min(ctl[1], kSliceMedCap);
+  for (;;) {
+    const int m = ticket(2);
+    if (m >= nmed) break;
+    const int* e = mlist + 5 * m;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    int n = 0;
-    if (h < nhub) {
-      const int* e = hlist + 5 * h;
-      n = e[0];
 #pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        const int beg = e[1 + 2 * d], len = e[2 + 2 * d];
-        const int nsteps = (len + 63) >> 6;
-        for (int st = tw; st < nsteps; st += 4 * 8) {
-          int2 pairs[8];
+    for (int d = 0; d < 2; ++d) slice_walk_wave(acc, prd[d], e[1 + 2 * d], e[2 + 2 * d], 0, 1, lane, Td[d]);
+    slice_wave_reduce(acc);
+    if (grp == 0 && col_ok) *reinterpret_cast<f32x4*>(a.out + (size_t)e[0] * D + col0 + 4 * sub) = acc;
+  }
+
+  // ---- huge nodes: the whole workgroup per node; wave w takes steps w, w+16, ...; wave sums are
+  // combined in wave order through LDS
+  const int nhuge = (GNNRAG_SLICE_ABLATE & 128) ? 0 : min(ctl[3], kSliceHugeCap);
+  for (int h = 0; h < nhuge; ++h) {
+    const int* e = hlist + 5 * h;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int off = (st + 4 * u) * 64 + lane;
-            pairs[u] = (off < len) ? prd[d][beg + off] : make_int2(0, 0);
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const float pk = __int_as_float(__shfl(pairs[u].x, k, 4));
-              const int rk = __shfl(pairs[u].y, k, 4);
-              if (pk != 0.f) acc += pk * *reinterpret_cast<const f32x4*>(Td[d] + (size_t)rk * kSliceW);
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int o = 4; o < 64; o <<= 1) {
-#pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2) acc[e2] += __shfl_xor(acc[e2], o, 64);
-      }
-      if (grp == 0) *reinterpret_cast<f32x4*>(red + wave * 16 + 4 * sub) = acc;
-    }
+    for (int d = 0; d < 2; ++d) slice_walk_wave(acc, prd[d], e[1 + 2 * d], e[2 + 2 * d], wave, 16, lane, Td[d]);
+    slice_wave_reduce(acc);
+    if (grp == 0) *reinterpret_cast<f32x4*>(red + wave * 16 + 4 * sub) = acc;
     __syncthreads();
-    if (h < nhub && tw == 0 && lane < 4) {
+    if (tid < 4) {
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int w = 0; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(red + (team * 4 + w) * 16 + 4 * lane);
-      if (col0 + 4 * lane < D) *reinterpret_cast<f32x4*>(a.out + (size_t)n * D + col0 + 4 * lane) = t;
+      for (int w = 0; w < 16; ++w) t += *reinterpret_cast<const f32x4*>(red + w * 16 + 4 * tid);
+      if (col0 + 4 * tid < D) *reinterpret_cast<f32x4*>(a.out + (size_t)e[0] * D + col0 + 4 * tid) = t;
     }
     __syncthreads();
   }
@@ -699,9 +750,9 @@ static size_t partial_bytes(const gnnrag_csr* csr, int D, int na) {
 static size_t prior_bytes(const gnnrag_csr* csr) {
   return align_up((size_t)2 * (size_t)(csr->F > 0 ? csr->F : 1) * sizeof(int2), 256);
 }
-constexpr int kSliceHeavyCap = 24;     // heavy nodes of one question kept in LDS (overflow: owner group walks them)
 static size_t slice_lds_bytes(int R1) {
-  return (size_t)2 * R1 * kSliceW * sizeof(float) + (4 + 5 * kSliceHeavyCap) * sizeof(int) + 16 * 16 * sizeof(float);
+  return (size_t)2 * R1 * kSliceW * sizeof(float) + (16 + 5 * (kSliceMedCap + kSliceHugeCap)) * sizeof(int) +
+         16 * 16 * sizeof(float);
 }
 // the LDS variant needs the two table slices of a question in one CU's LDS (160 KB)
 static bool slice_walk_fits(const gnnrag_csr* csr, int D) {
@@ -800,8 +851,7 @@ extern "C" int gnnrag_aggregate_fused(const gnnrag_csr* csr, const float* dist, 
     attr_set = true;
   }
   const int nblk = 8 * ((csr->B + 7) / 8) * nslice;
-  hipLaunchKernelGGL(k_walk_slice, dim3(nblk), dim3(kSliceThreads), lds, stream, a, (const int2*)pr, F, nslice,
-                     (int)kSliceHeavyCap);
+  hipLaunchKernelGGL(k_walk_slice, dim3(nblk), dim3(kSliceThreads), lds, stream, a, (const int2*)pr, F, nslice);
   GNNRAG_LAUNCH_CHECK();
   return 0;   // hubs were walked inside the kernel (whole-wave pass), nothing to add afterwards
 }

@@ -217,14 +217,16 @@ def test_rearev_call_site_fixture(dev):
     assert (dist.cpu().numpy().argmax(1) == z["pred"]).all()          # Hits@1 decisions identical
 
 
-@pytest.mark.parametrize("cfgname", ["tiny", "tiny50", "hub"])
+@pytest.mark.parametrize("cfgname", ["tiny", "tiny50", "hub", "huge"])
 def test_fused_kernels_vs_np64(dev, cfgname):
     """The fused path's own kernels (relation tables, fused walk incl. heavy chunks and the
     XCD-aware order, self-block update) against the float64 oracle."""
     import oracle.rearev_np64 as onp
     from gnnrag_amd import ops, synth
-    if cfgname == "hub":
+    if cfgname == "hub":      # rows of 33..4096 facts: the wave-per-node class of the LDS walk
         cfg = synth.GraphConfig(name="hub", B=3, N=600, E=4000, R=20, D=200, I=2, L=1, seed=3)
+    elif cfgname == "huge":   # a row with > 4096 facts: the workgroup-per-node class
+        cfg = synth.GraphConfig(name="huge", B=2, N=500, E=14000, R=20, D=200, I=2, L=1, seed=4)
     else:
         cfg = synth.CONFIGS[cfgname]
     batch = synth.make_batch(cfg)
@@ -253,6 +255,9 @@ def test_fused_kernels_vs_np64(dev, cfgname):
         T_f = ops.linear(rf, Wd, bd, pos)
         T_i = ops.linear(rfi, Wd, bd, posi)
         dist_d, ins_d, We = _to_dev(dev, prior, feats["ins"][0], params["e2e_linear0.weight"])
+        if cfgname == "huge":
+            deg = np.bincount(np.asarray(et[0]), minlength=B * N)
+            assert deg.max() > 4096, "config must exercise the workgroup-per-node class"
         P = ops.relation_tables(T_f, T_i, ins_d, We)
         # tables vs fp64
         Tn = [feats["rel_features"].astype(np.float64) @ params["rel_linear0.weight"].astype(np.float64).T

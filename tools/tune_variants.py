@@ -15,12 +15,10 @@ sys.path.insert(0, REPO)
 
 VARIANTS = {
     "full": {"GNNRAG_SLICE_ABLATE": 0},
-    "nostage": {"GNNRAG_SLICE_ABLATE": 1},
-    "nohubs": {"GNNRAG_SLICE_ABLATE": 2},
-    "nosets": {"GNNRAG_SLICE_ABLATE": 4},
-    "nostore": {"GNNRAG_SLICE_ABLATE": 8},
-    "only_stage": {"GNNRAG_SLICE_ABLATE": 6},
-    "nothing": {"GNNRAG_SLICE_ABLATE": 7},
+    "nomed": {"GNNRAG_SLICE_ABLATE": 64},
+    "nohuge": {"GNNRAG_SLICE_ABLATE": 128},
+    "nopass2": {"GNNRAG_SLICE_ABLATE": 2},
+    "nowalk": {"GNNRAG_SLICE_ABLATE": 2 + 32 + 16},
 }
 
 CHILD = r'''
@@ -36,8 +34,16 @@ batch = synth.make_batch(cfg); feats = synth.make_features(cfg); params = synth.
 devin = stack.DeviceInputs(batch, feats, dev)
 layer = stack.build_layer(cfg, batch, params, dev)
 stack.init_reason(layer, batch, devin, devin.h0)
-out = bench.roofline_leg(cfg, layer, devin, ops, batch.F // cfg.B, 10)
-print("RESULT " + json.dumps(out["kernel_ms"]))
+with torch.no_grad():
+    dense, _ = layer(devin.seed_dist, devin.ins[0], step=0)
+    rl, e2e = layer.rel_linear1, layer.e2e_linear1
+    Tf = ops.linear(devin.rel_features, rl.weight, rl.bias); Ti = ops.linear(devin.rel_features_inv, rl.weight, rl.bias)
+    P = ops.relation_tables(Tf, Ti, devin.ins[0], e2e.weight)
+    ms = {}
+    for name, prior in (("fused_dense", dense), ("fused_seed", devin.seed_dist)):
+        ops.aggregate_fused(layer.plan, prior, P)
+        ms[name] = float(np.mean(bench._events_ms(lambda: ops.aggregate_fused(layer.plan, prior, P), 10)))
+print("RESULT " + json.dumps(ms))
 '''
 
 
