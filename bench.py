@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-b", type=int, default=8)
+    ap.add_argument("--math", choices=["default", "fp32", "bf16x3"], default="default",
+                    help="math mode of the dense projections (default = the library's default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -83,6 +85,9 @@ def main():
     import gnnrag_amd  # noqa: F401
     from gnnrag_amd import _lib, ops, shard, stack, synth
     _lib.load()
+    if args.math != "default":
+        ops.set_dense_math(ops.MATH_BF16X3 if args.math == "bf16x3" else ops.MATH_FP32)
+    math_name = ["fp32 (v_mfma_f32_16x16x4_f32)", "bf16x3 (exact 3-way bf16 split, 6 plane products, fp32 accumulate)"][ops.get_dense_math()]
 
     cfg = synth.CONFIGS[args.workload]
     # every rank owns its own questions (weak scaling): same shapes, different seed
@@ -149,6 +154,7 @@ def main():
                    "D": cfg.D, "I": cfg.I, "L": cfg.L, "parallelism": "question-sharded x%d" % world},
         "fact_layers_per_sec": facts / (elapsed / args.steps),
         "csr_build_ms": csr_build_ms, "csr_first_call_ms": csr_first_ms,
+        "dense_math": math_name,
     }
 
     if rank == 0:

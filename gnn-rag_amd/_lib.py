@@ -37,6 +37,8 @@ SIGNATURES = {
     "gnnrag_csr_build": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                    _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(CsrStruct), _VP]),
     "gnnrag_csr_permute_weight": (C.c_int, [C.POINTER(CsrStruct), _VP, C.c_int, _VP, _VP, _VP]),
+    "gnnrag_set_dense_math": (C.c_int, [C.c_int]),
+    "gnnrag_get_dense_math": (C.c_int, []),
     "gnnrag_linear": (C.c_int, [_VP, C.c_int64, C.c_int32, _VP, _VP, _VP, C.c_int64, C.c_int, _VP,
                                 C.c_int32, _VP]),
     "gnnrag_aggregate_workspace_bytes": (C.c_size_t, [C.POINTER(CsrStruct), C.c_int32, C.c_int32]),
@@ -85,6 +87,11 @@ def load():
     if lib.gnnrag_abi_version() != ABI_VERSION:
         raise GnnragError("ABI mismatch: library %d, binding %d" % (lib.gnnrag_abi_version(), ABI_VERSION))
     _lib = lib
+    if "GNNRAG_MATH" in os.environ:                     # A/B runs: fp32 | bf16x3
+        mode = {"fp32": 0, "bf16x3": 1}[os.environ["GNNRAG_MATH"]]
+        check_code = lib.gnnrag_set_dense_math(mode)
+        if check_code != 0:
+            raise GnnragError("gnnrag_set_dense_math(%d) failed" % mode)
     return lib
 
 

@@ -27,9 +27,6 @@
 #ifndef GNNRAG_GEMM_BRANCHLESS
 #define GNNRAG_GEMM_BRANCHLESS 0
 #endif
-#ifndef GNNRAG_GEMM_PREFETCH
-#define GNNRAG_GEMM_PREFETCH 0
-#endif
 #ifndef GNNRAG_GEMM_EPILOGUE
 #define GNNRAG_GEMM_EPILOGUE 1   // 0 = direct stores from the MFMA layout, 1 = staged through LDS (row-wise, coalesced)
 #endif
@@ -40,7 +37,6 @@
 namespace gnnrag {
 
 constexpr int kBK = 32;    // k per LDS tile
-constexpr int kLS = 40;    // LDS row stride (floats)
 
 enum { EPI_LINEAR = 0, EPI_UPDATE = 1 };
 
@@ -159,8 +155,37 @@ __device__ __forceinline__ f32x4 load_w4(const GemmArgs& g, int j, int k) {
   return v;
 }
 
-template <int NT, int MT, bool V4, int EPI, int AMODE>
+// bf16 planes of 4 consecutive fp32 values (truncation split: x = hi + mid + lo EXACTLY - hi keeps the
+// top 8 significand bits, the remainder x - hi is exact in fp32 and has <= 16 bits, and so on)
+struct Split3 { uint2 hi, mid, lo; };
+__device__ __forceinline__ Split3 split3(f32x4 x) {
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned u = __float_as_uint(x[e]);
+    h[e] = u & 0xffff0000u;
+    const float r = x[e] - __uint_as_float(h[e]);
+    m[e] = __float_as_uint(r) & 0xffff0000u;
+    const float r2 = r - __uint_as_float(m[e]);
+    l[e] = __float_as_uint(r2);            // <= 8 significant bits: its low 16 encoding bits are zero
+  }
+  Split3 s;
+  s.hi = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
+  s.mid = make_uint2((m[0] >> 16) | m[1], (m[2] >> 16) | m[3]);
+  s.lo = make_uint2((l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u));
+  return s;
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// MATH = 0: v_mfma_f32_16x16x4_f32 (bit-exact fmaf chains).
+// MATH = 1: every fp32 operand is split exactly into three bf16 planes (hi, mid, lo) when its tile is
+//   staged to LDS and the product is formed from the six plane pairs that matter (hi*hi, hi*mid,
+//   mid*hi, hi*lo, lo*hi, mid*mid; the dropped ones are <= 3 * 2^-24 relative) with
+//   v_mfma_f32_16x16x32_bf16, fp32 accumulate: fp32-class accuracy at 6/16 of the fp32 MFMA time.
+template <int NT, int MT, bool V4, int EPI, int AMODE, int MATH>
 __global__ __launch_bounds__(256, (MT == 1 ? GNNRAG_GEMM_MT1_WAVES : 2)) void k_gemm_f32(GemmArgs g) {
+  constexpr int kLS = MATH ? 56 : 40;         // LDS row stride in floats (both conflict-free for ds_read_b128)
   constexpr int BM = 64 * MT;                 // rows per workgroup: 4 waves x MT accumulator row-tiles of 16
   constexpr int AR = BM / 32;                 // A staging rounds (32 rows per round)
   constexpr int WR = (NT * 16 + 31) / 32;     // W staging rounds (32 rows per round)
@@ -267,12 +292,35 @@ __global__ __launch_bounds__(256, (MT == 1 ? GNNRAG_GEMM_MT1_WAVES : 2)) void k_
     }
   };
   auto sstore = [&]() {
+    if constexpr (MATH == 0) {
 #pragma unroll
-    for (int r = 0; r < AR; ++r) *reinterpret_cast<f32x4*>(&As[(lr + 32 * r) * kLS + kq * 4]) = ra[r];
+      for (int r = 0; r < AR; ++r) *reinterpret_cast<f32x4*>(&As[(lr + 32 * r) * kLS + kq * 4]) = ra[r];
 #pragma unroll
-    for (int r = 0; r < WR; ++r) {
-      const int j = lr + 32 * r;
-      if (j < NT * 16) *reinterpret_cast<f32x4*>(&Ws[j * kLS + kq * 4]) = rw[r];
+      for (int r = 0; r < WR; ++r) {
+        const int j = lr + 32 * r;
+        if (j < NT * 16) *reinterpret_cast<f32x4*>(&Ws[j * kLS + kq * 4]) = rw[r];
+      }
+    } else {
+      // row image: [hi: 32 bf16 | mid: 32 bf16 | lo: 32 bf16 | pad] = 224 bytes; this thread owns k 4kq..4kq+3
+#pragma unroll
+      for (int r = 0; r < AR; ++r) {
+        const Split3 sp = split3(ra[r]);
+        float* row = &As[(lr + 32 * r) * kLS + kq * 2];
+        *reinterpret_cast<uint2*>(row) = sp.hi;
+        *reinterpret_cast<uint2*>(row + 16) = sp.mid;
+        *reinterpret_cast<uint2*>(row + 32) = sp.lo;
+      }
+#pragma unroll
+      for (int r = 0; r < WR; ++r) {
+        const int j = lr + 32 * r;
+        if (j < NT * 16) {
+          const Split3 sp = split3(rw[r]);
+          float* row = &Ws[j * kLS + kq * 2];
+          *reinterpret_cast<uint2*>(row) = sp.hi;
+          *reinterpret_cast<uint2*>(row + 16) = sp.mid;
+          *reinterpret_cast<uint2*>(row + 32) = sp.lo;
+        }
+      }
     }
   };
 
@@ -284,65 +332,60 @@ __global__ __launch_bounds__(256, (MT == 1 ? GNNRAG_GEMM_MT1_WAVES : 2)) void k_
   const int fg = lane >> 4;  // k group
   for (int t = 0; t < nT; ++t) {
     if (t + 1 < nT) gload(t + 1);
-#if GNNRAG_GEMM_PREFETCH == 0
+    if constexpr (MATH == 0) {
 #pragma unroll
-    for (int c = 0; c < kBK / 16; ++c) {
-      f32x4 a[MT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        a[mt] = *reinterpret_cast<const f32x4*>(&As[(wave * 16 * MT + mt * 16 + fr) * kLS + c * 16 + fg * 4]);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(&Ws[(nt * 16 + fr) * kLS + c * 16 + fg * 4]);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], b[s], acc[mt][nt], 0, 0, 0);
-        }
-      }
-    }
-#else
-    // fragments are read one step ahead of the MFMAs that consume them (LDS latency hidden)
-    const float* a_base = &As[(wave * 16 * MT + fr) * kLS + fg * 4];
-    const float* w_base = &Ws[fr * kLS + fg * 4];
-    constexpr int NSTEP = (kBK / 16) * NT;
-    f32x4 a[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(a_base + mt * 16 * kLS);
-    f32x4 bcur = *reinterpret_cast<const f32x4*>(w_base);
-#pragma unroll
-    for (int st = 0; st < NSTEP; ++st) {
-      const int nt = st % NT;
-      f32x4 bnxt = bcur;
-      f32x4 anxt[MT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) anxt[mt] = a[mt];
-      if (st + 1 < NSTEP) {
-        const int c2 = (st + 1) / NT, nt2 = (st + 1) % NT;
-        bnxt = *reinterpret_cast<const f32x4*>(w_base + nt2 * 16 * kLS + c2 * 16);
-        if (nt2 == 0) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            anxt[mt] = *reinterpret_cast<const f32x4*>(a_base + mt * 16 * kLS + c2 * 16);
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int c = 0; c < kBK / 16; ++c) {
+        f32x4 a[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], bcur[s], acc[mt][nt], 0, 0, 0);
-      }
-      bcur = bnxt;
+          a[mt] = *reinterpret_cast<const f32x4*>(&As[(wave * 16 * MT + mt * 16 + fr) * kLS + c * 16 + fg * 4]);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[mt] = anxt[mt];
-#if GNNRAG_GEMM_PREFETCH == 2
-      // pin the emitted order: next step's fragment read first, then this step's MFMAs
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT, 0);
-#endif
+        for (int nt = 0; nt < NT; ++nt) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(&Ws[(nt * 16 + fr) * kLS + c * 16 + fg * 4]);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], b[s], acc[mt][nt], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+      // one 16x16x32 MFMA spans the whole 32-wide k tile: lane (fr, fg) supplies k = 8*fg..8*fg+7
+      bf16x8 a[MT][3];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          a[mt][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(
+              &As[(wave * 16 * MT + mt * 16 + fr) * kLS + pl * 16 + fg * 4]));
+      // the six plane products of one accumulator form a dependent chain: keep two accumulators
+      // in flight (both row tiles, or two column tiles when MT == 1)
+      constexpr int NG = (MT == 1) ? 2 : 1;
+#pragma unroll
+      for (int nt0 = 0; nt0 < NT; nt0 += NG) {
+        bf16x8 b[NG][3];
+#pragma unroll
+        for (int q = 0; q < NG; ++q)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            b[q][pl] = (nt0 + q < NT) ? __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(
+                                            &Ws[((nt0 + q) * 16 + fr) * kLS + pl * 16 + fg * 4]))
+                                      : a[0][pl];
+        // (A plane, B plane) pairs, smallest terms first: mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi
+        constexpr int PA[6] = {1, 2, 0, 1, 0, 0};
+        constexpr int PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < NG; ++q)
+              if (nt0 + q < NT)
+                acc[mt][nt0 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][PA[p]], b[q][PB[p]],
+                                                                           acc[mt][nt0 + q], 0, 0, 0);
+      }
     }
-#endif
     __syncthreads();
     if (t + 1 < nT) {
       sstore();
@@ -501,6 +544,9 @@ __global__ __launch_bounds__(256) void k_score_rows(const float* __restrict__ h,
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// process-wide math mode of the dense projections (like a BLAS math mode): 0 = fp32 MFMA, 1 = bf16x3
+static int g_dense_math = 0;
+
 // ---- skinny problems (M up to a few thousand rows, e.g. the [R1,D] relation transforms) ------
 // The tiled kernel would run them on M/128 workgroups (5 for R1 = 602) and be latency bound.
 // Here one wave owns a 16 x 64 output tile and reads its MFMA fragments straight from global
@@ -570,15 +616,18 @@ static int launch_gemm(GemmArgs g, hipStream_t stream) {
   const int bm = small_tiles ? 64 : 128;
   const dim3 grid((g.M + bm - 1) / bm, ny);
   const int ncol = g.Nout - g.n0;
+  const bool b3 = g_dense_math == 1;
   g.v4out = (g.Nout % 4 == 0) && (g.n0 % 4 == 0) && aligned16(g.C) && (g.add == nullptr || aligned16(g.add));
 #define GNNRAG_GEMM_CASE(NT)                                                                               \
   do {                                                                                                     \
     if (small_tiles) {                                                                                     \
-      if (v4) hipLaunchKernelGGL((k_gemm_f32<NT, 1, true, EPI, AMODE>), grid, dim3(256), 0, stream, g);    \
-      else hipLaunchKernelGGL((k_gemm_f32<NT, 1, false, EPI, AMODE>), grid, dim3(256), 0, stream, g);      \
+      if (v4 && b3) hipLaunchKernelGGL((k_gemm_f32<NT, 1, true, EPI, AMODE, 1>), grid, dim3(256), 0, stream, g); \
+      else if (v4) hipLaunchKernelGGL((k_gemm_f32<NT, 1, true, EPI, AMODE, 0>), grid, dim3(256), 0, stream, g);  \
+      else hipLaunchKernelGGL((k_gemm_f32<NT, 1, false, EPI, AMODE, 0>), grid, dim3(256), 0, stream, g);   \
     } else {                                                                                               \
-      if (v4) hipLaunchKernelGGL((k_gemm_f32<NT, 2, true, EPI, AMODE>), grid, dim3(256), 0, stream, g);    \
-      else hipLaunchKernelGGL((k_gemm_f32<NT, 2, false, EPI, AMODE>), grid, dim3(256), 0, stream, g);      \
+      if (v4 && b3) hipLaunchKernelGGL((k_gemm_f32<NT, 2, true, EPI, AMODE, 1>), grid, dim3(256), 0, stream, g); \
+      else if (v4) hipLaunchKernelGGL((k_gemm_f32<NT, 2, true, EPI, AMODE, 0>), grid, dim3(256), 0, stream, g);  \
+      else hipLaunchKernelGGL((k_gemm_f32<NT, 2, false, EPI, AMODE, 0>), grid, dim3(256), 0, stream, g);   \
     }                                                                                                      \
   } while (0)
   if (ncol <= 64) GNNRAG_GEMM_CASE(4);
@@ -592,6 +641,14 @@ static int launch_gemm(GemmArgs g, hipStream_t stream) {
 }  // namespace gnnrag
 
 using namespace gnnrag;
+
+extern "C" int gnnrag_set_dense_math(int mode) {
+  if (mode != GNNRAG_MATH_FP32 && mode != GNNRAG_MATH_BF16X3) return GNNRAG_E_BADARG;
+  g_dense_math = mode;
+  return 0;
+}
+
+extern "C" int gnnrag_get_dense_math(void) { return g_dense_math; }
 
 extern "C" int gnnrag_linear(const float* A, int64_t M, int32_t K, const float* W, const float* bias,
                              const float* add, int64_t add_rows, int relu, float* C, int32_t Nout,

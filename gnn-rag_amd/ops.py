@@ -346,6 +346,22 @@ def reason_layer(plan: CsrPlan, h, dist, ins, relfeat, relfeat_inv, W_rel, b_rel
     return h_out, score, dist_out
 
 
+MATH_FP32, MATH_BF16X3 = 0, 1
+
+
+def set_dense_math(mode: int) -> int:
+    """Math mode of the dense projections (process wide): MATH_FP32 (exact fp32 MFMA) or
+    MATH_BF16X3 (exact 3-way bf16 split, six plane products, fp32 accumulate).  Returns the old mode."""
+    lib = _lib.load()
+    old = lib.gnnrag_get_dense_math()
+    _lib.check(lib.gnnrag_set_dense_math(int(mode)), "gnnrag_set_dense_math")
+    return old
+
+
+def get_dense_math() -> int:
+    return _lib.load().gnnrag_get_dense_math()
+
+
 def stream_copy(src: torch.Tensor, dst: torch.Tensor):
     lib = _lib.load()
     with torch.cuda.device(src.device):

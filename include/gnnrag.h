@@ -85,6 +85,17 @@ int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const int32_t* t
 int gnnrag_csr_permute_weight(const gnnrag_csr* csr, const float* w_per_fact, int square,
                               float* out_fwd, float* out_inv, gnnrag_stream_t stream);
 
+/* Math mode of the dense projections (gnnrag_linear on large M, gnnrag_update_score*,
+ * gnnrag_relation_tables), process wide like a BLAS math mode:
+ *   GNNRAG_MATH_FP32   v_mfma_f32_16x16x4_f32: bit-exact fp32 fmaf chains (default);
+ *   GNNRAG_MATH_BF16X3 each fp32 operand split EXACTLY into three bf16 planes, six plane products
+ *                      on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: per-product relative
+ *                      error <= 3*2^-24 (fp32 class), about 2.5x the fp32 MFMA rate. */
+#define GNNRAG_MATH_FP32   0
+#define GNNRAG_MATH_BF16X3 1
+int gnnrag_set_dense_math(int mode);
+int gnnrag_get_dense_math(void);
+
 /* C[M,Nout] = act( A[M,K] . W[Nout,K]^T + bias[Nout] + add[row < add_rows, :] ), fp32 MFMA.
  * Used for  T_d = rel_linear_step(rel_features_d) (+ pos_emb_d(rel)), computed once per
  * relation row instead of once per fact (reasongnn.py:71,75-79 / :98,102-105), and for

@@ -357,6 +357,67 @@ def test_full_size_properties_c2(dev, path):
     assert torch.equal(torch.cat(parts, 0), dist)
 
 
+@pytest.fixture
+def bf16x3(dev):
+    from gnnrag_amd import ops
+    old = ops.set_dense_math(ops.MATH_BF16X3)
+    yield
+    ops.set_dense_math(old)
+
+
+@pytest.mark.parametrize("M,K,Nout", [(5000, 200, 200), (6000, 1000, 200), (4500, 250, 50), (40000, 400, 200)])
+def test_bf16x3_linear_is_fp32_class(dev, bf16x3, M, K, Nout):
+    """The split-bf16 math mode against float64, and against the exact-fp32 MFMA mode: its error must
+    be of the same class (fp32 rounding), not bf16 class."""
+    from gnnrag_amd import ops
+    rng = np.random.default_rng(K)
+    A = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-6, 6, (M, 1)))).astype(np.float32)   # wide dynamic range
+    W = (rng.standard_normal((Nout, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(Nout).astype(np.float32)
+    want = A.astype(np.float64) @ W.astype(np.float64).T + b
+    Ad, Wd, bd = _to_dev(dev, A, W, b)
+    got3 = ops.linear(Ad, Wd, bd).cpu().numpy()
+    ops.set_dense_math(ops.MATH_FP32)
+    got32 = ops.linear(Ad, Wd, bd).cpu().numpy()
+    ops.set_dense_math(ops.MATH_BF16X3)
+    scale = np.abs(A).astype(np.float64) @ np.abs(W).astype(np.float64).T + np.abs(b)      # sum |a||w|
+    e3 = (np.abs(got3 - want) / scale).max()
+    e32 = (np.abs(got32 - want) / scale).max()
+    assert e3 <= 4e-7, (e3, e32)            # fp32 class: a few ulp of the absolute-value sum
+    assert e3 <= 8 * max(e32, 6e-8), (e3, e32)
+
+
+@pytest.mark.parametrize("path", [1, 2], ids=["unfused", "fused"])
+@pytest.mark.parametrize("name", ["layer_d200.npz", "layer_d50.npz"])
+def test_bf16x3_layer_stack_matches_reference_fixture(dev, bf16x3, name, path):
+    from gnnrag_amd import stack
+    cfg, batch, feats, params, ref = load_golden(name)
+    out = stack.run_stack(batch, feats, params, dev, path=path)
+    mask = batch.local_entity != batch.num_entity
+    for c in range(cfg.T * cfg.L):
+        dh = np.abs(out["h"][c] - ref["h"][c]).max()
+        dd = np.abs(out["dist"][c] - ref["dist"][c]).max()
+        ds = np.abs(out["score"][c][mask] - ref["score"][c][mask]).max() if mask.any() else 0.0
+        assert dh <= TOL_INTERNAL and dd <= TOL_INTERNAL and ds <= TOL_INTERNAL, (c, dh, dd, ds)
+        assert (out["dist"][c].argmax(1) == ref["dist"][c].argmax(1)).all()
+
+
+def test_bf16x3_mid_size_vs_torch_cpu_oracle(dev, bf16x3):
+    import oracle.rearev_torch_cpu as otorch
+    from gnnrag_amd import stack, synth
+    cfg = synth.GraphConfig(name="mid", B=4, N=2000, E=10000, R=600, D=200, I=2, L=3, T=2, seed=21)
+    batch = synth.make_batch(cfg)
+    feats = synth.make_features(cfg)
+    params = synth.make_layer_params(cfg)
+    want = otorch.run_stack(batch, feats, params)
+    for path in (1, 2):
+        got = stack.run_stack(batch, feats, params, dev, path=path)
+        for c in range(cfg.T * cfg.L):
+            assert np.abs(got["h"][c] - want["h"][c]).max() <= TOL_INTERNAL, (path, c)
+            assert np.abs(got["dist"][c] - want["dist"][c]).max() <= TOL_INTERNAL, (path, c)
+            assert (got["dist"][c].argmax(1) == want["dist"][c].argmax(1)).all()
+
+
 def test_inference_only_and_no_cpu_fallback(dev):
     from gnnrag_amd import _lib, stack, synth
     cfg = synth.CONFIGS["tiny"]
