@@ -76,10 +76,12 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    distributed = world > 1
+    # GNNRAG_FORCE_DIST=1 runs the RCCL path with world size 1 (single-GPU boxes: exercises init + all-gather)
+    distributed = world > 1 or os.environ.get("GNNRAG_FORCE_DIST") == "1"
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import gnnrag_amd  # noqa: F401

@@ -27,11 +27,14 @@
 #ifndef GNNRAG_GEMM_BRANCHLESS
 #define GNNRAG_GEMM_BRANCHLESS 0
 #endif
+#ifndef GNNRAG_GEMM_MT1_NW
+#define GNNRAG_GEMM_MT1_NW 8     // waves per workgroup of the 1-row-tile-per-wave variant (4 -> 64 rows, 8 -> 128 rows)
+#endif
+#ifndef GNNRAG_GEMM_PF2
+#define GNNRAG_GEMM_PF2 0        // A tiles requested two k-tiles ahead (plain A only)
+#endif
 #ifndef GNNRAG_GEMM_EPILOGUE
 #define GNNRAG_GEMM_EPILOGUE 1   // 0 = direct stores from the MFMA layout, 1 = staged through LDS (row-wise, coalesced)
-#endif
-#ifndef GNNRAG_GEMM_MT1_WAVES
-#define GNNRAG_GEMM_MT1_WAVES 3  // min waves/SIMD requested for the 64-row-tile variant
 #endif
 
 namespace gnnrag {
@@ -183,15 +186,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 //   staged to LDS and the product is formed from the six plane pairs that matter (hi*hi, hi*mid,
 //   mid*hi, hi*lo, lo*hi, mid*mid; the dropped ones are <= 3 * 2^-24 relative) with
 //   v_mfma_f32_16x16x32_bf16, fp32 accumulate: fp32-class accuracy at 6/16 of the fp32 MFMA time.
-template <int NT, int MT, bool V4, int EPI, int AMODE, int MATH>
-__global__ __launch_bounds__(256, (MT == 1 ? GNNRAG_GEMM_MT1_WAVES : 2)) void k_gemm_f32(GemmArgs g) {
+template <int NT, int MT, bool V4, int EPI, int AMODE, int MATH, int NW>
+__global__ __launch_bounds__(NW * 64, (MT == 2 ? 2 : NW == 8 ? 4 : 3))
+void k_gemm_f32(GemmArgs g) {
+  constexpr int RPR = NW * 8;                               // staging rows per round (8 threads per row)
   constexpr int kLS = MATH ? 56 : 40;         // LDS row stride in floats (both conflict-free for ds_read_b128)
-  constexpr int BM = 64 * MT;                 // rows per workgroup: 4 waves x MT accumulator row-tiles of 16
-  constexpr int AR = BM / 32;                 // A staging rounds (32 rows per round)
-  constexpr int WR = (NT * 16 + 31) / 32;     // W staging rounds (32 rows per round)
+  constexpr int BM = 16 * MT * NW;            // rows per workgroup: NW waves x MT accumulator row-tiles of 16
+  constexpr int AR = BM / RPR;                // A staging rounds
+  constexpr int WR = (NT * 16 + RPR - 1) / RPR;   // W staging rounds
   constexpr int LD = NT * 16 + 4;             // epilogue staging row stride (floats)
   constexpr int kTileFloats = (BM + NT * 16) * kLS;
-  constexpr int kStageFloats = 4 * 8 * LD;     // epilogue: 8 rows per wave at a time
+  constexpr int kStageFloats = NW * 8 * LD;    // epilogue: 8 rows per wave at a time
   constexpr int kSmemFloats = kTileFloats > kStageFloats ? kTileFloats : kStageFloats;
   __shared__ __attribute__((aligned(16))) float smem[kSmemFloats];
   float* As = smem;
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? GNNRAG_GEMM_MT1_WAVES : 2)) void k_
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int lr = tid >> 3;   // staging row 0..31
+  const int lr = tid >> 3;   // staging row 0..RPR-1
   const int kq = tid & 7;    // staging float4 within the 32-wide k tile
   const int m0 = blockIdx.x * BM;
   const int n0 = g.n0;
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? GNNRAG_GEMM_MT1_WAVES : 2)) void k_
     g.C += (size_t)dir * g.M * g.Nout;
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
-      const int m = m0 + lr + 32 * r;
+      const int m = m0 + lr + RPR * r;
       const int mm = m < g.M ? m : 0;
       const int b = mm / g.gen_R1, rr = mm - b * g.gen_R1;
       gen_t[r] = (m < g.M) ? g.A0 + (size_t)rr * g.gen_D : nullptr;
@@ -238,7 +243,14 @@ __global__ __launch_bounds__(256, (MT == 1 ? GNNRAG_GEMM_MT1_WAVES : 2)) void k_
   const int nT = (g.K + kBK - 1) / kBK;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  auto gload = [&](int t) {
+  constexpr bool PF2 = GNNRAG_GEMM_PF2 && AMODE == AMODE_PLAIN;
+  f32x4 ra2[PF2 ? AR : 1];
+  auto gload_a = [&](int t, f32x4 (&dst)[PF2 ? AR : 1]) {       // PF2 only: A tile t -> dst
+    const int k = t * kBK + kq * 4;
+#pragma unroll
+    for (int r = 0; r < (PF2 ? AR : 1); ++r) dst[r] = load_a4<V4, AMODE>(g, m0 + lr + RPR * r, k);
+  };
+  auto gload = [&](int t, bool with_a) {
     const int k = t * kBK + kq * 4;
     if constexpr (AMODE == AMODE_GEN && V4) {
       const bool kok = k < g.K;
@@ -256,7 +268,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? GNNRAG_GEMM_MT1_WAVES : 2)) void k_
       }
 #pragma unroll
       for (int r = 0; r < WR; ++r) {
-        const int j = lr + 32 * r;
+        const int j = lr + RPR * r;
         const bool ok = j < NT * 16 && n0 + j < g.Nout && kok;
         const f32x4 x = *reinterpret_cast<const f32x4*>(g.W + (size_t)(ok ? n0 + j : 0) * g.ldw + (ok ? wcol : 0));
         rw[r] = ok ? x : zero4;
@@ -273,7 +285,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? GNNRAG_GEMM_MT1_WAVES : 2)) void k_
       }
 #pragma unroll
       for (int r = 0; r < WR; ++r) {
-        const int j = lr + 32 * r;
+        const int j = lr + RPR * r;
         rw[r] = zero4;
         if (j < NT * 16 && n0 + j < g.Nout && kok)
           rw[r] = *reinterpret_cast<const f32x4*>(g.W + (size_t)(n0 + j) * g.ldw + wcol);
@@ -282,11 +294,13 @@ __global__ __launch_bounds__(256, (MT == 1 ? GNNRAG_GEMM_MT1_WAVES : 2)) void k_
       gen_kk += kBK;                       // next tile's column state
       while (gen_kk >= g.gen_D) { gen_kk -= g.gen_D; ++gen_i; }
     } else {
+      if (with_a) {
 #pragma unroll
-      for (int r = 0; r < AR; ++r) ra[r] = load_a4<V4, AMODE>(g, m0 + lr + 32 * r, k);
+        for (int r = 0; r < AR; ++r) ra[r] = load_a4<V4, AMODE>(g, m0 + lr + RPR * r, k);
+      }
 #pragma unroll
       for (int r = 0; r < WR; ++r) {
-        const int j = lr + 32 * r;
+        const int j = lr + RPR * r;
         rw[r] = (j < NT * 16) ? load_w4<V4, AMODE>(g, n0 + j, k) : zero4;
       }
     }
@@ -294,10 +308,10 @@ __global__ __launch_bounds__(256, (MT == 1 ? GNNRAG_GEMM_MT1_WAVES : 2)) void k_
   auto sstore = [&]() {
     if constexpr (MATH == 0) {
 #pragma unroll
-      for (int r = 0; r < AR; ++r) *reinterpret_cast<f32x4*>(&As[(lr + 32 * r) * kLS + kq * 4]) = ra[r];
+      for (int r = 0; r < AR; ++r) *reinterpret_cast<f32x4*>(&As[(lr + RPR * r) * kLS + kq * 4]) = ra[r];
 #pragma unroll
       for (int r = 0; r < WR; ++r) {
-        const int j = lr + 32 * r;
+        const int j = lr + RPR * r;
         if (j < NT * 16) *reinterpret_cast<f32x4*>(&Ws[j * kLS + kq * 4]) = rw[r];
       }
     } else {
@@ -305,14 +319,14 @@ __global__ __launch_bounds__(256, (MT == 1 ? GNNRAG_GEMM_MT1_WAVES : 2)) void k_
 #pragma unroll
       for (int r = 0; r < AR; ++r) {
         const Split3 sp = split3(ra[r]);
-        float* row = &As[(lr + 32 * r) * kLS + kq * 2];
+        float* row = &As[(lr + RPR * r) * kLS + kq * 2];
         *reinterpret_cast<uint2*>(row) = sp.hi;
         *reinterpret_cast<uint2*>(row + 16) = sp.mid;
         *reinterpret_cast<uint2*>(row + 32) = sp.lo;
       }
 #pragma unroll
       for (int r = 0; r < WR; ++r) {
-        const int j = lr + 32 * r;
+        const int j = lr + RPR * r;
         if (j < NT * 16) {
           const Split3 sp = split3(rw[r]);
           float* row = &Ws[j * kLS + kq * 2];
@@ -324,14 +338,26 @@ __global__ __launch_bounds__(256, (MT == 1 ? GNNRAG_GEMM_MT1_WAVES : 2)) void k_
     }
   };
 
-  gload(0);
+  gload(0, true);
   sstore();
   __syncthreads();
+  if constexpr (PF2) {
+    if (nT > 1) {                      // A(1) in flight while tile 0 is multiplied
+      const int k = kBK + kq * 4;
+#pragma unroll
+      for (int r = 0; r < AR; ++r) ra[r] = load_a4<V4, AMODE>(g, m0 + lr + RPR * r, k);
+    }
+  }
 
   const int fr = lane & 15;  // fragment row (A) / column (W) inside a 16x16 tile
   const int fg = lane >> 4;  // k group
   for (int t = 0; t < nT; ++t) {
-    if (t + 1 < nT) gload(t + 1);
+    // LDS holds tile t.  Without PF2: request tile t+1 (A and W).  With PF2: ra already holds A(t+1)
+    // (requested one iteration ago); request W(t+1) (L2 resident) and A(t+2) (HBM) now.
+    if (t + 1 < nT) gload(t + 1, !PF2);
+    if constexpr (PF2) {
+      if (t + 2 < nT) gload_a(t + 2, ra2);
+    }
     if constexpr (MATH == 0) {
 #pragma unroll
       for (int c = 0; c < kBK / 16; ++c) {
@@ -390,6 +416,10 @@ __global__ __launch_bounds__(256, (MT == 1 ? GNNRAG_GEMM_MT1_WAVES : 2)) void k_
     if (t + 1 < nT) {
       sstore();
       __syncthreads();
+    }
+    if constexpr (PF2) {
+#pragma unroll
+      for (int r = 0; r < AR; ++r) ra[r] = ra2[r];
     }
   }
 
@@ -613,27 +643,40 @@ static int launch_gemm(GemmArgs g, hipStream_t stream) {
   // mid-size problems (a few hundred tiles) run as twice as many 64-row tiles
   const int tiles128 = ((g.M + 127) / 128) * ny;
   const bool small_tiles = tiles128 < 1024;
-  const int bm = small_tiles ? 64 : 128;
+  // one 16-row tile per wave: 8-wave workgroups (128 rows, 4 waves/SIMD resident) when that still
+  // fills the chip evenly, else 4-wave workgroups (64 rows)
+  const int slots8 = 512;
+  const int t8 = tiles128;
+  const bool nw8 = small_tiles && (t8 >= 3 * slots8 / 2 || (t8 % slots8 == 0) || (t8 % slots8) > slots8 / 2) &&
+                   GNNRAG_GEMM_MT1_NW == 8;
+  const int bm = small_tiles ? (nw8 ? 128 : 64) : 128;
   const dim3 grid((g.M + bm - 1) / bm, ny);
   const int ncol = g.Nout - g.n0;
   const bool b3 = g_dense_math == 1;
   g.v4out = (g.Nout % 4 == 0) && (g.n0 % 4 == 0) && aligned16(g.C) && (g.add == nullptr || aligned16(g.add));
-#define GNNRAG_GEMM_CASE(NT)                                                                               \
-  do {                                                                                                     \
-    if (small_tiles) {                                                                                     \
-      if (v4 && b3) hipLaunchKernelGGL((k_gemm_f32<NT, 1, true, EPI, AMODE, 1>), grid, dim3(256), 0, stream, g); \
-      else if (v4) hipLaunchKernelGGL((k_gemm_f32<NT, 1, true, EPI, AMODE, 0>), grid, dim3(256), 0, stream, g);  \
-      else hipLaunchKernelGGL((k_gemm_f32<NT, 1, false, EPI, AMODE, 0>), grid, dim3(256), 0, stream, g);   \
-    } else {                                                                                               \
-      if (v4 && b3) hipLaunchKernelGGL((k_gemm_f32<NT, 2, true, EPI, AMODE, 1>), grid, dim3(256), 0, stream, g); \
-      else if (v4) hipLaunchKernelGGL((k_gemm_f32<NT, 2, true, EPI, AMODE, 0>), grid, dim3(256), 0, stream, g);  \
-      else hipLaunchKernelGGL((k_gemm_f32<NT, 2, false, EPI, AMODE, 0>), grid, dim3(256), 0, stream, g);   \
-    }                                                                                                      \
+#define GNNRAG_GEMM_LAUNCH(NT, MT, V, MATH, NW) \
+  hipLaunchKernelGGL((k_gemm_f32<NT, MT, V, EPI, AMODE, MATH, NW>), grid, dim3(64 * NW), 0, stream, g)
+#define GNNRAG_GEMM_CASE(NT)                                                        \
+  do {                                                                              \
+    if (small_tiles && nw8) {                                                       \
+      if (v4 && b3) GNNRAG_GEMM_LAUNCH(NT, 1, true, 1, 8);                          \
+      else if (v4) GNNRAG_GEMM_LAUNCH(NT, 1, true, 0, 8);                           \
+      else GNNRAG_GEMM_LAUNCH(NT, 1, false, 0, 8);                                  \
+    } else if (small_tiles) {                                                       \
+      if (v4 && b3) GNNRAG_GEMM_LAUNCH(NT, 1, true, 1, 4);                          \
+      else if (v4) GNNRAG_GEMM_LAUNCH(NT, 1, true, 0, 4);                           \
+      else GNNRAG_GEMM_LAUNCH(NT, 1, false, 0, 4);                                  \
+    } else {                                                                        \
+      if (v4 && b3) GNNRAG_GEMM_LAUNCH(NT, 2, true, 1, 4);                          \
+      else if (v4) GNNRAG_GEMM_LAUNCH(NT, 2, true, 0, 4);                           \
+      else GNNRAG_GEMM_LAUNCH(NT, 2, false, 0, 4);                                  \
+    }                                                                               \
   } while (0)
   if (ncol <= 64) GNNRAG_GEMM_CASE(4);
   else if (ncol <= 128) GNNRAG_GEMM_CASE(8);
   else GNNRAG_GEMM_CASE(13);
 #undef GNNRAG_GEMM_CASE
+#undef GNNRAG_GEMM_LAUNCH
   GNNRAG_LAUNCH_CHECK();
   return 0;
 }

@@ -14,11 +14,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
 VARIANTS = {
-    "full": {"GNNRAG_SLICE_ABLATE": 0},
-    "nomed": {"GNNRAG_SLICE_ABLATE": 64},
-    "nohuge": {"GNNRAG_SLICE_ABLATE": 128},
-    "nopass2": {"GNNRAG_SLICE_ABLATE": 2},
-    "nowalk": {"GNNRAG_SLICE_ABLATE": 2 + 32 + 16},
+    "nw4_w3": {"GNNRAG_GEMM_MT1_NW": 4, "GNNRAG_GEMM_MT1_WAVES": 3},
+    "nw8_w4": {"GNNRAG_GEMM_MT1_NW": 8, "GNNRAG_GEMM_MT1_WAVES": 4},
+    "nw8_w2": {"GNNRAG_GEMM_MT1_NW": 8, "GNNRAG_GEMM_MT1_WAVES": 2},
 }
 
 CHILD = r'''
@@ -34,15 +32,24 @@ batch = synth.make_batch(cfg); feats = synth.make_features(cfg); params = synth.
 devin = stack.DeviceInputs(batch, feats, dev)
 layer = stack.build_layer(cfg, batch, params, dev)
 stack.init_reason(layer, batch, devin, devin.h0)
+B, N, D, I = cfg.B, cfg.N, cfg.D, cfg.I
 with torch.no_grad():
     dense, _ = layer(devin.seed_dist, devin.ins[0], step=0)
-    rl, e2e = layer.rel_linear1, layer.e2e_linear1
+    rl, e2e, sf = layer.rel_linear1, layer.e2e_linear1, layer.score_func
+    h = devin.h0.reshape(B * N, D)
     Tf = ops.linear(devin.rel_features, rl.weight, rl.bias); Ti = ops.linear(devin.rel_features_inv, rl.weight, rl.bias)
     P = ops.relation_tables(Tf, Ti, devin.ins[0], e2e.weight)
+    nbr = ops.aggregate_fused(layer.plan, dense, P)
+    agg = ops.aggregate(layer.plan, dense, devin.ins[0], Tf, Ti)
     ms = {}
-    for name, prior in (("fused_dense", dense), ("fused_seed", devin.seed_dist)):
-        ops.aggregate_fused(layer.plan, prior, P)
-        ms[name] = float(np.mean(bench._events_ms(lambda: ops.aggregate_fused(layer.plan, prior, P), 10)))
+    for math in (0, 1):
+        ops.set_dense_math(math)
+        fns = {"tables": lambda: ops.relation_tables(Tf, Ti, devin.ins[0], e2e.weight),
+               "upd": lambda: ops.update_score(h, agg, e2e.weight, e2e.bias, sf.weight, sf.bias, layer.local_entity_mask, I),
+               "upd_fused": lambda: ops.update_score_fused(h, nbr, e2e.weight, e2e.bias, sf.weight, sf.bias, layer.local_entity_mask, I)}
+        for name, fn in fns.items():
+            fn()
+            ms["%%s_m%%d" %% (name, math)] = float(np.mean(bench._events_ms(fn, 10)))
 print("RESULT " + json.dumps(ms))
 '''
 
