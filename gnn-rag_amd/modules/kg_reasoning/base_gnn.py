@@ -38,6 +38,11 @@ def _device_from_args(args) -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
+def _check_gpu_tensor(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise GnnragError("%s needs GPU tensors (got %s); gnnrag_amd has no CPU fallback" % (what, t.device))
+
+
 class BaseGNNLayer(torch.nn.Module):
     """Builds the sparse structure of a batch (reference: base_gnn.py:9-54)."""
 

@@ -10,6 +10,7 @@ import torch.nn as nn
 
 from .. import ops
 from .._lib import GnnragError
+from .kg_reasoning import base_gnn
 from .kg_reasoning.base_gnn import plan_for
 
 VERY_NEG_NUMBER = -100000000000
@@ -31,8 +32,7 @@ class TypeLayer(nn.Module):
     def forward(self, local_entity, edge_list, rel_features):
         if torch.is_grad_enabled():
             raise GnnragError("gnnrag_amd.TypeLayer is inference-only: call it under torch.no_grad()")
-        if not rel_features.is_cuda:
-            raise GnnragError("gnnrag_amd.TypeLayer needs GPU tensors; there is no CPU fallback")
+        base_gnn._check_gpu_tensor(rel_features, "gnnrag_amd.TypeLayer")
         batch_size, max_local_entity = local_entity.size()
         plan = plan_for(edge_list, batch_size, max_local_entity, rel_features.size(0), rel_features.device)
         if self.norm_rel:

@@ -1,0 +1,171 @@
+"""Drop-in check against the LIVE reference (build container only; skipped where /root/reference
+is absent, e.g. on the GPU box).
+
+The reference's own ReaRev model, data loader and Evaluator run unchanged; its `reasoning` layer and
+`type_layer` are replaced by this package's modules (`install.swap`).  There is no GPU here, so the
+native calls (`ops.CsrPlan`, `ops.reason_layer`, `ops.linear`, `ops.typelayer`) are monkeypatched -
+in this test only - by the CPU oracle.  What is verified is everything on the host side of the
+C ABI: class surface, parameter names (state_dict carries over), the exact call sequence
+ReaRev.forward makes (TypeLayer first, same kb_adj_mat tuple, init_reason, T x L layer calls with
+the instructions QueryReform produces), side effects the model reads back, and that the unmodified
+Evaluator reports identical Hits@1 / F1."""
+import copy
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+REF = "/root/reference/gnn"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="live reference not available")
+
+
+class FakePlan:
+    def __init__(self, heads, rels, tails, B, N, R1, device, validate=True):
+        self.et = [np.asarray(heads), np.asarray(rels), np.asarray(tails)]
+        self.B, self.N, self.R1, self.F = B, N, R1, len(self.et[0])
+        self.w_gnn = self.w_rel = None
+
+    def attach_w_gnn(self, w):
+        self.w_gnn = list(w)
+
+    def attach_w_rel(self, w):
+        self.w_rel = list(w)
+
+    def tuple7(self):
+        F = self.F
+        one = [1.0] * F
+        return (self.et[0], self.et[1], self.et[2], self.et[0] // self.N, np.arange(F),
+                self.w_gnn or one, self.w_rel or one)
+
+
+def _patch_backend(monkeypatch):
+    import oracle.rearev_torch_cpu as otorch
+    from gnnrag_amd import ops
+    from gnnrag_amd.modules.kg_reasoning import base_gnn
+
+    def reason_layer(plan, h, dist, ins, relfeat, relfeat_inv, W_rel, b_rel, W_e2e, b_e2e, w_score, b_score,
+                     mask, pos=None, pos_inv=None, ws=None, path=0):
+        st = otorch.Structure(plan.tuple7(), plan.B, plan.N, plan.w_gnn is not None)
+        p = {"rel_linear0.weight": W_rel, "rel_linear0.bias": b_rel, "e2e_linear0.weight": W_e2e,
+             "e2e_linear0.bias": b_e2e, "score_func.weight": w_score.reshape(1, -1), "score_func.bias": b_score}
+        if pos is not None:
+            p["pos_emb0.weight"], p["pos_emb_inv0.weight"] = pos, pos_inv
+        B, N = plan.B, plan.N
+        score, nd, hn = otorch.layer_forward(st, h.reshape(B, N, -1), mask.reshape(B, N), dist.reshape(B, N), ins,
+                                             p, 0, relfeat, relfeat_inv, pos is not None)
+        return hn, score, nd
+
+    def linear(A, W, bias=None, add=None, relu=False):
+        out = torch.nn.functional.linear(A, W, bias)
+        if add is not None:
+            out[: add.shape[0]] += add
+        return torch.relu(out) if relu else out
+
+    def typelayer(plan, T, use_w_rel):
+        h, r, t = (torch.as_tensor(x, dtype=torch.long) for x in plan.et)
+        v = torch.tensor(plan.w_rel, dtype=torch.float32) if use_w_rel else torch.ones(plan.F)
+        msg = T.index_select(0, r) * v[:, None]
+        out = torch.zeros(plan.B * plan.N, T.shape[1])
+        out.index_add_(0, t, msg)
+        out.index_add_(0, h, msg)
+        return torch.relu(out)
+
+    monkeypatch.setattr(ops, "CsrPlan", FakePlan)
+    monkeypatch.setattr(ops, "reason_layer", reason_layer)
+    monkeypatch.setattr(ops, "linear", linear)
+    monkeypatch.setattr(ops, "typelayer", typelayer)
+    monkeypatch.setattr(base_gnn, "_device_from_args", lambda args: torch.device("cpu"))
+    monkeypatch.setattr(base_gnn, "_check_gpu_tensor", lambda t, what: None)
+    base_gnn._last_plan.update(key=None, plan=None, tuple=None)
+
+
+@pytest.fixture(scope="module")
+def reference_setup():
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden                      # dataset writer only
+    import parsing
+    parsing.create_parser_nutrea = lambda p: None                      # reference bug, SURVEY section 4(1)
+    from modules.question_encoding import base_encoder
+    if not getattr(base_encoder.BaseInstruction.__init__, "_gnnrag_shim", False):
+        orig = base_encoder.BaseInstruction.__init__
+
+        def _init(self, args, constraint=False):                       # reference bug, SURVEY section 4(2)
+            orig(self, args, constraint)
+        _init._gnnrag_shim = True
+        base_encoder.BaseInstruction.__init__ = _init
+    tmp = tempfile.mkdtemp(prefix="gnnrag_dropin_")
+    folder = os.path.join(tmp, "synth") + "/"
+    make_golden.write_dataset(folder, np.random.default_rng(17), n_ent=150, n_rel=11, n_q=10)
+    import argparse
+    parser = argparse.ArgumentParser()
+    parsing.add_parse_args(parser)
+    D = 50
+    args = vars(parser.parse_args(
+        ["ReaRev", "--data_folder", folder, "--lm", "lstm", "--relation_word_emb", "False", "--entity_dim", str(D),
+         "--kg_dim", str(D // 2), "--word_dim", "24", "--num_iter", "3", "--num_ins", "2", "--num_gnn", "3",
+         "--batch_size", "4", "--test_batch_size", "4", "--checkpoint_dir", tmp + "/", "--experiment_name", "t",
+         "--name", "synth"]))
+    args["use_cuda"] = False
+    args["word_emb_file"] = None
+    np.random.seed(3)
+    torch.manual_seed(3)
+    from dataset_load import load_data
+    from models.ReaRev.rearev import ReaRev
+    dataset = load_data(args, args["lm"])
+    model = ReaRev(args, len(dataset["entity2id"]), dataset["test"].num_kb_relation, dataset["num_word"])
+    model.eval()
+    return args, dataset, model
+
+
+def test_swapped_model_reproduces_reference_forward(reference_setup, monkeypatch):
+    args, dataset, model = reference_setup
+    from gnnrag_amd import install
+    test = dataset["test"]
+    test.reset_batches(is_sequential=True)
+    np.random.seed(11)
+    batch = test.get_batch(0, 4, fact_dropout=0.0, test=True)
+    with torch.no_grad():
+        _, pred_ref, dist_ref, _ = model(batch[:-1])
+    _patch_backend(monkeypatch)
+    mine = install.swap(copy.deepcopy(model), args)
+    assert type(mine.reasoning).__module__.startswith("gnnrag_amd.")
+    assert type(mine.type_layer).__module__.startswith("gnnrag_amd.")
+    with torch.no_grad():
+        _, pred, dist, _ = mine(batch[:-1])
+    np.testing.assert_allclose(dist.numpy(), dist_ref.numpy(), rtol=0, atol=1e-6)
+    assert torch.equal(pred, pred_ref)
+    # side effects the model / callers read back
+    assert mine.reasoning.local_entity_emb.shape == model.reasoning.local_entity_emb.shape
+    assert len(mine.reasoning.possible_cand) == args["num_iter"] * args["num_gnn"]
+
+
+def test_unmodified_evaluator_reports_identical_metrics(reference_setup, monkeypatch):
+    args, dataset, model = reference_setup
+    from evaluate import Evaluator
+    from gnnrag_amd import install
+    ev_args = dict(args)
+
+    def run(m):
+        np.random.seed(5)
+        ev = Evaluator(args=ev_args, model=m, entity2id=dataset["entity2id"], relation2id=dataset["relation2id"],
+                       device=torch.device("cpu"))
+        return ev.evaluate(dataset["test"], 4, write_info=False)
+
+    ref = run(model)
+    _patch_backend(monkeypatch)
+    mine = run(install.swap(copy.deepcopy(model), args))
+    assert tuple(mine) == tuple(ref), (mine, ref)          # (f1, h1, em): Hits@1 identical
+
+
+def test_autograd_raises_instead_of_detaching(reference_setup, monkeypatch):
+    args, dataset, model = reference_setup
+    from gnnrag_amd import _lib, install
+    _patch_backend(monkeypatch)
+    mine = install.swap(copy.deepcopy(model), args)
+    batch = dataset["test"].get_batch(0, 2, fact_dropout=0.0, test=True)
+    with pytest.raises(_lib.GnnragError):
+        mine(batch[:-1])                                     # grad enabled: no backward kernel yet
