@@ -33,6 +33,11 @@
 //    deterministic, no atomics, scales to hubs with 10^5 facts.
 #include "gnnrag_common.h"
 
+#ifndef GNNRAG_REASON_SLICE
+#define GNNRAG_REASON_SLICE 0    // unfused aggregation through LDS table slices when the tables fit.  Measured (C2):
+                                 // dense prior 258 vs 281 us, seed prior 202 vs 138 us - its 64-byte output pieces
+                                 // (4 per node and slice) lose to the gather walk's full 3200-byte rows, so it is off
+#endif
 #ifndef GNNRAG_SLICE_ABLATE
 #define GNNRAG_SLICE_ABLATE 0   // timing experiments only (tools/tune_variants.py): 1 no staging, 2 no medium/huge pass,
                                 // 4 no sets, 8 no stores, 16 no row walk (structure loads only), 32 no queueing of big nodes,
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(256) void k_fact_prior(const int2* __restrict__ e0,
 // their group held every workgroup for ~65 us).  Hence the wave-wide class.
 constexpr int kSliceLightDeg = 32;
 constexpr int kSliceTeamDeg = 4096;
-constexpr int kSliceMedCap = 96;    // medium nodes of one question kept in LDS (overflow: owner group walks them)
+constexpr int kSliceMedCap = 64;    // medium nodes of one question kept in LDS (overflow: owner group walks them)
 constexpr int kSliceHugeCap = 8;    // huge nodes of one question kept in LDS (overflow: treated as medium)
 
 // one node's rows in both directions + its first 8 (p, rel) pairs per direction
@@ -484,13 +489,33 @@ __device__ __forceinline__ int quad_bcast(int v) {
   return __builtin_amdgcn_mov_dpp(v, K * 0x55, 0xf, 0xf, true);
 }
 
+// Per-lane accumulators of the LDS walk: FUSED sums both directions into one float4; REASON keeps
+// NI float4 (one per instruction) per direction and applies relu(t * q_i) per fact.
+template <int MODE, int NI> struct SliceAcc {
+  static constexpr int n = (MODE == MODE_REASON) ? NI : 1;
+  f32x4 v[n];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < n; ++i) v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+};
+
 // acc += sum over the 4 facts a lane group (one quad) holds one per lane in `pairs`
-__device__ __forceinline__ void slice_fma4(f32x4& acc, int2 pairs, const float* __restrict__ Td) {
+template <int MODE, int NI>
+__device__ __forceinline__ void slice_fma4(SliceAcc<MODE, NI>& acc, int2 pairs, const float* __restrict__ Td,
+                                           const f32x4 (&q)[SliceAcc<MODE, NI>::n]) {
 #define GNNRAG_SLICE_STEP(K)                                                                        \
   {                                                                                                 \
     const float pk = __int_as_float(quad_bcast<K>(pairs.x));                                        \
     const int rk = quad_bcast<K>(pairs.y);                                                          \
-    if (pk != 0.f) acc += pk * *reinterpret_cast<const f32x4*>(Td + (size_t)rk * kSliceW);          \
+    if (pk != 0.f) {                                                                                \
+      const f32x4 t = *reinterpret_cast<const f32x4*>(Td + (size_t)rk * kSliceW);                   \
+      if constexpr (MODE == MODE_REASON) {                                                          \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) acc.v[i] += pk * vrelu(t * q[i]);            \
+      } else {                                                                                      \
+        acc.v[0] += pk * t;                                                                         \
+      }                                                                                             \
+    }                                                                                               \
   }
   GNNRAG_SLICE_STEP(0) GNNRAG_SLICE_STEP(1) GNNRAG_SLICE_STEP(2) GNNRAG_SLICE_STEP(3)
 #undef GNNRAG_SLICE_STEP
@@ -498,8 +523,11 @@ __device__ __forceinline__ void slice_fma4(f32x4& acc, int2 pairs, const float* 
 
 // one direction of one row, walked by a whole wave: 64 facts per step (lane group k owns facts
 // 4k..4k+3 of a step), steps first, first+stride, ...; up to 8 steps requested before consuming
-__device__ __forceinline__ void slice_walk_wave(f32x4& acc, const int2* __restrict__ prd, int beg, int len,
-                                                int first, int stride, int lane, const float* __restrict__ Td) {
+template <int MODE, int NI>
+__device__ __forceinline__ void slice_walk_wave(SliceAcc<MODE, NI>& acc, const int2* __restrict__ prd, int beg,
+                                                int len, int first, int stride, int lane,
+                                                const float* __restrict__ Td,
+                                                const f32x4 (&q)[SliceAcc<MODE, NI>::n]) {
   const int nsteps = (len + 63) >> 6;
   for (int st = first; st < nsteps; st += stride * 8) {
     int2 pairs[8];
@@ -509,27 +537,43 @@ __device__ __forceinline__ void slice_walk_wave(f32x4& acc, const int2* __restri
       pairs[u] = (off < len) ? prd[beg + off] : make_int2(0, 0);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) slice_fma4(acc, pairs[u], Td);
+    for (int u = 0; u < 8; ++u) slice_fma4<MODE, NI>(acc, pairs[u], Td, q);
   }
 }
 
-__device__ __forceinline__ void slice_wave_reduce(f32x4& acc) {
+template <int MODE, int NI>
+__device__ __forceinline__ void slice_wave_reduce(SliceAcc<MODE, NI>& acc) {
 #pragma unroll
-  for (int o = 4; o < 64; o <<= 1) {
+  for (int i = 0; i < SliceAcc<MODE, NI>::n; ++i)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
-  }
+    for (int o = 4; o < 64; o <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc.v[i][e] += __shfl_xor(acc.v[i][e], o, 64);
+    }
 }
 
+// where the float4 of (node n, accumulator i, direction d) goes
+template <int MODE>
+__device__ __forceinline__ float* slice_out(const WalkArgs& a, int n, int i, int d, int col) {
+  if constexpr (MODE == MODE_REASON)
+    return a.out + (size_t)n * (2 * a.I) * a.D + (size_t)(2 * (a.i0 + i) + d) * a.D + col;
+  else
+    return a.out + (size_t)n * a.D + col;
+}
+
+template <int MODE, int NI>
 __global__ __launch_bounds__(kSliceThreads) void k_walk_slice(const WalkArgs a, const int2* __restrict__ pr,
                                                               int64_t F, int nslice) {
+  typedef SliceAcc<MODE, NI> Acc;
+  constexpr int NA = Acc::n;
+  constexpr int ND = (MODE == MODE_REASON) ? 2 : 1;     // output slots per node: per direction / summed
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
   float* Ts = s_mem;                                   // [2][R1][16]
   // ctl: [0] set ticket, [1] medium count, [2] medium ticket, [3] huge count
   int* ctl = reinterpret_cast<int*>(s_mem + (size_t)2 * a.R1 * kSliceW);
   int* mlist = ctl + 16;                               // [kSliceMedCap][5]: node, beg0, len0, beg1, len1
   int* hlist = mlist + 5 * kSliceMedCap;               // [kSliceHugeCap][5]
-  float* red = reinterpret_cast<float*>(hlist + 5 * kSliceHugeCap);   // [16 waves][16 floats]
+  float* red = reinterpret_cast<float*>(hlist + 5 * kSliceHugeCap);   // [16 waves][NA][16 floats]
   // XCD-aware order: the nslice workgroups of question g all land on XCD g % 8
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int g = (slot / nslice) * 8 + xcd;
@@ -539,14 +583,15 @@ __global__ __launch_bounds__(kSliceThreads) void k_walk_slice(const WalkArgs a, 
   const int D = a.D, R1 = a.R1, N = a.N;
   const int tid = threadIdx.x;
   if (tid < 16) ctl[tid] = 0;
-  // stage the two table slices (float4 granules; rows are D*4 bytes apart in P)
+  // stage the two table slices (float4 granules; rows are D*4 bytes apart).  FUSED: the question's own
+  // tables P[d, g]; REASON: the shared tables T_d
   for (int idx = tid; idx < ((GNNRAG_SLICE_ABLATE & 1) ? 0 : 2 * R1 * 4); idx += kSliceThreads) {
     const int d = idx / (R1 * 4);
     const int rem = idx - d * (R1 * 4);
     const int r = rem >> 2, k = rem & 3;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (col0 + 4 * k < D)
-      v = *reinterpret_cast<const f32x4*>(a.T[d] + ((size_t)g * R1 + r) * D + col0 + 4 * k);
+    const float* tab = (MODE == MODE_FUSED) ? a.T[d] + (size_t)g * R1 * D : a.T[d];
+    if (col0 + 4 * k < D) v = *reinterpret_cast<const f32x4*>(tab + (size_t)r * D + col0 + 4 * k);
     *reinterpret_cast<f32x4*>(Ts + ((size_t)d * R1 + r) * kSliceW + 4 * k) = v;
   }
   __syncthreads();
@@ -557,6 +602,13 @@ __global__ __launch_bounds__(kSliceThreads) void k_walk_slice(const WalkArgs a, 
   const bool col_ok = col0 + 4 * sub < D;
   const int2* const prd[2] = {pr, pr + F};
   const float* Td[2] = {Ts + 4 * sub, Ts + (size_t)R1 * kSliceW + 4 * sub};
+  f32x4 q[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    q[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (MODE == MODE_REASON && col_ok)
+      q[i] = *reinterpret_cast<const f32x4*>(a.ins + ((size_t)g * a.I + a.i0 + i) * D + col0 + 4 * sub);
+  }
 
   // ---- light nodes: 4 lanes per node, 16 nodes (a "set") per wave step, sets handed out by an LDS
   // ticket.  The dependent chain ticket -> row pointers -> first pairs -> table slices is software
@@ -606,7 +658,8 @@ __global__ __launch_bounds__(kSliceThreads) void k_walk_slice(const WalkArgs a, 
       }
     }
     if (s0.valid && !s0.big) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      Acc acc;
+      acc.zero();
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
         const int beg = s0.beg[d], len = s0.len[d];
@@ -615,14 +668,20 @@ __global__ __launch_bounds__(kSliceThreads) void k_walk_slice(const WalkArgs a, 
           int2 n0 = make_int2(0, 0), n1 = make_int2(0, 0);
           if (j + 8 + sub < len) n0 = prd[d][beg + j + 8 + sub];
           if (j + 12 + sub < len) n1 = prd[d][beg + j + 12 + sub];
-          slice_fma4(acc, c0, Td[d]);
-          slice_fma4(acc, c1, Td[d]);
+          slice_fma4<MODE, NI>(acc, c0, Td[d], q);
+          slice_fma4<MODE, NI>(acc, c1, Td[d], q);
           c0 = n0;
           c1 = n1;
         }
+        if (ND == 2 || d == 1) {
+          if (col_ok && (!(GNNRAG_SLICE_ABLATE & 8) || acc.v[0][0] == 12345.f)) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+              *reinterpret_cast<f32x4*>(slice_out<MODE>(a, s0.n, i, d, col0 + 4 * sub)) = acc.v[i];
+          }
+          acc.zero();
+        }
       }
-      if (col_ok && (!(GNNRAG_SLICE_ABLATE & 8) || acc[0] == 12345.f))
-        *reinterpret_cast<f32x4*>(a.out + (size_t)s0.n * D + col0 + 4 * sub) = acc;
     }
     s0 = s1; t0 = t1;
     s1 = s2; t1 = t2;
@@ -637,11 +696,21 @@ __global__ __launch_bounds__(kSliceThreads) void k_walk_slice(const WalkArgs a, 
     const int m = ticket(2);
     if (m >= nmed) break;
     const int* e = mlist + 5 * m;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    Acc acc;
+    acc.zero();
 #pragma unroll
-    for (int d = 0; d < 2; ++d) slice_walk_wave(acc, prd[d], e[1 + 2 * d], e[2 + 2 * d], 0, 1, lane, Td[d]);
-    slice_wave_reduce(acc);
-    if (grp == 0 && col_ok) *reinterpret_cast<f32x4*>(a.out + (size_t)e[0] * D + col0 + 4 * sub) = acc;
+    for (int d = 0; d < 2; ++d) {
+      slice_walk_wave<MODE, NI>(acc, prd[d], e[1 + 2 * d], e[2 + 2 * d], 0, 1, lane, Td[d], q);
+      if (ND == 2 || d == 1) {
+        slice_wave_reduce<MODE, NI>(acc);
+        if (grp == 0 && col_ok) {
+#pragma unroll
+          for (int i = 0; i < NA; ++i)
+            *reinterpret_cast<f32x4*>(slice_out<MODE>(a, e[0], i, d, col0 + 4 * sub)) = acc.v[i];
+        }
+        acc.zero();
+      }
+    }
   }
 
   // ---- huge nodes: the whole workgroup per node; wave w takes steps w, w+16, ...; wave sums are
@@ -649,19 +718,29 @@ __global__ __launch_bounds__(kSliceThreads) void k_walk_slice(const WalkArgs a, 
   const int nhuge = (GNNRAG_SLICE_ABLATE & 128) ? 0 : min(ctl[3], kSliceHugeCap);
   for (int h = 0; h < nhuge; ++h) {
     const int* e = hlist + 5 * h;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    Acc acc;
+    acc.zero();
 #pragma unroll
-    for (int d = 0; d < 2; ++d) slice_walk_wave(acc, prd[d], e[1 + 2 * d], e[2 + 2 * d], wave, 16, lane, Td[d]);
-    slice_wave_reduce(acc);
-    if (grp == 0) *reinterpret_cast<f32x4*>(red + wave * 16 + 4 * sub) = acc;
-    __syncthreads();
-    if (tid < 4) {
-      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < 2; ++d) {
+      slice_walk_wave<MODE, NI>(acc, prd[d], e[1 + 2 * d], e[2 + 2 * d], wave, 16, lane, Td[d], q);
+      if (ND == 2 || d == 1) {
+        slice_wave_reduce<MODE, NI>(acc);
+        if (grp == 0) {
 #pragma unroll
-      for (int w = 0; w < 16; ++w) t += *reinterpret_cast<const f32x4*>(red + w * 16 + 4 * tid);
-      if (col0 + 4 * tid < D) *reinterpret_cast<f32x4*>(a.out + (size_t)e[0] * D + col0 + 4 * tid) = t;
+          for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(red + (wave * NA + i) * 16 + 4 * sub) = acc.v[i];
+        }
+        __syncthreads();
+        if (tid < 4 * NA) {
+          const int i = tid >> 2, sb = tid & 3;
+          f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int w = 0; w < 16; ++w) t += *reinterpret_cast<const f32x4*>(red + (w * NA + i) * 16 + 4 * sb);
+          if (col0 + 4 * sb < D) *reinterpret_cast<f32x4*>(slice_out<MODE>(a, e[0], i, d, col0 + 4 * sb)) = t;
+        }
+        __syncthreads();
+        acc.zero();
+      }
     }
-    __syncthreads();
   }
 }
 
@@ -750,9 +829,9 @@ static size_t partial_bytes(const gnnrag_csr* csr, int D, int na) {
 static size_t prior_bytes(const gnnrag_csr* csr) {
   return align_up((size_t)2 * (size_t)(csr->F > 0 ? csr->F : 1) * sizeof(int2), 256);
 }
-static size_t slice_lds_bytes(int R1) {
+static size_t slice_lds_bytes(int R1, int na = 3) {
   return (size_t)2 * R1 * kSliceW * sizeof(float) + (16 + 5 * (kSliceMedCap + kSliceHugeCap)) * sizeof(int) +
-         16 * 16 * sizeof(float);
+         (size_t)na * 16 * 16 * sizeof(float);
 }
 // the LDS variant needs the two table slices of a question in one CU's LDS (160 KB)
 static bool slice_walk_fits(const gnnrag_csr* csr, int D) {
@@ -781,6 +860,35 @@ static int fill_common(WalkArgs& a, const gnnrag_csr* csr, int D, void* ws, size
   return 0;
 }
 
+// k_fact_prior + k_walk_slice<MODE, NI>: the LDS walk of one aggregation call (or one pass of <= 3
+// instructions of it).  na = accumulators whose partial-sum scratch precedes the prior pairs.
+template <int MODE, int NI>
+static int launch_slice(const WalkArgs& a, const gnnrag_csr* csr, void* workspace, size_t workspace_bytes,
+                        int na_ws, hipStream_t stream) {
+  const int D = a.D;
+  if (workspace_bytes < partial_bytes(csr, D, na_ws) + prior_bytes(csr)) return GNNRAG_E_WORKSPACE;
+  int2* pr = (int2*)((char*)workspace + partial_bytes(csr, D, na_ws));
+  const int64_t F = csr->F;
+  if (F > 0 && a.i0 == 0) {     // the (p, rel) pairs do not depend on the instruction pass
+    hipLaunchKernelGGL(k_fact_prior, dim3((unsigned)((F + 255) / 256), 2), dim3(256), 0, stream, a.edge[0],
+                       a.edge[1], a.w[0], a.w[1], a.dist, F, pr);
+    GNNRAG_LAUNCH_CHECK();
+  }
+  const int nslice = (D + kSliceW - 1) / kSliceW;
+  const size_t lds = slice_lds_bytes(csr->R1, SliceAcc<MODE, NI>::n);
+  static bool attr_set = false;   // raising the dynamic-LDS cap is idempotent; once per kernel and process
+  if (!attr_set) {
+    GNNRAG_HIP(hipFuncSetAttribute((const void*)k_walk_slice<MODE, NI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+    attr_set = true;
+  }
+  const int nblk = 8 * ((csr->B + 7) / 8) * nslice;
+  hipLaunchKernelGGL((k_walk_slice<MODE, NI>), dim3(nblk), dim3(kSliceThreads), lds, stream, a, (const int2*)pr, F,
+                     nslice);
+  GNNRAG_LAUNCH_CHECK();
+  return 0;   // hubs were walked inside the kernel, nothing to add afterwards
+}
+
 }  // namespace gnnrag
 
 using namespace gnnrag;
@@ -807,10 +915,18 @@ extern "C" int gnnrag_aggregate(const gnnrag_csr* csr, const float* dist, const 
   a.out = agg;
   a.I = I;
   // up to 3 instructions share one walk (their accumulators live in registers side by side)
+  const bool lds_walk = slice_walk_fits(csr, D) && GNNRAG_REASON_SLICE;
   for (int i0 = 0; i0 < I; i0 += 3) {
     a.i0 = i0;
     const int ni = (I - i0) < 3 ? (I - i0) : 3;
-    rc = launch_walk<MODE_REASON>(a, ni, (hipStream_t)stream);
+    if (lds_walk) {
+      const int na_ws = I < 3 ? I : 3;
+      if (ni == 1) rc = launch_slice<MODE_REASON, 1>(a, csr, workspace, workspace_bytes, na_ws, (hipStream_t)stream);
+      else if (ni == 2) rc = launch_slice<MODE_REASON, 2>(a, csr, workspace, workspace_bytes, na_ws, (hipStream_t)stream);
+      else rc = launch_slice<MODE_REASON, 3>(a, csr, workspace, workspace_bytes, na_ws, (hipStream_t)stream);
+    } else {
+      rc = launch_walk<MODE_REASON>(a, ni, (hipStream_t)stream);
+    }
     if (rc) return rc;
   }
   return 0;
@@ -833,27 +949,7 @@ extern "C" int gnnrag_aggregate_fused(const gnnrag_csr* csr, const float* dist, 
   a.out = out;
   a.I = 1;
   if (!slice_walk_fits(csr, D)) return launch_walk<MODE_FUSED>(a, 1, stream);   // tables too big for LDS
-
-  if (workspace_bytes < partial_bytes(csr, D, 1) + prior_bytes(csr)) return GNNRAG_E_WORKSPACE;
-  int2* pr = (int2*)((char*)workspace + partial_bytes(csr, D, 1));
-  const int64_t F = csr->F;
-  if (F > 0) {
-    hipLaunchKernelGGL(k_fact_prior, dim3((unsigned)((F + 255) / 256), 2), dim3(256), 0, stream, a.edge[0],
-                       a.edge[1], a.w[0], a.w[1], dist, F, pr);
-    GNNRAG_LAUNCH_CHECK();
-  }
-  const int nslice = (D + kSliceW - 1) / kSliceW;
-  const size_t lds = slice_lds_bytes(csr->R1);
-  static bool attr_set = false;   // raising the dynamic-LDS cap is idempotent; do it once per process
-  if (!attr_set) {
-    GNNRAG_HIP(hipFuncSetAttribute((const void*)k_walk_slice, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024));
-    attr_set = true;
-  }
-  const int nblk = 8 * ((csr->B + 7) / 8) * nslice;
-  hipLaunchKernelGGL(k_walk_slice, dim3(nblk), dim3(kSliceThreads), lds, stream, a, (const int2*)pr, F, nslice);
-  GNNRAG_LAUNCH_CHECK();
-  return 0;   // hubs were walked inside the kernel (whole-wave pass), nothing to add afterwards
+  return launch_slice<MODE_FUSED, 1>(a, csr, workspace, workspace_bytes, 1, stream);
 }
 
 extern "C" int gnnrag_typelayer(const gnnrag_csr* csr, const float* T, int use_w_rel, float* h0, int32_t D,
