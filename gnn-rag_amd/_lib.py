@@ -26,6 +26,8 @@ class CsrStruct(C.Structure):
         ("heavy", C.c_void_p * 2), ("chunk_off", C.c_void_p * 2),
         ("n_heavy", C.c_void_p), ("n_chunks", C.c_void_p),
         ("heavy_cap", C.c_int32), ("max_chunks", C.c_int32),
+        ("big_cnt", C.c_void_p), ("big_nodes", C.c_void_p),
+        ("big_deg", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -41,6 +43,8 @@ SIGNATURES = {
     "gnnrag_get_dense_math": (C.c_int, []),
     "gnnrag_linear": (C.c_int, [_VP, C.c_int64, C.c_int32, _VP, _VP, _VP, C.c_int64, C.c_int, _VP,
                                 C.c_int32, _VP]),
+    "gnnrag_linear_pair": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, _VP, _VP, _VP, _VP, C.c_int64, _VP, _VP,
+                                     C.c_int32, _VP]),
     "gnnrag_aggregate_workspace_bytes": (C.c_size_t, [C.POINTER(CsrStruct), C.c_int32, C.c_int32]),
     "gnnrag_aggregate": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32,
                                    _VP, C.c_size_t, _VP]),
@@ -60,7 +64,7 @@ SIGNATURES = {
     "gnnrag_error_string": (C.c_char_p, [C.c_int]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 PATH_AUTO, PATH_UNFUSED, PATH_FUSED = 0, 1, 2
 _lib = None
 

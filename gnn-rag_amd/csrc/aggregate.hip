@@ -41,7 +41,7 @@
 #ifndef GNNRAG_SLICE_ABLATE
 #define GNNRAG_SLICE_ABLATE 0   // timing experiments only (tools/tune_variants.py): 1 no staging, 2 no medium/huge pass,
                                 // 4 no sets, 8 no stores, 16 no row walk (structure loads only), 32 no queueing of big nodes,
-                                // 64 no medium pass, 128 no huge pass
+                                // 64 no medium nodes, 128 no huge nodes
 #endif
 
 namespace gnnrag {
@@ -94,6 +94,9 @@ struct WalkArgs {
   int32_t bpg;                // FUSED: workgroups per question for the XCD-aware mapping (0 = off)
   int32_t dir;                // k_heavy_reduce in read-modify-write modes: direction of this launch
   int32_t heavy_only;         // host side: the light rows were already walked by another kernel
+  const int32_t* big_cnt;     // LDS walk: per-question count / list of nodes with > big_deg facts in a direction
+  const int32_t* big_nodes;
+  int32_t big_deg;
 };
 
 template <int MODE, int NI> struct AccN { static constexpr int n = (MODE == MODE_REASON) ? NI : 1; };
@@ -438,16 +441,17 @@ __global__ __launch_bounds__(256) void k_fact_prior(const int2* __restrict__ e0,
 }
 
 // Node classes of the LDS walk (by the larger of the two directions' fact counts):
-//   light  (<= kSliceLightDeg): a 4-lane group per node, 16 nodes per wave step;
-//   medium (<= kSliceTeamDeg) : one whole wave per node (64 facts per step, 8 steps in flight);
-//   huge                      : the whole workgroup per node.
+//   light  (<= big_deg = 32) : a 4-lane group per node, 16 nodes per wave step;
+//   medium (<= kSliceTeamDeg): one whole wave per node (64 facts per step, 8 steps in flight);
+//   huge                     : the whole workgroup per node.
 // A lane group walks its row with ONE outstanding 8-fact step, i.e. a row of n facts costs n/8
-// dependent L2 round trips - fine for 32 facts, ruinous for 500 (measured: medium rows walked by
-// their group held every workgroup for ~65 us).  Hence the wave-wide class.
-constexpr int kSliceLightDeg = 32;
+// dependent L2 round trips - fine for 32 facts, ruinous for 500.  Hence the wave-wide class.  The big
+// (medium + huge) nodes of every question are listed once at plan time (csr->big_nodes), so a
+// workgroup knows them up front: huge nodes first (whole workgroup), then ONE ticket stream hands
+// out the medium nodes (longest work first) followed by the light sets - no barrier in between.
 constexpr int kSliceTeamDeg = 4096;
-constexpr int kSliceMedCap = 64;    // medium nodes of one question kept in LDS (overflow: owner group walks them)
-constexpr int kSliceHugeCap = 8;    // huge nodes of one question kept in LDS (overflow: treated as medium)
+constexpr int kSliceBigCap = 72;    // big nodes of one question kept in LDS; a question with more is walked
+                                    // entirely by lane groups (slow, correct)
 
 // one node's rows in both directions + its first 8 (p, rel) pairs per direction
 struct SetRows {
@@ -469,7 +473,7 @@ __device__ __forceinline__ void set_load_rows(SetRows& s, const WalkArgs& a, int
     if (s.valid) {
       s.beg[d] = a.row_ptr[d][s.n];
       s.len[d] = a.row_ptr[d][s.n + 1] - s.beg[d];
-      s.big |= s.len[d] > kSliceLightDeg;
+      s.big |= s.len[d] > a.big_deg;
     }
   }
 }
@@ -561,19 +565,19 @@ __device__ __forceinline__ float* slice_out(const WalkArgs& a, int n, int i, int
     return a.out + (size_t)n * a.D + col;
 }
 
+// Two 1024-thread workgroups per CU need 8 waves per SIMD, i.e. <= 64 VGPRs: ask for it where the
+// accumulators allow (one float4 per lane in FUSED mode).
 template <int MODE, int NI>
-__global__ __launch_bounds__(kSliceThreads) void k_walk_slice(const WalkArgs a, const int2* __restrict__ pr,
+__global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k_walk_slice(const WalkArgs a, const int2* __restrict__ pr,
                                                               int64_t F, int nslice) {
   typedef SliceAcc<MODE, NI> Acc;
   constexpr int NA = Acc::n;
   constexpr int ND = (MODE == MODE_REASON) ? 2 : 1;     // output slots per node: per direction / summed
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
   float* Ts = s_mem;                                   // [2][R1][16]
-  // ctl: [0] set ticket, [1] medium count, [2] medium ticket, [3] huge count
-  int* ctl = reinterpret_cast<int*>(s_mem + (size_t)2 * a.R1 * kSliceW);
-  int* mlist = ctl + 16;                               // [kSliceMedCap][5]: node, beg0, len0, beg1, len1
-  int* hlist = mlist + 5 * kSliceMedCap;               // [kSliceHugeCap][5]
-  float* red = reinterpret_cast<float*>(hlist + 5 * kSliceHugeCap);   // [16 waves][NA][16 floats]
+  int* ctl = reinterpret_cast<int*>(s_mem + (size_t)2 * a.R1 * kSliceW);   // [0] the ticket
+  int* blist = ctl + 16;                               // [kSliceBigCap][5]: node, beg0, len0, beg1, len1
+  float* red = reinterpret_cast<float*>(blist + 5 * kSliceBigCap);   // [16 waves][NA][16 floats]
   // XCD-aware order: the nslice workgroups of question g all land on XCD g % 8
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int g = (slot / nslice) * 8 + xcd;
@@ -583,6 +587,20 @@ __global__ __launch_bounds__(kSliceThreads) void k_walk_slice(const WalkArgs a, 
   const int D = a.D, R1 = a.R1, N = a.N;
   const int tid = threadIdx.x;
   if (tid < 16) ctl[tid] = 0;
+  // the question's big nodes (listed at plan time) with their row bounds -> LDS
+  const int nbig = a.big_cnt[g];
+  const int nlist = (nbig <= kSliceBigCap && !(GNNRAG_SLICE_ABLATE & 32)) ? nbig : 0;   // 0: lane groups walk everything
+  if (tid < nlist) {
+    const int n = a.big_nodes[(size_t)g * N + tid];
+    int* e = blist + 5 * tid;
+    e[0] = n;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int beg = a.row_ptr[d][n];
+      e[1 + 2 * d] = beg;
+      e[2 + 2 * d] = a.row_ptr[d][n + 1] - beg;
+    }
+  }
   // stage the two table slices (float4 granules; rows are D*4 bytes apart).  FUSED: the question's own
   // tables P[d, g]; REASON: the shared tables T_d
   for (int idx = tid; idx < ((GNNRAG_SLICE_ABLATE & 1) ? 0 : 2 * R1 * 4); idx += kSliceThreads) {
@@ -610,52 +628,84 @@ __global__ __launch_bounds__(kSliceThreads) void k_walk_slice(const WalkArgs a, 
       q[i] = *reinterpret_cast<const f32x4*>(a.ins + ((size_t)g * a.I + a.i0 + i) * D + col0 + 4 * sub);
   }
 
-  // ---- light nodes: 4 lanes per node, 16 nodes (a "set") per wave step, sets handed out by an LDS
-  // ticket.  The dependent chain ticket -> row pointers -> first pairs -> table slices is software
-  // pipelined over three sets: while set i is walked, the first pairs of set i+1 and the row
-  // pointers of set i+2 are already in flight.  A row is walked 8 facts per step (two 32-byte
-  // coalesced accesses per group), the next step requested before the current one is consumed.
-  auto ticket = [&](int which) {
-    int t = 0;
-    if (lane == 0) t = atomicAdd(&ctl[which], 1);
-    return __builtin_amdgcn_readfirstlane(t);
+  // ---- huge nodes first: the whole workgroup per node; wave w takes steps w, w+16, ...; wave sums
+  // are combined by a fixed xor tree inside the wave and in wave order through LDS
+  if (!(GNNRAG_SLICE_ABLATE & 128)) {
+    for (int h = 0; h < nlist; ++h) {
+      const int* e = blist + 5 * h;
+      if (e[2] <= kSliceTeamDeg && e[4] <= kSliceTeamDeg) continue;     // workgroup-uniform
+      Acc acc;
+      acc.zero();
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        slice_walk_wave<MODE, NI>(acc, prd[d], e[1 + 2 * d], e[2 + 2 * d], wave, 16, lane, Td[d], q);
+        if (ND == 2 || d == 1) {
+          slice_wave_reduce<MODE, NI>(acc);
+          if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(red + (wave * NA + i) * 16 + 4 * sub) = acc.v[i];
+          }
+          __syncthreads();
+          if (tid < 4 * NA) {
+            const int i = tid >> 2, sb = tid & 3;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 16; ++w) t += *reinterpret_cast<const f32x4*>(red + (w * NA + i) * 16 + 4 * sb);
+            if (col0 + 4 * sb < D) *reinterpret_cast<f32x4*>(slice_out<MODE>(a, e[0], i, d, col0 + 4 * sb)) = t;
+          }
+          __syncthreads();
+          acc.zero();
+        }
+      }
+    }
+  }
+
+  // ---- one ticket stream: tickets [0, nlist) are the big nodes (a whole wave walks a medium one;
+  // huge ones are done), tickets >= nlist are the light sets (4 lanes per node, 16 nodes per set).
+  // For sets the dependent chain ticket -> row pointers -> first pairs -> table slices is software
+  // pipelined three deep: while set i is walked, the first pairs of set i+1 and the row pointers of
+  // set i+2 are in flight.  A row is walked 8 facts per step (two 32-byte coalesced accesses per
+  // group), the next step requested before the current one is consumed.
+  auto next_set = [&]() {
+    for (;;) {
+      int t = 0;
+      if (lane == 0) t = atomicAdd(&ctl[0], 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= nlist) return t - nlist;
+      if (GNNRAG_SLICE_ABLATE & 64) continue;
+      const int* e = blist + 5 * t;
+      if (e[2] > kSliceTeamDeg || e[4] > kSliceTeamDeg) continue;       // huge: already walked
+      Acc acc;
+      acc.zero();
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        slice_walk_wave<MODE, NI>(acc, prd[d], e[1 + 2 * d], e[2 + 2 * d], 0, 1, lane, Td[d], q);
+        if (ND == 2 || d == 1) {
+          slice_wave_reduce<MODE, NI>(acc);
+          if (grp == 0 && col_ok) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+              *reinterpret_cast<f32x4*>(slice_out<MODE>(a, e[0], i, d, col0 + 4 * sub)) = acc.v[i];
+          }
+          acc.zero();
+        }
+      }
+    }
   };
   SetRows s0, s1, s2;
-  int t0 = (GNNRAG_SLICE_ABLATE & 4) ? nsets : ticket(0);
+  int t0 = (GNNRAG_SLICE_ABLATE & 4) ? nsets : next_set();
   set_load_rows(s0, a, g, t0, nsets, grp);
-  int t1 = t0 < nsets ? ticket(0) : nsets;
+  int t1 = t0 < nsets ? next_set() : nsets;
   set_load_rows(s1, a, g, t1, nsets, grp);
   set_load_first(s0, prd, sub);
   while (t0 < nsets) {
-    const int t2 = t1 < nsets ? ticket(0) : nsets;
+    const int t2 = t1 < nsets ? next_set() : nsets;
     set_load_rows(s2, a, g, t2, nsets, grp);
     set_load_first(s1, prd, sub);
 
-    if (s0.valid && s0.big && !(GNNRAG_SLICE_ABLATE & 32)) {
-      // queue for the wave-wide / workgroup-wide passes; if both lists are full the owner group
-      // walks the node itself (slow, correct)
-      const bool huge = s0.len[0] > kSliceTeamDeg || s0.len[1] > kSliceTeamDeg;
-      int* list = nullptr;
-      if (huge) {
-        int pos = kSliceHugeCap;
-        if (sub == 0) pos = atomicAdd(&ctl[3], 1);
-        pos = __shfl(pos, 0, 4);
-        if (pos < kSliceHugeCap) list = hlist + 5 * pos;
-      }
-      if (!list) {
-        int pos = kSliceMedCap;
-        if (sub == 0) pos = atomicAdd(&ctl[1], 1);
-        pos = __shfl(pos, 0, 4);
-        if (pos < kSliceMedCap) list = mlist + 5 * pos;
-      }
-      if (list) {
-        if (sub == 0) {
-          list[0] = s0.n; list[1] = s0.beg[0]; list[2] = s0.len[0]; list[3] = s0.beg[1]; list[4] = s0.len[1];
-        }
-      } else {
-        s0.big = false;
-        set_load_first(s0, prd, sub);
-      }
+    if (s0.valid && s0.big && nlist == 0) {     // no list for this question: the owner group walks it
+      s0.big = false;
+      set_load_first(s0, prd, sub);
     }
     if (s0.valid && !s0.big) {
       Acc acc;
@@ -685,62 +735,6 @@ __global__ __launch_bounds__(kSliceThreads) void k_walk_slice(const WalkArgs a, 
     }
     s0 = s1; t0 = t1;
     s1 = s2; t1 = t2;
-  }
-  __syncthreads();
-  if (GNNRAG_SLICE_ABLATE & 2) return;
-
-  // ---- medium nodes: one wave per node, handed out by a second ticket.  Partial sums of the 16
-  // lane groups are combined by a fixed xor tree: deterministic, no atomics.
-  const int nmed = (GNNRAG_SLICE_ABLATE & 64) ? 0 : min(ctl[1], kSliceMedCap);
-  for (;;) {
-    const int m = ticket(2);
-    if (m >= nmed) break;
-    const int* e = mlist + 5 * m;
-    Acc acc;
-    acc.zero();
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-      slice_walk_wave<MODE, NI>(acc, prd[d], e[1 + 2 * d], e[2 + 2 * d], 0, 1, lane, Td[d], q);
-      if (ND == 2 || d == 1) {
-        slice_wave_reduce<MODE, NI>(acc);
-        if (grp == 0 && col_ok) {
-#pragma unroll
-          for (int i = 0; i < NA; ++i)
-            *reinterpret_cast<f32x4*>(slice_out<MODE>(a, e[0], i, d, col0 + 4 * sub)) = acc.v[i];
-        }
-        acc.zero();
-      }
-    }
-  }
-
-  // ---- huge nodes: the whole workgroup per node; wave w takes steps w, w+16, ...; wave sums are
-  // combined in wave order through LDS
-  const int nhuge = (GNNRAG_SLICE_ABLATE & 128) ? 0 : min(ctl[3], kSliceHugeCap);
-  for (int h = 0; h < nhuge; ++h) {
-    const int* e = hlist + 5 * h;
-    Acc acc;
-    acc.zero();
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-      slice_walk_wave<MODE, NI>(acc, prd[d], e[1 + 2 * d], e[2 + 2 * d], wave, 16, lane, Td[d], q);
-      if (ND == 2 || d == 1) {
-        slice_wave_reduce<MODE, NI>(acc);
-        if (grp == 0) {
-#pragma unroll
-          for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(red + (wave * NA + i) * 16 + 4 * sub) = acc.v[i];
-        }
-        __syncthreads();
-        if (tid < 4 * NA) {
-          const int i = tid >> 2, sb = tid & 3;
-          f32x4 t = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int w = 0; w < 16; ++w) t += *reinterpret_cast<const f32x4*>(red + (w * NA + i) * 16 + 4 * sb);
-          if (col0 + 4 * sb < D) *reinterpret_cast<f32x4*>(slice_out<MODE>(a, e[0], i, d, col0 + 4 * sb)) = t;
-        }
-        __syncthreads();
-        acc.zero();
-      }
-    }
   }
 }
 
@@ -830,7 +824,7 @@ static size_t prior_bytes(const gnnrag_csr* csr) {
   return align_up((size_t)2 * (size_t)(csr->F > 0 ? csr->F : 1) * sizeof(int2), 256);
 }
 static size_t slice_lds_bytes(int R1, int na = 3) {
-  return (size_t)2 * R1 * kSliceW * sizeof(float) + (16 + 5 * (kSliceMedCap + kSliceHugeCap)) * sizeof(int) +
+  return (size_t)2 * R1 * kSliceW * sizeof(float) + (16 + 5 * kSliceBigCap) * sizeof(int) +
          (size_t)na * 16 * 16 * sizeof(float);
 }
 // the LDS variant needs the two table slices of a question in one CU's LDS (160 KB)
@@ -850,6 +844,9 @@ static int fill_common(WalkArgs& a, const gnnrag_csr* csr, int D, void* ws, size
   a.max_chunks = csr->max_chunks;
   a.heavy_cap = csr->heavy_cap;
   a.heavy_deg = csr->heavy_deg;
+  a.big_cnt = csr->big_cnt;
+  a.big_nodes = csr->big_nodes;
+  a.big_deg = csr->big_deg;
   a.BN = csr->B * csr->N;
   a.B = csr->B;
   a.N = csr->N;

@@ -19,7 +19,7 @@
 namespace gnnrag {
 
 struct CsrLayout {
-  size_t row_ptr[2], edge[2], perm[2], w_gnn[2], w_rel[2], heavy[2], chunk_off[2], n_heavy, total;
+  size_t row_ptr[2], edge[2], perm[2], w_gnn[2], w_rel[2], heavy[2], chunk_off[2], n_heavy, big_cnt, big_nodes, total;
   int32_t heavy_cap;
 };
 
@@ -42,6 +42,8 @@ static CsrLayout csr_layout(int64_t F, int32_t B, int32_t N, int has_w_gnn, int 
   for (int d = 0; d < 2; ++d) L.heavy[d] = take((size_t)L.heavy_cap * sizeof(int32_t));
   for (int d = 0; d < 2; ++d) L.chunk_off[d] = take(((size_t)L.heavy_cap + 1) * sizeof(int32_t));
   L.n_heavy = take(4 * sizeof(int32_t));   // n_heavy[2], n_chunks[2]
+  L.big_cnt = take((size_t)B * sizeof(int32_t));
+  L.big_nodes = take(BN * sizeof(int32_t));
   L.total = off;
   return L;
 }
@@ -108,6 +110,22 @@ __global__ __launch_bounds__(256) void k_csr_heavy(const int32_t* __restrict__ r
   if (row_ptr[n + 1] - row_ptr[n] > heavy_deg) {
     const int32_t pos = atomicAdd(count, 1);
     if (pos < cap) list[pos] = (int32_t)n;  // order is irrelevant: each row's own sum order is fixed
+  }
+}
+
+// Per-question list of "big" nodes (more than kBigDeg facts in a direction): the LDS walk hands them
+// to whole waves / the whole workgroup instead of a 4-lane group.  Order inside a question's list is
+// whatever the atomics give; results do not depend on it (each row's own sum order is fixed).
+__global__ __launch_bounds__(256) void k_csr_big(const int32_t* __restrict__ rp0, const int32_t* __restrict__ rp1,
+                                                 int64_t BN, int32_t N, int32_t big_deg,
+                                                 int32_t* __restrict__ big_cnt, int32_t* __restrict__ big_nodes) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= BN) return;
+  const int l0 = rp0[n + 1] - rp0[n], l1 = rp1[n + 1] - rp1[n];
+  if (max(l0, l1) > big_deg) {
+    const int b = (int)(n / N);
+    const int pos = atomicAdd(&big_cnt[b], 1);
+    big_nodes[(size_t)b * N + pos] = (int32_t)n;
   }
 }
 
@@ -230,6 +248,10 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
   }
   out->n_heavy = (int32_t*)(base + L.n_heavy);
   out->n_chunks = out->n_heavy + 2;
+  out->big_cnt = (int32_t*)(base + L.big_cnt);
+  out->big_nodes = (int32_t*)(base + L.big_nodes);
+  out->big_deg = kBigDeg;
+  GNNRAG_HIP(hipMemsetAsync(out->big_cnt, 0, (size_t)B * sizeof(int32_t), stream));
   out->max_chunks = 2 * L.heavy_cap;   // sum ceil(deg/256) over rows with deg > 256 < F/256 + F/257
   GNNRAG_HIP(hipMemsetAsync(out->n_heavy, 0, 4 * sizeof(int32_t), stream));
 
@@ -268,6 +290,9 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
   hipLaunchKernelGGL(k_csr_heavy_chunks, dim3(2), dim3(1024), 0, stream, out->row_ptr[0], out->row_ptr[1],
                      out->heavy[0], out->heavy[1], out->n_heavy, out->heavy_cap, out->chunk_off[0],
                      out->chunk_off[1], out->n_chunks);
+  GNNRAG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_csr_big, dim3((int)((BN + 255) / 256)), dim3(256), 0, stream, out->row_ptr[0],
+                     out->row_ptr[1], BN, N, (int32_t)kBigDeg, out->big_cnt, out->big_nodes);
   GNNRAG_LAUNCH_CHECK();
   return 0;
 }

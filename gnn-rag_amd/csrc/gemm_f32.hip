@@ -46,7 +46,9 @@ enum { EPI_LINEAR = 0, EPI_UPDATE = 1 };
 struct GemmArgs {
   const float* A0;      // [M, K0]  (plain: K0 = K; update: h, K0 = D)
   const float* A1;      // [M, K-K0] or nullptr (update: agg)
-  const float* A0b;     // AMODE_GEN: table of direction 1 (A0 = direction 0)
+  const float* A0b;     // AMODE_GEN: table of direction 1 (A0 = direction 0); skinny pair: second problem's A
+  const float* add_b;   // skinny pair: second problem's add / C (blockIdx.z = 1)
+  float* C_b;
   const float* W;       // [Nout, K]
   const float* bias;    // [Nout] or nullptr
   const float* add;     // [add_rows, Nout] or nullptr
@@ -582,7 +584,12 @@ static int g_dense_math = 0;
 // Here one wave owns a 16 x 64 output tile and reads its MFMA fragments straight from global
 // memory (the operands are L2 resident), so a 602 x 200 problem spreads over ~150 waves.
 template <bool V4>
-__global__ __launch_bounds__(256) void k_gemm_skinny(const GemmArgs g) {
+__global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs g) {
+  if (blockIdx.z) {          // second problem of a pair (same W / bias / shapes): one launch for both
+    g.A0 = g.A0b;
+    g.add = g.add_b;
+    g.C = g.C_b;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int m0 = blockIdx.x * 16;
@@ -630,9 +637,10 @@ static int launch_gemm(GemmArgs g, hipStream_t stream) {
   if (g.M <= 0) return 0;
   const bool v4 = (g.K % 4 == 0) && (g.K0 % 4 == 0) && (g.ldw % 4 == 0) && (g.wc0 % 4 == 0) &&
                   aligned16(g.A0) && aligned16(g.W) && (g.A1 == nullptr || aligned16(g.A1)) &&
+                  (g.C_b == nullptr || aligned16(g.A0b)) &&
                   (AMODE != AMODE_GEN || g.gen_D % 4 == 0);
   if (EPI == EPI_LINEAR && AMODE == AMODE_PLAIN && g.M <= 4096 && g.n0 == 0) {
-    const dim3 grid((g.M + 15) / 16, (g.Nout + 255) / 256);
+    const dim3 grid((g.M + 15) / 16, (g.Nout + 255) / 256, g.C_b ? 2 : 1);
     if (v4) hipLaunchKernelGGL((k_gemm_skinny<true>), grid, dim3(256), 0, stream, g);
     else hipLaunchKernelGGL((k_gemm_skinny<false>), grid, dim3(256), 0, stream, g);
     GNNRAG_LAUNCH_CHECK();
@@ -731,6 +739,25 @@ static int update_common(GemmArgs g, int64_t BN, int32_t D, hipStream_t stream) 
                      g.score, (int)BN, D);
   GNNRAG_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int gnnrag_linear_pair(const float* A0, const float* A1, int64_t M, int32_t K, const float* W,
+                                  const float* bias, const float* add0, const float* add1, int64_t add_rows,
+                                  float* C0, float* C1, int32_t Nout, gnnrag_stream_t stream) {
+  if (!A0 || !A1 || !W || !C0 || !C1 || M < 0 || K <= 0 || Nout <= 0) return GNNRAG_E_BADARG;
+  if ((add0 == nullptr) != (add1 == nullptr)) return GNNRAG_E_BADARG;
+  if (M > 4096) {            // large problems: two ordinary launches
+    int rc = gnnrag_linear(A0, M, K, W, bias, add0, add_rows, 0, C0, Nout, stream);
+    if (rc) return rc;
+    return gnnrag_linear(A1, M, K, W, bias, add1, add_rows, 0, C1, Nout, stream);
+  }
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A0 = A0; g.A0b = A1; g.W = W; g.bias = bias; g.add = add0; g.add_b = add1; g.C = C0; g.C_b = C1;
+  g.M = (int32_t)M; g.K = K; g.K0 = K; g.Nout = Nout; g.ldw = K;
+  g.add_rows = add0 ? (int32_t)(add_rows < M ? add_rows : M) : 0;
+  const int rc = launch_gemm<EPI_LINEAR, AMODE_PLAIN>(g, (hipStream_t)stream);
+  return rc == (1 << 30) ? 0 : rc;
 }
 
 extern "C" int gnnrag_update_score(const float* h, const float* agg, const float* W, const float* b,

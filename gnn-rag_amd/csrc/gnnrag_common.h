@@ -21,7 +21,8 @@
 namespace gnnrag {
 
 constexpr int kWave = 64;            // CDNA wavefront
-constexpr int kHeavyDeg = 256;       // rows with more facts are walked by a whole workgroup
+constexpr int kHeavyDeg = 256;       // gather walk: rows with more facts are cut into chunks
+constexpr int kBigDeg = 32;          // LDS walk: rows with more facts go to a whole wave / workgroup
 constexpr float kVeryNeg = -100000000000.0f;  // reasongnn.py:9 (VERY_NEG_NUMBER), rounded to fp32
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -3,10 +3,12 @@
 
 namespace gnnrag {
 
-// dist[g,:] = softmax(score[g,:])  (reasongnn.py:169).  One 1024-thread workgroup per question:
-// the N scores (<= 80 KB at N = 20k) are read three times, the 2nd/3rd time from L1/L2.
+// dist[g,:] = softmax(score[g,:])  (reasongnn.py:169).  One 1024-thread workgroup per question.
 // Masked slots hold exactly -1e11 (fp32), so exp(-1e11 - max) == 0 exactly; a question whose
 // slots are all masked gets exactly 1/N everywhere, like the reference.
+// ITEMS > 0: the N <= 1024*ITEMS scores are read ONCE into registers (the kernel is pure latency:
+// 64 workgroups on a 256-CU chip); ITEMS == 0: any N, three passes over L1/L2-resident data.
+template <int ITEMS>
 __global__ __launch_bounds__(1024) void k_masked_softmax(const float* __restrict__ score,
                                                          float* __restrict__ dist, int N) {
   __shared__ float red[16];
@@ -14,9 +16,19 @@ __global__ __launch_bounds__(1024) void k_masked_softmax(const float* __restrict
   const float* s = score + (size_t)blockIdx.x * N;
   float* o = dist + (size_t)blockIdx.x * N;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float v[ITEMS > 0 ? ITEMS : 1];
 
   float m = -INFINITY;
-  for (int i = threadIdx.x; i < N; i += 1024) m = fmaxf(m, s[i]);
+  if constexpr (ITEMS > 0) {
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int i = threadIdx.x + k * 1024;
+      v[k] = i < N ? s[i] : -INFINITY;
+      m = fmaxf(m, v[k]);
+    }
+  } else {
+    for (int i = threadIdx.x; i < N; i += 1024) m = fmaxf(m, s[i]);
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   if (lane == 0) red[wave] = m;
@@ -31,7 +43,15 @@ __global__ __launch_bounds__(1024) void k_masked_softmax(const float* __restrict
   __syncthreads();
 
   float sum = 0.f;
-  for (int i = threadIdx.x; i < N; i += 1024) sum += expf(s[i] - m);
+  if constexpr (ITEMS > 0) {
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      v[k] = expf(v[k] - m);            // exp(-inf) = 0 for the padding lanes
+      sum += v[k];
+    }
+  } else {
+    for (int i = threadIdx.x; i < N; i += 1024) sum += expf(s[i] - m);
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
   if (lane == 0) red[wave] = sum;
@@ -43,7 +63,15 @@ __global__ __launch_bounds__(1024) void k_masked_softmax(const float* __restrict
   }
   __syncthreads();
   const float total = bcast;
-  for (int i = threadIdx.x; i < N; i += 1024) o[i] = expf(s[i] - m) / total;
+  if constexpr (ITEMS > 0) {
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int i = threadIdx.x + k * 1024;
+      if (i < N) o[i] = v[k] / total;
+    }
+  } else {
+    for (int i = threadIdx.x; i < N; i += 1024) o[i] = expf(s[i] - m) / total;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_stream_copy(const f32x4* __restrict__ src, f32x4* __restrict__ dst,
@@ -91,7 +119,9 @@ using namespace gnnrag;
 extern "C" int gnnrag_masked_softmax(const float* score, float* dist, int32_t B, int32_t N,
                                      gnnrag_stream_t stream) {
   if (!score || !dist || B <= 0 || N <= 0) return GNNRAG_E_BADARG;
-  hipLaunchKernelGGL(k_masked_softmax, dim3(B), dim3(1024), 0, (hipStream_t)stream, score, dist, N);
+  if (N <= 2048) hipLaunchKernelGGL(k_masked_softmax<2>, dim3(B), dim3(1024), 0, (hipStream_t)stream, score, dist, N);
+  else if (N <= 8192) hipLaunchKernelGGL(k_masked_softmax<8>, dim3(B), dim3(1024), 0, (hipStream_t)stream, score, dist, N);
+  else hipLaunchKernelGGL(k_masked_softmax<0>, dim3(B), dim3(1024), 0, (hipStream_t)stream, score, dist, N);
   GNNRAG_LAUNCH_CHECK();
   return 0;
 }
@@ -130,9 +160,8 @@ extern "C" int gnnrag_reason_layer(const gnnrag_csr* csr, const float* h, const 
   const int64_t BN = (int64_t)csr->B * csr->N;
   int rc;
   // T_d = rel_linear(rel_features_d) (+ pos_emb_d): once per relation row, not once per fact
-  rc = gnnrag_linear(relfeat_fwd, csr->R1, D, W_rel, b_rel, pos_fwd, pos_fwd ? pos_rows : 0, 0, T_fwd, D, stream);
-  if (rc) return rc;
-  rc = gnnrag_linear(relfeat_inv, csr->R1, D, W_rel, b_rel, pos_inv, pos_inv ? pos_rows : 0, 0, T_inv, D, stream);
+  rc = gnnrag_linear_pair(relfeat_fwd, relfeat_inv, csr->R1, D, W_rel, b_rel, pos_fwd, pos_inv,
+                          pos_fwd ? pos_rows : 0, T_fwd, T_inv, D, stream);
   if (rc) return rc;
   if (path == GNNRAG_PATH_AUTO)
     path = fused_is_cheaper(csr->B, csr->N, csr->R1, D, I) ? GNNRAG_PATH_FUSED : GNNRAG_PATH_UNFUSED;

@@ -140,6 +140,9 @@ class CsrPlan:
                 out[key] = t.cpu().numpy()
         nc = self._view(self.c.n_chunks, 2, torch.int32).numpy()
         out["n_chunks"] = nc
+        bc = self._view(self.c.big_cnt, self.B, torch.int32).numpy()
+        bn = self._view(self.c.big_nodes, BN, torch.int32).numpy().reshape(self.B, self.N)
+        out["big"] = [np.sort(bn[b, : bc[b]]) for b in range(self.B)]
         return out
 
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GNNRAG_ABI_VERSION 2
+#define GNNRAG_ABI_VERSION 3
 
 #define GNNRAG_E_BADARG      (-1)  /* null pointer / negative size / inconsistent sizes   */
 #define GNNRAG_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set (see DESIGN)  */
@@ -62,6 +62,10 @@ typedef struct gnnrag_csr {
   int32_t* n_chunks;    /* [2] device counters: heavy chunks per direction                 */
   int32_t  heavy_cap;
   int32_t  max_chunks;  /* upper bound of n_chunks[d] (sizes the partial-sum workspace)    */
+  int32_t* big_cnt;     /* [B]    nodes of each question with > big_deg facts in a direction */
+  int32_t* big_nodes;   /* [B][N] their node ids (order irrelevant)                         */
+  int32_t  big_deg;
+  int32_t  reserved_;
 } gnnrag_csr;
 
 /* Bytes of caller-owned device memory a gnnrag_csr needs (persistent part / build scratch). */
@@ -104,6 +108,12 @@ int gnnrag_get_dense_math(void);
 int gnnrag_linear(const float* A, int64_t M, int32_t K, const float* W, const float* bias,
                   const float* add, int64_t add_rows, int relu,
                   float* C, int32_t Nout, gnnrag_stream_t stream);
+
+/* Two gnnrag_linear problems that share W, bias and shapes (the forward and inverse relation
+ * transforms of one layer call) in ONE launch. */
+int gnnrag_linear_pair(const float* A0, const float* A1, int64_t M, int32_t K, const float* W,
+                       const float* bias, const float* add0, const float* add1, int64_t add_rows,
+                       float* C0, float* C1, int32_t Nout, gnnrag_stream_t stream);
 
 /* agg[n, 2i+d, :] = sum_{f: dst_d(f)=n} w_f * dist[src_d(f)] * relu(T_d[rel_f,:] * ins[n/N, i, :])
  * = reason_layer (reasongnn.py:61-89, d=0) and reason_layer_inv (reasongnn.py:91-116, d=1)

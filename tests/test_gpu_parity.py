@@ -57,6 +57,9 @@ def test_csr_plan_bit_exact(dev, name):
         deg = np.diff(want["row_ptr%d" % d])
         np.testing.assert_array_equal(got["heavy%d" % d], np.flatnonzero(deg > 256).astype(np.int32))
         assert got["n_chunks"][d] == int(np.ceil(deg[deg > 256] / 256).sum())
+    deg2 = np.maximum(np.diff(want["row_ptr0"]), np.diff(want["row_ptr1"])).reshape(cfg.B, cfg.N)
+    for b in range(cfg.B):
+        np.testing.assert_array_equal(got["big"][b], b * cfg.N + np.flatnonzero(deg2[b] > 32))
     if name == "mid":
         assert got["n_heavy"].sum() > 0, "the Zipf hub must exercise the heavy-row path"
 
