@@ -161,7 +161,7 @@ def main():
 
     if rank == 0:
         out.update(roofline_leg(cfg, layer, devin, ops, F_g, args.steps))
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # rank 0 at N = 1 only (the other ranks would idle)
             out["cpu_baseline"] = cpu_baseline_leg(cfg, args.cpu_sample_b)
     if distributed:
         dist.barrier()

@@ -360,6 +360,37 @@ def test_full_size_properties_c2(dev, path):
     assert torch.equal(torch.cat(parts, 0), dist)
 
 
+@pytest.mark.parametrize("B,N,E,R,D,I", [
+    (1, 17, 40, 3, 64, 1),        # one question, N not a multiple of 16, 16-lane walk groups, NT=4 GEMM
+    (2, 50, 200, 9, 100, 4),      # I > 3: two instruction passes; D=100 -> 32-lane groups, NT=8 GEMM
+    (2, 33, 150, 5, 128, 2),
+    (3, 70, 300, 6, 256, 3),      # D > 208: column-blocked update + separate score kernel
+    (2, 40, 160, 4, 300, 2),      # two float4 chunks per lane
+    (2, 30, 100, 5, 36, 2),       # D % 4 == 0 but tiny
+    (2, 30, 100, 5, 30, 2),       # D % 4 != 0: float2 walk, scalar GEMM loaders
+    (2, 30, 100, 5, 25, 1),       # odd D: scalar everything
+])
+def test_shape_sweep_both_paths_vs_np64(dev, B, N, E, R, D, I):
+    """Odd shapes through every dispatch branch (vector width, lane-group size, GEMM tile variants,
+    instruction passes), both kernel paths, against the float64 oracle."""
+    import oracle.rearev_np64 as onp
+    from gnnrag_amd import stack, synth
+    cfg = synth.GraphConfig(name="sweep", B=B, N=N, E=E, R=R, D=D, I=I, L=2, T=2, seed=B * 1000 + D,
+                            normalized_gnn=(D % 2 == 0), pos_emb=(I % 2 == 1), n_real_min=max(2, N // 2))
+    batch = synth.make_batch(cfg)
+    feats = synth.make_features(cfg)
+    params = synth.make_layer_params(cfg)
+    want = onp.run_stack(batch, feats, params, use_type_layer=True, norm_rel=True)
+    for path in (1, 2):
+        got = stack.run_stack(batch, feats, params, dev, use_type_layer=True, norm_rel=True, path=path)
+        np.testing.assert_allclose(got["h0"], want["h0"], rtol=0, atol=TOL_INTERNAL, err_msg="h0 path %d" % path)
+        for c in range(cfg.T * cfg.L):
+            np.testing.assert_allclose(got["h"][c], want["h"][c], rtol=0, atol=TOL_INTERNAL,
+                                       err_msg="h call %d path %d" % (c, path))
+            np.testing.assert_allclose(got["dist"][c], want["dist"][c], rtol=0, atol=TOL_INTERNAL,
+                                       err_msg="dist call %d path %d" % (c, path))
+
+
 @pytest.fixture
 def bf16x3(dev):
     from gnnrag_amd import ops
