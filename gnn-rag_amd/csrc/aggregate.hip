@@ -38,11 +38,6 @@
                                  // dense prior 258 vs 281 us, seed prior 202 vs 138 us - its 64-byte output pieces
                                  // (4 per node and slice) lose to the gather walk's full 3200-byte rows, so it is off
 #endif
-#ifndef GNNRAG_SLICE_ABLATE
-#define GNNRAG_SLICE_ABLATE 0   // timing experiments only (tools/tune_variants.py): 1 no staging, 2 no medium/huge pass,
-                                // 4 no sets, 8 no stores, 16 no row walk (structure loads only), 32 no queueing of big nodes,
-                                // 64 no medium nodes, 128 no huge nodes
-#endif
 
 namespace gnnrag {
 
@@ -589,7 +584,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
   if (tid < 16) ctl[tid] = 0;
   // the question's big nodes (listed at plan time) with their row bounds -> LDS
   const int nbig = a.big_cnt[g];
-  const int nlist = (nbig <= kSliceBigCap && !(GNNRAG_SLICE_ABLATE & 32)) ? nbig : 0;   // 0: lane groups walk everything
+  const int nlist = nbig <= kSliceBigCap ? nbig : 0;   // 0: lane groups walk everything
   if (tid < nlist) {
     const int n = a.big_nodes[(size_t)g * N + tid];
     int* e = blist + 5 * tid;
@@ -603,7 +598,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
   }
   // stage the two table slices (float4 granules; rows are D*4 bytes apart).  FUSED: the question's own
   // tables P[d, g]; REASON: the shared tables T_d
-  for (int idx = tid; idx < ((GNNRAG_SLICE_ABLATE & 1) ? 0 : 2 * R1 * 4); idx += kSliceThreads) {
+  for (int idx = tid; idx < 2 * R1 * 4; idx += kSliceThreads) {
     const int d = idx / (R1 * 4);
     const int rem = idx - d * (R1 * 4);
     const int r = rem >> 2, k = rem & 3;
@@ -630,7 +625,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
 
   // ---- huge nodes first: the whole workgroup per node; wave w takes steps w, w+16, ...; wave sums
   // are combined by a fixed xor tree inside the wave and in wave order through LDS
-  if (!(GNNRAG_SLICE_ABLATE & 128)) {
+  {
     for (int h = 0; h < nlist; ++h) {
       const int* e = blist + 5 * h;
       if (e[2] <= kSliceTeamDeg && e[4] <= kSliceTeamDeg) continue;     // workgroup-uniform
@@ -672,7 +667,6 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
       if (lane == 0) t = atomicAdd(&ctl[0], 1);
       t = __builtin_amdgcn_readfirstlane(t);
       if (t >= nlist) return t - nlist;
-      if (GNNRAG_SLICE_ABLATE & 64) continue;
       const int* e = blist + 5 * t;
       if (e[2] > kSliceTeamDeg || e[4] > kSliceTeamDeg) continue;       // huge: already walked
       Acc acc;
@@ -693,7 +687,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
     }
   };
   SetRows s0, s1, s2;
-  int t0 = (GNNRAG_SLICE_ABLATE & 4) ? nsets : next_set();
+  int t0 = next_set();
   set_load_rows(s0, a, g, t0, nsets, grp);
   int t1 = t0 < nsets ? next_set() : nsets;
   set_load_rows(s1, a, g, t1, nsets, grp);
@@ -714,7 +708,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
       for (int d = 0; d < 2; ++d) {
         const int beg = s0.beg[d], len = s0.len[d];
         int2 c0 = s0.first[d][0], c1 = s0.first[d][1];
-        for (int j = 0; j < ((GNNRAG_SLICE_ABLATE & 16) ? 0 : len); j += 8) {
+        for (int j = 0; j < len; j += 8) {
           int2 n0 = make_int2(0, 0), n1 = make_int2(0, 0);
           if (j + 8 + sub < len) n0 = prd[d][beg + j + 8 + sub];
           if (j + 12 + sub < len) n1 = prd[d][beg + j + 12 + sub];
@@ -724,7 +718,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
           c1 = n1;
         }
         if (ND == 2 || d == 1) {
-          if (col_ok && (!(GNNRAG_SLICE_ABLATE & 8) || acc.v[0][0] == 12345.f)) {
+          if (col_ok) {
 #pragma unroll
             for (int i = 0; i < NA; ++i)
               *reinterpret_cast<f32x4*>(slice_out<MODE>(a, s0.n, i, d, col0 + 4 * sub)) = acc.v[i];

@@ -23,19 +23,12 @@
 // tile t+1 are issued before the MFMAs of tile t (register prefetch), two workgroups per CU.
 #include "gnnrag_common.h"
 
-// tuning switches (A/B-tested on MI355X with tools/tune_variants.py; defaults = fastest measured)
-#ifndef GNNRAG_GEMM_BRANCHLESS
-#define GNNRAG_GEMM_BRANCHLESS 0
-#endif
-#ifndef GNNRAG_GEMM_MT1_NW
-#define GNNRAG_GEMM_MT1_NW 8     // waves per workgroup of the 1-row-tile-per-wave variant (4 -> 64 rows, 8 -> 128 rows)
-#endif
-#ifndef GNNRAG_GEMM_PF2
-#define GNNRAG_GEMM_PF2 0        // A tiles requested two k-tiles ahead (plain A only)
-#endif
-#ifndef GNNRAG_GEMM_EPILOGUE
-#define GNNRAG_GEMM_EPILOGUE 1   // 0 = direct stores from the MFMA layout, 1 = staged through LDS (row-wise, coalesced)
-#endif
+// Variants that were A/B-tested on MI355X and did NOT pay (removed; see DESIGN.md section 3.5 and git history):
+// branch-free clamped tile loads (-8 %), source-level fragment double buffering / sched_group_barrier
+// pinning (+-0), A tiles requested two k-tiles ahead (+-0), prefetching all A tiles of a short-K problem
+// (register blow-up), direct stores from the MFMA layout instead of the LDS-staged epilogue (-25 % on the
+// self-block update).
+#define GNNRAG_GEMM_MT1_NW 8     // the one-row-tile-per-wave variant may use 8-wave (128-row) workgroups
 
 namespace gnnrag {
 
@@ -73,15 +66,7 @@ enum { AMODE_PLAIN = 0, AMODE_GEN = 1 };
 template <bool V4, int AMODE>
 __device__ __forceinline__ f32x4 load_a4(const GemmArgs& g, int m, int k) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#if GNNRAG_GEMM_BRANCHLESS
-  if constexpr (V4 && AMODE == AMODE_PLAIN) {
-    if (m >= g.M) { m = g.M - 1; k = g.K; }     // clamp the row, force the zero select below
-  } else {
-    if (m >= g.M) return v;
-  }
-#else
   if (m >= g.M) return v;
-#endif
   if constexpr (AMODE == AMODE_GEN) {
     // relu(T_d[r,:] * ins[b,i,:]) generated on the fly: the [B*R1, I*D] operand never exists in HBM
     if (k >= g.K) return v;
@@ -106,19 +91,8 @@ __device__ __forceinline__ f32x4 load_a4(const GemmArgs& g, int m, int k) {
     return v;
   } else if constexpr (V4) {
     // K0, K-K0 multiples of 4 and 16-byte aligned bases: a float4 never straddles the split.
-#if GNNRAG_GEMM_BRANCHLESS
-    // Branch-free: out-of-range lanes read a clamped (valid) address and are zeroed afterwards,
-    // so the tile's loads issue back to back instead of one basic block each.
-    const bool in0 = k < g.K0;
-    const bool ok = k < g.K;
-    const float* p0 = g.A0 + (size_t)m * g.K0 + (in0 ? k : 0);
-    const float* p1 = g.A1 ? g.A1 + (size_t)m * (g.K - g.K0) + ((ok && !in0) ? k - g.K0 : 0) : p0;
-    const f32x4 x = *reinterpret_cast<const f32x4*>(in0 ? p0 : p1);
-    v = ok ? x : v;
-#else
     if (k < g.K0) v = *reinterpret_cast<const f32x4*>(g.A0 + (size_t)m * g.K0 + k);
     else if (k < g.K) v = *reinterpret_cast<const f32x4*>(g.A1 + (size_t)m * (g.K - g.K0) + (k - g.K0));
-#endif
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -145,13 +119,7 @@ template <bool V4, int AMODE>
 __device__ __forceinline__ f32x4 load_w4(const GemmArgs& g, int j, int k) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   if constexpr (V4) {
-#if GNNRAG_GEMM_BRANCHLESS
-    const bool ok = j < g.Nout && k < g.K;
-    const f32x4 x = *reinterpret_cast<const f32x4*>(g.W + (size_t)(ok ? j : 0) * g.ldw + w_col<AMODE>(g, ok ? k : 0));
-    v = ok ? x : v;
-#else
     if (j < g.Nout && k < g.K) v = *reinterpret_cast<const f32x4*>(g.W + (size_t)j * g.ldw + w_col<AMODE>(g, k));
-#endif
   } else {
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
@@ -245,37 +213,11 @@ void k_gemm_f32(GemmArgs g) {
   const int nT = (g.K + kBK - 1) / kBK;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  constexpr bool PF2 = GNNRAG_GEMM_PF2 && AMODE == AMODE_PLAIN;
-  f32x4 ra2[PF2 ? AR : 1];
-  auto gload_a = [&](int t, f32x4 (&dst)[PF2 ? AR : 1]) {       // PF2 only: A tile t -> dst
-    const int k = t * kBK + kq * 4;
-#pragma unroll
-    for (int r = 0; r < (PF2 ? AR : 1); ++r) dst[r] = load_a4<V4, AMODE>(g, m0 + lr + RPR * r, k);
-  };
-  auto gload = [&](int t, bool with_a) {
+  auto gload = [&](int t) {
     const int k = t * kBK + kq * 4;
     if constexpr (AMODE == AMODE_GEN && V4) {
       const bool kok = k < g.K;
       const int wcol = (1 + 2 * gen_i + g.gen_dir) * g.gen_D + gen_kk;
-#if GNNRAG_GEMM_BRANCHLESS
-#pragma unroll
-      for (int r = 0; r < AR; ++r) {
-        // branch-free: rows past M read row 0 / columns past K read column 0, then select zero
-        const float* tp = gen_t[r] ? gen_t[r] : g.A0;
-        const int kk = kok ? gen_kk : 0, ii = kok ? gen_i : 0;
-        const f32x4 tv = *reinterpret_cast<const f32x4*>(tp + kk);
-        const f32x4 qv = *reinterpret_cast<const f32x4*>(gen_q[r] + (size_t)ii * g.gen_D + kk);
-        const f32x4 x = __builtin_elementwise_max(tv * qv, zero4);
-        ra[r] = (kok && gen_t[r]) ? x : zero4;
-      }
-#pragma unroll
-      for (int r = 0; r < WR; ++r) {
-        const int j = lr + RPR * r;
-        const bool ok = j < NT * 16 && n0 + j < g.Nout && kok;
-        const f32x4 x = *reinterpret_cast<const f32x4*>(g.W + (size_t)(ok ? n0 + j : 0) * g.ldw + (ok ? wcol : 0));
-        rw[r] = ok ? x : zero4;
-      }
-#else
 #pragma unroll
       for (int r = 0; r < AR; ++r) {
         ra[r] = zero4;
@@ -292,14 +234,11 @@ void k_gemm_f32(GemmArgs g) {
         if (j < NT * 16 && n0 + j < g.Nout && kok)
           rw[r] = *reinterpret_cast<const f32x4*>(g.W + (size_t)(n0 + j) * g.ldw + wcol);
       }
-#endif
       gen_kk += kBK;                       // next tile's column state
       while (gen_kk >= g.gen_D) { gen_kk -= g.gen_D; ++gen_i; }
     } else {
-      if (with_a) {
 #pragma unroll
-        for (int r = 0; r < AR; ++r) ra[r] = load_a4<V4, AMODE>(g, m0 + lr + RPR * r, k);
-      }
+      for (int r = 0; r < AR; ++r) ra[r] = load_a4<V4, AMODE>(g, m0 + lr + RPR * r, k);
 #pragma unroll
       for (int r = 0; r < WR; ++r) {
         const int j = lr + RPR * r;
@@ -340,26 +279,14 @@ void k_gemm_f32(GemmArgs g) {
     }
   };
 
-  gload(0, true);
+  gload(0);
   sstore();
   __syncthreads();
-  if constexpr (PF2) {
-    if (nT > 1) {                      // A(1) in flight while tile 0 is multiplied
-      const int k = kBK + kq * 4;
-#pragma unroll
-      for (int r = 0; r < AR; ++r) ra[r] = load_a4<V4, AMODE>(g, m0 + lr + RPR * r, k);
-    }
-  }
 
   const int fr = lane & 15;  // fragment row (A) / column (W) inside a 16x16 tile
   const int fg = lane >> 4;  // k group
   for (int t = 0; t < nT; ++t) {
-    // LDS holds tile t.  Without PF2: request tile t+1 (A and W).  With PF2: ra already holds A(t+1)
-    // (requested one iteration ago); request W(t+1) (L2 resident) and A(t+2) (HBM) now.
-    if (t + 1 < nT) gload(t + 1, !PF2);
-    if constexpr (PF2) {
-      if (t + 2 < nT) gload_a(t + 2, ra2);
-    }
+    if (t + 1 < nT) gload(t + 1);      // tile t+1 is in flight while tile t (in LDS) is multiplied
     if constexpr (MATH == 0) {
 #pragma unroll
       for (int c = 0; c < kBK / 16; ++c) {
@@ -419,56 +346,8 @@ void k_gemm_f32(GemmArgs g) {
       sstore();
       __syncthreads();
     }
-    if constexpr (PF2) {
-#pragma unroll
-      for (int r = 0; r < AR; ++r) ra[r] = ra2[r];
-    }
   }
 
-#if GNNRAG_GEMM_EPILOGUE == 0
-  // C/D layout of the 16x16 tile: column = lane & 15, row = (lane >> 4) * 4 + reg; direct stores.
-  {
-    float part[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) part[mt][r] = 0.f;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int col = n0 + nt * 16 + fr;
-      const bool cok = col < g.Nout;
-      const float bia = (cok && g.bias) ? g.bias[col] : 0.f;
-      const float ws = (EPI == EPI_UPDATE && cok) ? g.w_s[col] : 0.f;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = m0 + wave * 16 * MT + mt * 16 + fg * 4 + r;
-          float v = acc[mt][nt][r] + bia;
-          if (g.add && cok && row < g.add_rows) v += g.add[(size_t)row * g.Nout + col];
-          if (EPI == EPI_UPDATE || g.relu) v = fmaxf(v, 0.f);
-          if (cok && row < g.M) g.C[(size_t)row * g.Nout + col] = v;
-          if (EPI == EPI_UPDATE) part[mt][r] += v * ws;
-        }
-      }
-    }
-    if constexpr (EPI == EPI_UPDATE) {
-      const float bs = g.b_s[0];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float sc = part[mt][r];
-          sc += __shfl_xor(sc, 1, 64);
-          sc += __shfl_xor(sc, 2, 64);
-          sc += __shfl_xor(sc, 4, 64);
-          sc += __shfl_xor(sc, 8, 64);
-          const int row = m0 + wave * 16 * MT + mt * 16 + fg * 4 + r;
-          if (fr == 0 && row < g.M) g.score[row] = (sc + bs) + (1.0f - g.mask[row]) * kVeryNeg;
-        }
-    }
-  }
-#else
   // ---- epilogue -------------------------------------------------------------------------------
   // The MFMA C layout (column = lane & 15, row = (lane >> 4) * 4 + reg) would give 64-byte global
   // pieces.  Each wave instead transposes one 16-row tile at a time through its own LDS region
@@ -556,7 +435,6 @@ void k_gemm_f32(GemmArgs g) {
       }
     }
   }
-#endif
 }
 
 // score for Nout > 208 (column blocks): one wave per row, dot(h', w_s)

@@ -13,10 +13,12 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
+# name -> extra -D switches.  Switches that exist today: GNNRAG_REASON_SLICE (aggregate.hip),
+# GNNRAG_GEMM_MT1_NW (gemm_f32.hip).  Add a macro to the kernel source, list its values here, run.
 VARIANTS = {
-    "nw4_w3": {"GNNRAG_GEMM_MT1_NW": 4, "GNNRAG_GEMM_MT1_WAVES": 3},
-    "nw8_w4": {"GNNRAG_GEMM_MT1_NW": 8, "GNNRAG_GEMM_MT1_WAVES": 4},
-    "nw8_w2": {"GNNRAG_GEMM_MT1_NW": 8, "GNNRAG_GEMM_MT1_WAVES": 2},
+    "default": {},
+    "reason_slice": {"GNNRAG_REASON_SLICE": 1},
+    "gemm_nw4": {"GNNRAG_GEMM_MT1_NW": 4},
 }
 
 CHILD = r'''
