@@ -219,7 +219,7 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
                                                                           sf.bias, layer.local_entity_mask, I)))
     del agg
     box.pop("agg")
-    ms["relation_tables"] = t(lambda: box.__setitem__("P", ops.relation_tables(Tf, Ti, ins, e2e.weight)))
+    ms["relation_tables"] = t(lambda: box.__setitem__("P", ops.relation_tables(plan, Tf, Ti, ins, e2e.weight)))
     P = box["P"]
     ms["aggregate_fused_dense"] = t(lambda: box.__setitem__("nbr", ops.aggregate_fused(plan, dense, P)))
     ms["aggregate_fused_seed"] = t(lambda: ops.aggregate_fused(plan, seed, P))
@@ -237,7 +237,7 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
     tc = _events_ms(lambda: ops.stream_copy(src, dst), 10)
     copy_gbps = 2 * n * 4 / (np.median(tc) * 1e-3) / 1e9
 
-    fused = layer.path == 2 or (layer.path == 0 and 2.0 * B * cfg.R1 * I * D * D + B * N * D * D
+    fused = layer.path == 2 or (layer.path == 0 and 2.0 * plan.rel_total * I * D * D + B * N * D * D
                                 < 0.8 * B * N * (2 * I + 1) * D * D)
     ba = bytes_agg(cfg, F_g)
 
@@ -286,8 +286,8 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
         "roofline_dense": {
             "update_score": mfma("gnnrag_update_score (k_gemm_f32 [BN,(2I+1)D]x[(2I+1)D,D])", flops_update(cfg),
                                  ms["update_score"]),
-            "relation_tables": mfma("gnnrag_relation_tables (k_gemm_f32 generated-A [2*B*R1, I*D]x[I*D, D])",
-                                    2.0 * 2 * B * cfg.R1 * I * D * D, ms["relation_tables"]),
+            "relation_tables": mfma("gnnrag_relation_tables (k_gemm_f32 generated-A [2*rel_total, I*D]x[I*D, D])",
+                                    2.0 * 2 * plan.rel_total * I * D * D, ms["relation_tables"]),
             "update_score_fused": mfma("gnnrag_update_score_fused (k_gemm_f32 [BN,D]x[D,D] + nbr)",
                                        2.0 * B * N * D * D, ms["update_score_fused"]),
         },

@@ -28,14 +28,16 @@ class CsrStruct(C.Structure):
         ("heavy_cap", C.c_int32), ("max_chunks", C.c_int32),
         ("big_cnt", C.c_void_p), ("big_nodes", C.c_void_p),
         ("big_deg", C.c_int32), ("reserved_", C.c_int32),
+        ("edge_l", C.c_void_p * 2), ("rel_off", C.c_void_p), ("rel_rows", C.c_void_p),
+        ("rel_total", C.c_int32), ("rel_max", C.c_int32),
     ]
 
 
 # name -> (restype, argtypes); every symbol include/gnnrag.h declares
 _VP = C.c_void_p
 SIGNATURES = {
-    "gnnrag_csr_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int, C.c_int]),
-    "gnnrag_csr_scratch_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "gnnrag_csr_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int, C.c_int]),
+    "gnnrag_csr_scratch_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "gnnrag_csr_build": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                    _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(CsrStruct), _VP]),
     "gnnrag_csr_permute_weight": (C.c_int, [C.POINTER(CsrStruct), _VP, C.c_int, _VP, _VP, _VP]),
@@ -49,7 +51,7 @@ SIGNATURES = {
     "gnnrag_aggregate": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32,
                                    _VP, C.c_size_t, _VP]),
     "gnnrag_aggregate_fused": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, C.c_int32, _VP, C.c_size_t, _VP]),
-    "gnnrag_relation_tables": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP]),
+    "gnnrag_relation_tables": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32, _VP]),
     "gnnrag_update_score_fused": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_int32,
                                             C.c_int32, _VP]),
     "gnnrag_update_score": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_int32,
@@ -64,7 +66,7 @@ SIGNATURES = {
     "gnnrag_error_string": (C.c_char_p, [C.c_int]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PATH_AUTO, PATH_UNFUSED, PATH_FUSED = 0, 1, 2
 _lib = None
 

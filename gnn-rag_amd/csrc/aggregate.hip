@@ -75,7 +75,8 @@ struct WalkArgs {
   const int32_t* row_ptr[2];
   const int2* edge[2];
   const float* w[2];          // per-fact weight in sorted order or nullptr
-  const float* T[2];          // REASON/TYPE: [R1,D]; FUSED: P[d] = [B][R1][D]
+  const float* T[2];          // REASON/TYPE: [R1,D]; FUSED: P[d] = [rel_total][D], question b's rows at rel_off[b]
+  const int32_t* rel_off;     // FUSED: [B+1] first compact relation row of each question
   const float* dist;          // [BN] (REASON, FUSED)
   const float* ins;           // [B,I,D] (REASON)
   float* out;                 // REASON: [BN,2I*D]; TYPE/FUSED: [BN,D]
@@ -85,7 +86,7 @@ struct WalkArgs {
   const int32_t* n_chunks;
   float* partial;             // [2][max_chunks][NI*D] heavy-chunk partial sums
   int32_t max_chunks, heavy_cap, heavy_deg;
-  int32_t BN, N, D, I, i0, R1, B;
+  int32_t BN, N, D, I, i0, R1, B;   // R1: table rows (FUSED: largest per-question count, sizes the LDS slices)
   int32_t bpg;                // FUSED: workgroups per question for the XCD-aware mapping (0 = off)
   int32_t dir;                // k_heavy_reduce in read-modify-write modes: direction of this launch
   int32_t heavy_only;         // host side: the light rows were already walked by another kernel
@@ -216,7 +217,7 @@ __device__ __forceinline__ void load_q(const WalkArgs& a, int b, const int (&col
 }
 
 __device__ __forceinline__ const float* table_of(const WalkArgs& a, int mode, int d, int b) {
-  return (mode == MODE_FUSED) ? a.T[d] + (size_t)b * a.R1 * a.D : a.T[d];
+  return (mode == MODE_FUSED) ? a.T[d] + (size_t)a.rel_off[b] * a.D : a.T[d];
 }
 
 // ---- light rows: one LPN-lane group per destination node, both directions ------------------
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
   constexpr int NA = Acc::n;
   constexpr int ND = (MODE == MODE_REASON) ? 2 : 1;     // output slots per node: per direction / summed
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
-  float* Ts = s_mem;                                   // [2][R1][16]
+  float* Ts = s_mem;                                   // [2][Rg][16] (room for [2][R1][16])
   int* ctl = reinterpret_cast<int*>(s_mem + (size_t)2 * a.R1 * kSliceW);   // [0] the ticket
   int* blist = ctl + 16;                               // [kSliceBigCap][5]: node, beg0, len0, beg1, len1
   float* red = reinterpret_cast<float*>(blist + 5 * kSliceBigCap);   // [16 waves][NA][16 floats]
@@ -579,7 +580,13 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
   if (g >= a.B) return;
   const int c = slot % nslice;
   const int col0 = c * kSliceW;
-  const int D = a.D, R1 = a.R1, N = a.N;
+  const int D = a.D, N = a.N;
+  // rows of this question's tables: FUSED tables hold only the relations the question uses
+  int Rg = a.R1, roff = 0;
+  if constexpr (MODE == MODE_FUSED) {
+    roff = a.rel_off[g];
+    Rg = a.rel_off[g + 1] - roff;
+  }
   const int tid = threadIdx.x;
   if (tid < 16) ctl[tid] = 0;
   // the question's big nodes (listed at plan time) with their row bounds -> LDS
@@ -598,14 +605,14 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
   }
   // stage the two table slices (float4 granules; rows are D*4 bytes apart).  FUSED: the question's own
   // tables P[d, g]; REASON: the shared tables T_d
-  for (int idx = tid; idx < 2 * R1 * 4; idx += kSliceThreads) {
-    const int d = idx / (R1 * 4);
-    const int rem = idx - d * (R1 * 4);
+  for (int idx = tid; idx < 2 * Rg * 4; idx += kSliceThreads) {
+    const int d = idx >= Rg * 4;
+    const int rem = idx - d * (Rg * 4);
     const int r = rem >> 2, k = rem & 3;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    const float* tab = (MODE == MODE_FUSED) ? a.T[d] + (size_t)g * R1 * D : a.T[d];
+    const float* tab = a.T[d] + (size_t)roff * D;
     if (col0 + 4 * k < D) v = *reinterpret_cast<const f32x4*>(tab + (size_t)r * D + col0 + 4 * k);
-    *reinterpret_cast<f32x4*>(Ts + ((size_t)d * R1 + r) * kSliceW + 4 * k) = v;
+    *reinterpret_cast<f32x4*>(Ts + ((size_t)d * Rg + r) * kSliceW + 4 * k) = v;
   }
   __syncthreads();
 
@@ -614,7 +621,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
   const int nsets = (N + 15) / 16;
   const bool col_ok = col0 + 4 * sub < D;
   const int2* const prd[2] = {pr, pr + F};
-  const float* Td[2] = {Ts + 4 * sub, Ts + (size_t)R1 * kSliceW + 4 * sub};
+  const float* Td[2] = {Ts + 4 * sub, Ts + (size_t)Rg * kSliceW + 4 * sub};
   f32x4 q[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
@@ -821,9 +828,10 @@ static size_t slice_lds_bytes(int R1, int na = 3) {
   return (size_t)2 * R1 * kSliceW * sizeof(float) + (16 + 5 * kSliceBigCap) * sizeof(int) +
          (size_t)na * 16 * 16 * sizeof(float);
 }
-// the LDS variant needs the two table slices of a question in one CU's LDS (160 KB)
-static bool slice_walk_fits(const gnnrag_csr* csr, int D) {
-  return D % 4 == 0 && slice_lds_bytes(csr->R1) <= 160 * 1024 - 1024;
+// the LDS variant needs the two table slices of a question in one CU's LDS (160 KB); rows = table rows
+// of the largest question (fused: relations it uses; unfused: the whole vocabulary)
+static bool slice_walk_fits(int rows, int D) {
+  return D % 4 == 0 && slice_lds_bytes(rows) <= 160 * 1024 - 1024;
 }
 
 static int fill_common(WalkArgs& a, const gnnrag_csr* csr, int D, void* ws, size_t ws_bytes, int na) {
@@ -866,7 +874,7 @@ static int launch_slice(const WalkArgs& a, const gnnrag_csr* csr, void* workspac
     GNNRAG_LAUNCH_CHECK();
   }
   const int nslice = (D + kSliceW - 1) / kSliceW;
-  const size_t lds = slice_lds_bytes(csr->R1, SliceAcc<MODE, NI>::n);
+  const size_t lds = slice_lds_bytes(a.R1, SliceAcc<MODE, NI>::n);
   static bool attr_set = false;   // raising the dynamic-LDS cap is idempotent; once per kernel and process
   if (!attr_set) {
     GNNRAG_HIP(hipFuncSetAttribute((const void*)k_walk_slice<MODE, NI>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -906,7 +914,7 @@ extern "C" int gnnrag_aggregate(const gnnrag_csr* csr, const float* dist, const 
   a.out = agg;
   a.I = I;
   // up to 3 instructions share one walk (their accumulators live in registers side by side)
-  const bool lds_walk = slice_walk_fits(csr, D) && GNNRAG_REASON_SLICE;
+  const bool lds_walk = slice_walk_fits(csr->R1, D) && GNNRAG_REASON_SLICE;
   for (int i0 = 0; i0 < I; i0 += 3) {
     a.i0 = i0;
     const int ni = (I - i0) < 3 ? (I - i0) : 3;
@@ -926,7 +934,7 @@ extern "C" int gnnrag_aggregate(const gnnrag_csr* csr, const float* dist, const 
 extern "C" int gnnrag_aggregate_fused(const gnnrag_csr* csr, const float* dist, const float* P, float* out,
                                       int32_t D, void* workspace, size_t workspace_bytes,
                                       gnnrag_stream_t stream_) {
-  if (!csr || !dist || !P || !out || D <= 0) return GNNRAG_E_BADARG;
+  if (!csr || !dist || !P || !out || D <= 0 || csr->rel_total < 0) return GNNRAG_E_BADARG;
   hipStream_t stream = (hipStream_t)stream_;
   WalkArgs a;
   memset(&a, 0, sizeof(a));
@@ -935,11 +943,14 @@ extern "C" int gnnrag_aggregate_fused(const gnnrag_csr* csr, const float* dist, 
   a.w[0] = csr->w_gnn[0];
   a.w[1] = csr->w_gnn[1];
   a.T[0] = P;
-  a.T[1] = P + (size_t)csr->B * csr->R1 * D;
+  a.T[1] = P + (size_t)csr->rel_total * D;
+  for (int d = 0; d < 2; ++d) a.edge[d] = (const int2*)csr->edge_l[d];   // relation = compact index in the question
+  a.rel_off = csr->rel_off;
+  a.R1 = csr->rel_max;
   a.dist = dist;
   a.out = out;
   a.I = 1;
-  if (!slice_walk_fits(csr, D)) return launch_walk<MODE_FUSED>(a, 1, stream);   // tables too big for LDS
+  if (!slice_walk_fits(csr->rel_max, D)) return launch_walk<MODE_FUSED>(a, 1, stream);   // tables too big for LDS
   return launch_slice<MODE_FUSED, 1>(a, csr, workspace, workspace_bytes, 1, stream);
 }
 

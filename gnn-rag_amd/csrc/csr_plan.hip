@@ -19,11 +19,12 @@
 namespace gnnrag {
 
 struct CsrLayout {
-  size_t row_ptr[2], edge[2], perm[2], w_gnn[2], w_rel[2], heavy[2], chunk_off[2], n_heavy, big_cnt, big_nodes, total;
+  size_t row_ptr[2], edge[2], perm[2], w_gnn[2], w_rel[2], heavy[2], chunk_off[2], n_heavy, big_cnt, big_nodes;
+  size_t edge_l[2], rel_off, rel_rows, total;
   int32_t heavy_cap;
 };
 
-static CsrLayout csr_layout(int64_t F, int32_t B, int32_t N, int has_w_gnn, int has_w_rel) {
+static CsrLayout csr_layout(int64_t F, int32_t B, int32_t N, int32_t R1, int has_w_gnn, int has_w_rel) {
   CsrLayout L;
   size_t off = 0;
   const size_t BN = (size_t)B * (size_t)N;
@@ -41,9 +42,13 @@ static CsrLayout csr_layout(int64_t F, int32_t B, int32_t N, int has_w_gnn, int 
   for (int d = 0; d < 2; ++d) L.w_rel[d] = has_w_rel ? take(Fp * sizeof(float)) : 0;
   for (int d = 0; d < 2; ++d) L.heavy[d] = take((size_t)L.heavy_cap * sizeof(int32_t));
   for (int d = 0; d < 2; ++d) L.chunk_off[d] = take(((size_t)L.heavy_cap + 1) * sizeof(int32_t));
-  L.n_heavy = take(4 * sizeof(int32_t));   // n_heavy[2], n_chunks[2]
+  L.n_heavy = take(8 * sizeof(int32_t));   // n_heavy[2], n_chunks[2], rel_total, rel_max
   L.big_cnt = take((size_t)B * sizeof(int32_t));
   L.big_nodes = take(BN * sizeof(int32_t));
+  for (int d = 0; d < 2; ++d) L.edge_l[d] = take(Fp * 2 * sizeof(int32_t));
+  L.rel_off = take(((size_t)B + 1) * sizeof(int32_t));
+  const size_t BR = (size_t)B * (size_t)R1;
+  L.rel_rows = take((BR < Fp ? BR : Fp) * 2 * sizeof(int32_t));   // every compact row has >= 1 fact
   L.total = off;
   return L;
 }
@@ -76,12 +81,16 @@ __global__ __launch_bounds__(256) void k_csr_fill(const int32_t* __restrict__ pe
                                                   const int32_t* __restrict__ rels,
                                                   const float* __restrict__ wg,
                                                   const float* __restrict__ wr, int64_t F,
-                                                  int2* __restrict__ edge, float* __restrict__ wg_out,
-                                                  float* __restrict__ wr_out) {
+                                                  const int32_t* __restrict__ g2l, int32_t N, int32_t R1,
+                                                  int2* __restrict__ edge, int2* __restrict__ edge_l,
+                                                  float* __restrict__ wg_out, float* __restrict__ wr_out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= F) return;
   const int32_t f = perm[i];
-  edge[i] = make_int2(src[f], rels[f]);
+  const int32_t s = src[f], r = rels[f];
+  edge[i] = make_int2(s, r);
+  // the same fact with its relation renumbered inside its question (fused path)
+  edge_l[i] = make_int2(s, (unsigned)r < (unsigned)R1 ? g2l[(size_t)(s / N) * R1 + r] : 0);
   if (wg_out) {
     const float v = wg[f];
     wg_out[i] = v * v;  // the weight enters head2fact AND fact2tail (base_gnn.py:44-47)
@@ -181,6 +190,93 @@ __global__ __launch_bounds__(1024) void k_csr_heavy_chunks(const int32_t* __rest
   }
 }
 
+// ---- per-question relation compaction ---------------------------------------------------------
+// exclusive prefix of one int per thread over a 1024-thread workgroup (wsum: 16 ints of LDS)
+__device__ __forceinline__ int block_scan_excl(int v, int* wsum, int& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  int wp = 0;
+  total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) wp += wsum[w];
+    total += wsum[w];
+  }
+  __syncthreads();
+  return wp + x - v;
+}
+
+// g2l[b*R1 + r] = 1 for every (question, relation) pair that occurs (benign write race)
+__global__ __launch_bounds__(256) void k_rel_flag(const int32_t* __restrict__ heads,
+                                                  const int32_t* __restrict__ rels, int64_t F, int32_t N,
+                                                  int32_t R1, int32_t B, int32_t* __restrict__ g2l) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F) return;
+  const int32_t r = rels[i];
+  const int32_t b = heads[i] / N;
+  if ((unsigned)r < (unsigned)R1 && (unsigned)b < (unsigned)B) g2l[(size_t)b * R1 + r] = 1;
+}
+
+// one workgroup per question: flags -> compact index (or -1), number of used relations -> cnt[b]
+__global__ __launch_bounds__(1024) void k_rel_scan(int32_t* __restrict__ g2l, int32_t R1,
+                                                   int32_t* __restrict__ cnt) {
+  __shared__ int wsum[16];
+  int32_t* row = g2l + (size_t)blockIdx.x * R1;
+  int carry = 0;
+  for (int base = 0; base < R1; base += 1024) {
+    const int i = base + (int)threadIdx.x;
+    const int v = (i < R1) ? row[i] : 0;
+    int total;
+    const int ex = block_scan_excl(v, wsum, total);
+    if (i < R1) row[i] = v ? carry + ex : -1;
+    carry += total;
+  }
+  if (threadIdx.x == 0) cnt[blockIdx.x] = carry;
+}
+
+// rel_off[1..B] holds the per-question counts on entry; prefix sum in place, totals to stats
+__global__ __launch_bounds__(1024) void k_rel_off(int32_t* __restrict__ rel_off, int32_t B,
+                                                  int32_t* __restrict__ stats) {
+  __shared__ int wsum[16];
+  __shared__ int mx;
+  if (threadIdx.x == 0) mx = 0;
+  __syncthreads();
+  int carry = 0;
+  for (int base = 0; base < B; base += 1024) {
+    const int i = base + (int)threadIdx.x;
+    const int v = (i < B) ? rel_off[i + 1] : 0;
+    atomicMax(&mx, v);
+    int total;
+    const int ex = block_scan_excl(v, wsum, total);
+    if (i < B) rel_off[i + 1] = carry + ex + v;
+    carry += total;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    rel_off[0] = 0;
+    stats[0] = carry;
+    stats[1] = mx;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_rel_rows(const int32_t* __restrict__ g2l,
+                                                  const int32_t* __restrict__ rel_off, int32_t R1, int64_t BR,
+                                                  int2* __restrict__ rel_rows) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= BR) return;
+  const int l = g2l[idx];
+  if (l < 0) return;
+  const int b = (int)(idx / R1);
+  rel_rows[rel_off[b] + l] = make_int2(b, (int)(idx - (int64_t)b * R1));
+}
+
 __global__ __launch_bounds__(256) void k_csr_permute_weight(const int32_t* __restrict__ perm,
                                                             const float* __restrict__ w, int64_t F, int square,
                                                             float* __restrict__ out) {
@@ -209,16 +305,17 @@ extern "C" int gnnrag_csr_permute_weight(const gnnrag_csr* csr, const float* w_p
   return 0;
 }
 
-extern "C" size_t gnnrag_csr_bytes(int64_t F, int32_t B, int32_t N, int has_w_gnn, int has_w_rel) {
-  if (F < 0 || B <= 0 || N <= 0) return 0;
-  return csr_layout(F, B, N, has_w_gnn, has_w_rel).total;
+extern "C" size_t gnnrag_csr_bytes(int64_t F, int32_t B, int32_t N, int32_t R1, int has_w_gnn, int has_w_rel) {
+  if (F < 0 || B <= 0 || N <= 0 || R1 <= 0) return 0;
+  return csr_layout(F, B, N, R1, has_w_gnn, has_w_rel).total;
 }
 
-extern "C" size_t gnnrag_csr_scratch_bytes(int64_t F, int32_t B, int32_t N) {
-  if (F < 0 || B <= 0 || N <= 0) return 0;
+extern "C" size_t gnnrag_csr_scratch_bytes(int64_t F, int32_t B, int32_t N, int32_t R1) {
+  if (F < 0 || B <= 0 || N <= 0 || R1 <= 0) return 0;
   const size_t Fp = (size_t)(F > 0 ? F : 1);
   const unsigned bits = key_bits((size_t)B * (size_t)N);
-  return align_up(Fp * sizeof(uint32_t), 256) + align_up(sort_temp_bytes(F, bits), 256);
+  return align_up(Fp * sizeof(uint32_t), 256) + align_up(sort_temp_bytes(F, bits), 256) +
+         align_up((size_t)B * (size_t)R1 * sizeof(int32_t), 256);
 }
 
 extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const int32_t* tails,
@@ -230,7 +327,8 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
   const int64_t BN = (int64_t)B * N;
   if (BN >= ((int64_t)1 << 31) || F >= ((int64_t)1 << 31)) return GNNRAG_E_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
-  const CsrLayout L = csr_layout(F, B, N, w_gnn != nullptr, w_rel != nullptr);
+  if ((int64_t)B * R1 >= ((int64_t)1 << 31)) return GNNRAG_E_UNSUPPORTED;
+  const CsrLayout L = csr_layout(F, B, N, R1, w_gnn != nullptr, w_rel != nullptr);
   if (csr_bytes < L.total) return GNNRAG_E_WORKSPACE;
   char* base = (char*)csr_mem;
   memset(out, 0, sizeof(*out));
@@ -245,7 +343,10 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
     out->w_rel[d] = w_rel ? (float*)(base + L.w_rel[d]) : nullptr;
     out->heavy[d] = (int32_t*)(base + L.heavy[d]);
     out->chunk_off[d] = (int32_t*)(base + L.chunk_off[d]);
+    out->edge_l[d] = (int32_t*)(base + L.edge_l[d]);
   }
+  out->rel_off = (int32_t*)(base + L.rel_off);
+  out->rel_rows = (int32_t*)(base + L.rel_rows);
   out->n_heavy = (int32_t*)(base + L.n_heavy);
   out->n_chunks = out->n_heavy + 2;
   out->big_cnt = (int32_t*)(base + L.big_cnt);
@@ -253,17 +354,37 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
   out->big_deg = kBigDeg;
   GNNRAG_HIP(hipMemsetAsync(out->big_cnt, 0, (size_t)B * sizeof(int32_t), stream));
   out->max_chunks = 2 * L.heavy_cap;   // sum ceil(deg/256) over rows with deg > 256 < F/256 + F/257
-  GNNRAG_HIP(hipMemsetAsync(out->n_heavy, 0, 4 * sizeof(int32_t), stream));
+  GNNRAG_HIP(hipMemsetAsync(out->n_heavy, 0, 8 * sizeof(int32_t), stream));
+  GNNRAG_HIP(hipMemsetAsync(out->rel_off, 0, ((size_t)B + 1) * sizeof(int32_t), stream));
+  int32_t* rel_stats = out->n_heavy + 4;
 
   const unsigned bits = key_bits((size_t)BN);
   const size_t keys_bytes = align_up((size_t)(F > 0 ? F : 1) * sizeof(uint32_t), 256);
   size_t temp_bytes = 0;
   if (F > 0) {
     temp_bytes = sort_temp_bytes(F, bits);
-    if (scratch_bytes < keys_bytes + temp_bytes) return GNNRAG_E_WORKSPACE;
+    temp_bytes = align_up(temp_bytes, 256);
+    if (scratch_bytes < keys_bytes + temp_bytes + (size_t)B * R1 * sizeof(int32_t)) return GNNRAG_E_WORKSPACE;
   }
   uint32_t* keys_sorted = (uint32_t*)scratch;
   void* temp = (char*)scratch + keys_bytes;
+  int32_t* g2l = (int32_t*)((char*)scratch + keys_bytes + temp_bytes);
+
+  // relations each question uses -> compact numbering (before the fills, which store it per fact)
+  if (F > 0) {
+    const int64_t BR = (int64_t)B * R1;
+    GNNRAG_HIP(hipMemsetAsync(g2l, 0, (size_t)BR * sizeof(int32_t), stream));
+    hipLaunchKernelGGL(k_rel_flag, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, stream, heads, rels, F, N,
+                       R1, B, g2l);
+    GNNRAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_rel_scan, dim3(B), dim3(1024), 0, stream, g2l, R1, out->rel_off + 1);
+    GNNRAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_rel_off, dim3(1), dim3(1024), 0, stream, out->rel_off, B, rel_stats);
+    GNNRAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_rel_rows, dim3((unsigned)((BR + 255) / 256)), dim3(256), 0, stream, g2l, out->rel_off,
+                       R1, BR, (int2*)out->rel_rows);
+    GNNRAG_LAUNCH_CHECK();
+  }
 
   const int nb_rows = (int)((BN + 1 + 255) / 256);
   for (int d = 0; d < 2; ++d) {
@@ -276,7 +397,8 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
                                            out->perm[d], (size_t)F, 0u, bits, stream, false));
       const int nb = (int)((F + 255) / 256);
       hipLaunchKernelGGL(k_csr_fill, dim3(nb), dim3(256), 0, stream, out->perm[d], src, rels, w_gnn,
-                         w_rel, F, (int2*)out->edge[d], out->w_gnn[d], out->w_rel[d]);
+                         w_rel, F, g2l, N, R1, (int2*)out->edge[d], (int2*)out->edge_l[d], out->w_gnn[d],
+                         out->w_rel[d]);
       GNNRAG_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_csr_row_ptr, dim3(nb_rows), dim3(256), 0, stream, keys_sorted, F, BN,
@@ -294,5 +416,11 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
   hipLaunchKernelGGL(k_csr_big, dim3((int)((BN + 255) / 256)), dim3(256), 0, stream, out->row_ptr[0],
                      out->row_ptr[1], BN, N, (int32_t)kBigDeg, out->big_cnt, out->big_nodes);
   GNNRAG_LAUNCH_CHECK();
+  // the relation counts size the fused path's tables and launches: hand them to the host
+  int32_t stats[2] = {0, 0};
+  GNNRAG_HIP(hipMemcpyAsync(stats, rel_stats, sizeof(stats), hipMemcpyDeviceToHost, stream));
+  GNNRAG_HIP(hipStreamSynchronize(stream));
+  out->rel_total = stats[0];
+  out->rel_max = stats[1];
   return 0;
 }

@@ -54,9 +54,10 @@ struct GemmArgs {
   int32_t n0;           // first output column of this launch's column block (EPI_LINEAR, Nout > 208)
   int32_t ldw;          // row stride of W in floats (>= K; e2e_linear column blocks are used in place)
   int32_t wc0;          // first column of W used (AMODE_PLAIN)
-  // AMODE_GEN (per-question relation tables): row m = (b, r), column k = (i, kk):
+  // AMODE_GEN (per-question relation tables): row m = compact row (b, r) = gen_rows[m], column k = (i, kk):
   //   A[m,k] = relu(A0[r*D + kk] * A1[(b*I + i)*D + kk]),  W column = (1 + 2i + gen_dir)*D + kk
-  int32_t gen_R1, gen_D, gen_I, gen_dir;
+  const int2* gen_rows;
+  int32_t gen_D, gen_I, gen_dir;
   int32_t v4out;        // rows of C/add are 16-byte aligned and Nout % 4 == 0: float4 epilogue
 };
 
@@ -70,7 +71,8 @@ __device__ __forceinline__ f32x4 load_a4(const GemmArgs& g, int m, int k) {
   if constexpr (AMODE == AMODE_GEN) {
     // relu(T_d[r,:] * ins[b,i,:]) generated on the fly: the [B*R1, I*D] operand never exists in HBM
     if (k >= g.K) return v;
-    const int b = m / g.gen_R1, r = m - b * g.gen_R1;
+    const int2 br = g.gen_rows[m];
+    const int b = br.x, r = br.y;
     const int i = k / g.gen_D, kk = k - i * g.gen_D;
     const float* tp = g.A0 + (size_t)r * g.gen_D + kk;
     const float* qp = g.A1 + ((size_t)b * g.gen_I + i) * g.gen_D + kk;
@@ -194,10 +196,9 @@ void k_gemm_f32(GemmArgs g) {
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
       const int m = m0 + lr + RPR * r;
-      const int mm = m < g.M ? m : 0;
-      const int b = mm / g.gen_R1, rr = mm - b * g.gen_R1;
-      gen_t[r] = (m < g.M) ? g.A0 + (size_t)rr * g.gen_D : nullptr;
-      gen_q[r] = g.A1 + (size_t)b * g.gen_I * g.gen_D;
+      const int2 br = g.gen_rows[m < g.M ? m : 0];     // (question, relation) of this compact row
+      gen_t[r] = (m < g.M) ? g.A0 + (size_t)br.y * g.gen_D : nullptr;
+      gen_q[r] = g.A1 + (size_t)br.x * g.gen_I * g.gen_D;
     }
     gen_i = (kq * 4) / g.gen_D;
     gen_kk = kq * 4 - gen_i * g.gen_D;
@@ -671,20 +672,20 @@ extern "C" int gnnrag_update_score_fused(const float* h, const float* nbr, const
   return update_common(g, BN, D, (hipStream_t)stream);
 }
 
-extern "C" int gnnrag_relation_tables(const float* T_fwd, const float* T_inv, const float* ins, const float* W,
-                                      float* P, int32_t B, int32_t R1, int32_t D, int32_t I,
+extern "C" int gnnrag_relation_tables(const gnnrag_csr* csr, const float* T_fwd, const float* T_inv,
+                                      const float* ins, const float* W, float* P, int32_t D, int32_t I,
                                       gnnrag_stream_t stream) {
-  if (!T_fwd || !T_inv || !ins || !W || !P || B <= 0 || R1 <= 0 || D <= 0 || I <= 0) return GNNRAG_E_BADARG;
-  if ((int64_t)B * R1 >= ((int64_t)1 << 31)) return GNNRAG_E_UNSUPPORTED;
+  if (!csr || !T_fwd || !T_inv || !ins || !W || !P || D <= 0 || I <= 0 || csr->rel_total < 0) return GNNRAG_E_BADARG;
+  if (csr->rel_total == 0) return 0;      // no facts, no tables
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.A0 = T_fwd;
   g.A0b = T_inv;
   g.A1 = ins;
   g.W = W;
-  g.C = P;                       // direction d (blockIdx.y) writes P + d*B*R1*D
-  g.M = B * R1; g.K = I * D; g.K0 = g.K; g.Nout = D; g.ldw = (2 * I + 1) * D;
-  g.gen_R1 = R1; g.gen_D = D; g.gen_I = I;
+  g.C = P;                       // direction d (blockIdx.y) writes P + d*rel_total*D
+  g.M = csr->rel_total; g.K = I * D; g.K0 = g.K; g.Nout = D; g.ldw = (2 * I + 1) * D;
+  g.gen_rows = (const int2*)csr->rel_rows; g.gen_D = D; g.gen_I = I;
   for (int n0 = 0; n0 < D; n0 += 208) {
     g.n0 = n0;
     const int rc = launch_gemm<EPI_LINEAR, AMODE_GEN>(g, (hipStream_t)stream);

@@ -84,10 +84,11 @@ __global__ __launch_bounds__(256) void k_stream_copy(const f32x4* __restrict__ s
 struct LayerWs { size_t T_fwd, T_inv, agg, P, nbr, partial, partial_bytes, total; };
 
 // flops of the dense part per layer call: unfused = one [BN,(2I+1)D]x[(2I+1)D,D] GEMM; fused = the
-// per-question relation tables [2*B*R1, I*D]x[I*D, D] plus the self block [BN,D]x[D,D]
-static bool fused_is_cheaper(int64_t B, int64_t N, int64_t R1, int64_t D, int64_t I) {
+// per-question relation tables [2*rel_total, I*D]x[I*D, D] (rel_total = sum over questions of the
+// relations each one uses) plus the self block [BN,D]x[D,D]
+static bool fused_is_cheaper(int64_t B, int64_t N, int64_t rel_total, int64_t D, int64_t I) {
   const double unfused = (double)B * N * (2 * I + 1) * D * D;
-  const double fused = 2.0 * B * R1 * I * D * D + (double)B * N * D * D;
+  const double fused = 2.0 * rel_total * I * D * D + (double)B * N * D * D;
   return fused < 0.8 * unfused;
 }
 
@@ -100,7 +101,7 @@ static LayerWs layer_ws(const gnnrag_csr* csr, int32_t D, int32_t I) {
   w.T_inv = take((size_t)csr->R1 * D * sizeof(float));
   // the two paths never run in the same call: their big buffers share one region
   const size_t a_bytes = BN * 2 * I * D * sizeof(float);
-  const size_t p_bytes = align_up((size_t)2 * csr->B * csr->R1 * D * sizeof(float), 256);
+  const size_t p_bytes = align_up((size_t)2 * (csr->rel_total > 0 ? csr->rel_total : 1) * D * sizeof(float), 256);
   const size_t n_bytes = BN * D * sizeof(float);
   const size_t big = take(a_bytes > p_bytes + n_bytes ? a_bytes : p_bytes + n_bytes);
   w.agg = big;
@@ -164,11 +165,11 @@ extern "C" int gnnrag_reason_layer(const gnnrag_csr* csr, const float* h, const 
                           pos_fwd ? pos_rows : 0, T_fwd, T_inv, D, stream);
   if (rc) return rc;
   if (path == GNNRAG_PATH_AUTO)
-    path = fused_is_cheaper(csr->B, csr->N, csr->R1, D, I) ? GNNRAG_PATH_FUSED : GNNRAG_PATH_UNFUSED;
+    path = fused_is_cheaper(csr->B, csr->N, csr->rel_total, D, I) ? GNNRAG_PATH_FUSED : GNNRAG_PATH_UNFUSED;
   if (path == GNNRAG_PATH_FUSED) {
     float* P = (float*)(base + w.P);
     float* nbr = (float*)(base + w.nbr);
-    rc = gnnrag_relation_tables(T_fwd, T_inv, ins, W_e2e, P, csr->B, csr->R1, D, I, stream);
+    rc = gnnrag_relation_tables(csr, T_fwd, T_inv, ins, W_e2e, P, D, I, stream);
     if (rc) return rc;
     rc = gnnrag_aggregate_fused(csr, dist, P, nbr, D, base + w.partial, w.partial_bytes, stream);
     if (rc) return rc;

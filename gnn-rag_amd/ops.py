@@ -65,8 +65,8 @@ class CsrPlan:
         hrt[0, :F], hrt[1, :F], hrt[2, :F] = heads, rels, tails
         with torch.cuda.device(self.device):
             self._hrt = torch.from_numpy(hrt).to(self.device, non_blocking=False)   # ONE int32 upload
-            nbytes = lib.gnnrag_csr_bytes(F, B, N, 0, 0)
-            sbytes = lib.gnnrag_csr_scratch_bytes(F, B, N)
+            nbytes = lib.gnnrag_csr_bytes(F, B, N, R1, 0, 0)
+            sbytes = lib.gnnrag_csr_scratch_bytes(F, B, N, R1)
             self._mem = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
             scratch = torch.empty(max(sbytes, 256), dtype=torch.uint8, device=self.device)
             self.c = _lib.CsrStruct()
@@ -75,9 +75,10 @@ class CsrPlan:
                 row[0].data_ptr(), row[1].data_ptr(), row[2].data_ptr(), None, None,
                 F, B, N, R1, self._mem.data_ptr(), self._mem.numel(),
                 scratch.data_ptr(), scratch.numel(), C.byref(self.c), _stream()), "gnnrag_csr_build")
-            # scratch is only read by kernels already enqueued on this stream; the caching
-            # allocator re-issues it to later work on the same stream only, so dropping it is safe
+            # the build waits for its stream once (it returns the relation counts), so scratch is free
         self._w = {}
+        # compact relation rows: question b's tables are rows rel_off[b] : rel_off[b+1] of P[d]
+        self.rel_total, self.rel_max = int(self.c.rel_total), int(self.c.rel_max)
 
     def walk_workspace(self, D: int, I: int) -> torch.Tensor:
         """Scratch for the heavy-row partial sums of the walk kernels (cached per (D, I))."""
@@ -143,7 +144,15 @@ class CsrPlan:
         bc = self._view(self.c.big_cnt, self.B, torch.int32).numpy()
         bn = self._view(self.c.big_nodes, BN, torch.int32).numpy().reshape(self.B, self.N)
         out["big"] = [np.sort(bn[b, : bc[b]]) for b in range(self.B)]
+        for d in (0, 1):
+            out["edge_l%d" % d] = self._view(self.c.edge_l[d], 2 * self.F, torch.int32).numpy().reshape(-1, 2)
+        out["rel_off"] = self._view(self.c.rel_off, self.B + 1, torch.int32).numpy()
+        out["rel_rows"] = self._view(self.c.rel_rows, 2 * self.rel_total, torch.int32).numpy().reshape(-1, 2)
         return out
+
+    def rel_rows(self) -> np.ndarray:
+        """[rel_total, 2] (question, relation id) of every compact relation row (host copy)."""
+        return self._view(self.c.rel_rows, 2 * self.rel_total, torch.int32).numpy().reshape(-1, 2)
 
 
 def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
@@ -190,19 +199,23 @@ def aggregate(plan: CsrPlan, dist: torch.Tensor, ins: torch.Tensor, T_fwd: torch
     return agg
 
 
-def relation_tables(T_fwd: torch.Tensor, T_inv: torch.Tensor, ins: torch.Tensor, W_e2e: torch.Tensor) -> torch.Tensor:
-    """P[d,b,r,:] = sum_i W_e2e[:, block(i,d)] relu(T_d[r,:] * ins[b,i,:])  ->  [2,B,R1,D]."""
+def relation_tables(plan: CsrPlan, T_fwd: torch.Tensor, T_inv: torch.Tensor, ins: torch.Tensor,
+                    W_e2e: torch.Tensor) -> torch.Tensor:
+    """P[d,row(b,r),:] = sum_i W_e2e[:, block(i,d)] relu(T_d[r,:] * ins[b,i,:])  ->  [2,rel_total,D],
+    one row per (question, relation the question uses) - ``plan.rel_rows()`` lists them."""
     lib = _lib.load()
     ins = _chk(ins, "ins")
     B, I, D = ins.shape
-    T_fwd = _chk(T_fwd, "T_fwd")
-    R1 = T_fwd.shape[0]
-    T_inv = _chk(T_inv, "T_inv", shape=(R1, D))
+    if B != plan.B:
+        raise ValueError("ins has %d questions, the plan %d" % (B, plan.B))
+    T_fwd = _chk(T_fwd, "T_fwd", shape=(plan.R1, D))
+    T_inv = _chk(T_inv, "T_inv", shape=(plan.R1, D))
     W_e2e = _chk(W_e2e, "e2e_linear.weight", shape=(D, (2 * I + 1) * D))
-    P = torch.empty((2, B, R1, D), dtype=torch.float32, device=ins.device)
+    P = torch.empty((2, plan.rel_total, D), dtype=torch.float32, device=ins.device)
     with torch.cuda.device(ins.device):
-        _lib.check(lib.gnnrag_relation_tables(T_fwd.data_ptr(), T_inv.data_ptr(), ins.data_ptr(), W_e2e.data_ptr(),
-                                              P.data_ptr(), B, R1, D, I, _stream()), "gnnrag_relation_tables")
+        _lib.check(lib.gnnrag_relation_tables(C.byref(plan.c), T_fwd.data_ptr(), T_inv.data_ptr(), ins.data_ptr(),
+                                              W_e2e.data_ptr(), P.data_ptr(), D, I, _stream()),
+                   "gnnrag_relation_tables")
     return P
 
 
@@ -211,8 +224,8 @@ def aggregate_fused(plan: CsrPlan, dist: torch.Tensor, P: torch.Tensor) -> torch
     B, N = plan.B, plan.N
     P = _chk(P, "P")
     D = P.shape[-1]
-    if tuple(P.shape) != (2, B, plan.R1, D):
-        raise ValueError("P must be [2,B,R1,D]")
+    if tuple(P.shape) != (2, plan.rel_total, D):
+        raise ValueError("P must be [2, plan.rel_total, D]")
     dist = _chk(dist, "dist").reshape(-1)
     out = torch.empty((B * N, D), dtype=torch.float32, device=dist.device)
     ws = plan.walk_workspace(D, 1)
@@ -296,12 +309,11 @@ class LayerWorkspace:
         self.buf = None
 
     def get(self, plan: "CsrPlan", D, I, device) -> torch.Tensor:
-        key = (plan.B, plan.N, plan.R1, plan.F, D, I, str(device))
-        if key != self.key:
-            nbytes = _lib.load().gnnrag_layer_workspace_bytes(C.byref(plan.c), D, I)
+        nbytes = max(_lib.load().gnnrag_layer_workspace_bytes(C.byref(plan.c), D, I), 256)
+        if self.key != str(device) or self.buf is None or self.buf.numel() < nbytes:
             self.buf = None                      # release the old buffer before taking the new one
-            self.buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
-            self.key = key
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self.key = str(device)
         return self.buf
 
 

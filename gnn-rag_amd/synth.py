@@ -37,6 +37,9 @@ class GraphConfig:
     normalized_gnn: bool = False
     pos_emb: bool = False
     n_real_min: Optional[int] = None   # ragged: real nodes per question in [n_real_min, N]
+    rel_per_question: Optional[int] = None   # each question draws its relations from its own subset of
+                                             # this many ids out of R (a Freebase subgraph touches a few
+                                             # hundred of the ~6k relations); None = uniform over R
     seed: int = SEED_DEFAULT
 
     @property
@@ -60,8 +63,12 @@ CONFIGS = {
                       n_real_min=50),
     "C3": GraphConfig(name="C3", B=32, N=2000, E=6000, R=600, D=50, I=2, L=3, T=3,
                       n_real_min=50),
+    # C2 with the full Freebase relation vocabulary of WebQSP (6105 relations), a few hundred per question
+    "C2fb": GraphConfig(name="C2fb", B=64, N=2000, E=10000, R=6105, D=200, I=2, L=3, rel_per_question=300),
     # small cases for parity tests
     "tiny": GraphConfig(name="tiny", B=3, N=48, E=150, R=11, D=200, I=2, L=3),
+    "tinyfb": GraphConfig(name="tinyfb", B=5, N=64, E=300, R=1500, D=200, I=2, L=3, rel_per_question=40,
+                          n_real_min=0),
     "tiny50": GraphConfig(name="tiny50", B=4, N=40, E=90, R=7, D=50, I=3, L=2,
                           normalized_gnn=True, pos_emb=True, n_real_min=5),
 }
@@ -99,7 +106,11 @@ def make_edge_tuple(cfg: GraphConfig, rng: np.random.Generator, n_real: np.ndarr
         else:
             h = rng.integers(0, max(n, 1), size=e, dtype=np.int64)
         t = rng.integers(0, max(n, 1), size=e, dtype=np.int64)
-        r = rng.integers(0, cfg.R, size=e, dtype=np.int64)
+        if cfg.rel_per_question:
+            own = rng.choice(cfg.R, size=min(cfg.rel_per_question, cfg.R), replace=False)
+            r = own[(rng.zipf(1.3, size=e) - 1) % len(own)].astype(np.int64)
+        else:
+            r = rng.integers(0, cfg.R, size=e, dtype=np.int64)
         perm = rng.permutation(e)                      # dataset_load.py:489-490
         off = i * cfg.N                                # dataset_load.py:483
         heads.append(h[perm] + off)

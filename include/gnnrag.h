@@ -12,7 +12,8 @@
  *  - plain C: pointers + sizes only, no torch types.  All data pointers are DEVICE pointers
  *    owned by the caller; the library never allocates, frees or retains them.
  *  - all work is enqueued on the given hipStream_t (passed as void*); no internal
- *    synchronisation, no global state, re-entrant per stream.
+ *    synchronisation (one exception: gnnrag_csr_build waits for the stream once, to hand the
+ *    relation counts back to the host), no global state, re-entrant per stream.
  *  - fp32 values, int32 indices, row-major contiguous.
  *  - return value: 0 = success; > 0 = hipError_t of a failed runtime call / launch;
  *    < 0 = GNNRAG_E_* argument error.  gnnrag_error_string() renders either.
@@ -30,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNNRAG_ABI_VERSION 3
+#define GNNRAG_ABI_VERSION 4
 
 #define GNNRAG_E_BADARG      (-1)  /* null pointer / negative size / inconsistent sizes   */
 #define GNNRAG_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set (see DESIGN)  */
@@ -66,17 +67,27 @@ typedef struct gnnrag_csr {
   int32_t* big_nodes;   /* [B][N] their node ids (order irrelevant)                         */
   int32_t  big_deg;
   int32_t  reserved_;
+  /* Per-question relation compaction (fused path).  A question's subgraph touches a small part of
+   * the KB's relation vocabulary (hundreds of Freebase's ~6k relations), so its relation tables
+   * are built over the relations it USES: compact row rel_off[b] + j  <->  (b, j-th smallest
+   * relation id used by question b). */
+  int32_t* edge_l[2];   /* [F][2]   (source node, compact relation index within its question)  */
+  int32_t* rel_off;     /* [B+1]    first compact row of each question (prefix sum)            */
+  int32_t* rel_rows;    /* [rel_total][2]  (question, relation id) of every compact row        */
+  int32_t  rel_total;   /* compact rows in the batch (host copy, filled by gnnrag_csr_build)   */
+  int32_t  rel_max;     /* largest number of relations used by one question                    */
 } gnnrag_csr;
 
 /* Bytes of caller-owned device memory a gnnrag_csr needs (persistent part / build scratch). */
-size_t gnnrag_csr_bytes(int64_t F, int32_t B, int32_t N, int has_w_gnn, int has_w_rel);
-size_t gnnrag_csr_scratch_bytes(int64_t F, int32_t B, int32_t N);
+size_t gnnrag_csr_bytes(int64_t F, int32_t B, int32_t N, int32_t R1, int has_w_gnn, int has_w_rel);
+size_t gnnrag_csr_scratch_bytes(int64_t F, int32_t B, int32_t N, int32_t R1);
 
 /* Builds the structure on the device.  heads/rels/tails are the batch tuple's first three
  * arrays (dataset_load.py:527) narrowed to int32; w_gnn = weight_list (used when
  * args['normalized_gnn']), w_rel = weight_rel_list (used when norm_rel), either may be NULL.
  * Replaces BaseGNNLayer.build_matrix (base_gnn.py:19-51) and the two COO builds inside
- * TypeLayer.forward (layer_init.py:35-36,53-54). */
+ * TypeLayer.forward (layer_init.py:35-36,53-54).  Relation ids must lie in [0, R1).
+ * Synchronises `stream` once at the end (rel_total / rel_max are returned in *out). */
 int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const int32_t* tails,
                      const float* w_gnn, const float* w_rel,
                      int64_t F, int32_t B, int32_t N, int32_t R1,
@@ -127,9 +138,10 @@ int gnnrag_aggregate(const gnnrag_csr* csr, const float* dist, const float* ins,
 
 /* Fused form of the same aggregation: e2e_linear is linear over the concatenated blocks, so it is
  * applied to the per-question relation tables first (gnnrag_relation_tables) and the walk emits
- *   out[n,:] = sum_d sum_{f: dst_d(f)=n} w_f * dist[src_d(f)] * P[d, n/N, rel_f, :]      [B*N, D]
+ *   out[n,:] = sum_d sum_{f: dst_d(f)=n} w_f * dist[src_d(f)] * P[d, row(n/N, rel_f), :]    [B*N, D]
  * = sum_k W_e2e[:, block k] . agg[n,k,:], i.e. the neighbour part of reasongnn.py:161-163 without
- * ever writing agg.  P [2,B,R1,D].  workspace: gnnrag_aggregate_workspace_bytes(csr, D, 1). */
+ * ever writing agg.  P [2,rel_total,D] over the compact rows.
+ * workspace: gnnrag_aggregate_workspace_bytes(csr, D, 1). */
 int gnnrag_aggregate_fused(const gnnrag_csr* csr, const float* dist, const float* P, float* out,
                            int32_t D, void* workspace, size_t workspace_bytes,
                            gnnrag_stream_t stream);
@@ -153,12 +165,12 @@ int gnnrag_masked_softmax(const float* score, float* dist, int32_t B, int32_t N,
 int gnnrag_typelayer(const gnnrag_csr* csr, const float* T, int use_w_rel, float* h0,
                      int32_t D, void* workspace, size_t workspace_bytes, gnnrag_stream_t stream);
 
-/* Per-question relation tables of the fused path:
- *   P[d,b,r,:] = sum_i W_e2e[:, (1+2i+d)D : (2+2i+d)D] . relu(T_d[r,:] * ins[b,i,:])      [2,B,R1,D]
+/* Per-question relation tables of the fused path, one row per (question b, relation r used by b):
+ *   P[d,row(b,r),:] = sum_i W_e2e[:, (1+2i+d)D : (2+2i+d)D] . relu(T_d[r,:] * ins[b,i,:])   [2,rel_total,D]
  * (the e2e_linear column blocks in the concat order of reasongnn.py:150-161).  The operand
  * relu(T_d * ins) is generated inside the GEMM's tile loader and never stored. */
-int gnnrag_relation_tables(const float* T_fwd, const float* T_inv, const float* ins, const float* W_e2e,
-                           float* P, int32_t B, int32_t R1, int32_t D, int32_t I, gnnrag_stream_t stream);
+int gnnrag_relation_tables(const gnnrag_csr* csr, const float* T_fwd, const float* T_inv, const float* ins,
+                           const float* W_e2e, float* P, int32_t D, int32_t I, gnnrag_stream_t stream);
 
 /* h_out = relu(h . W_e2e[:, 0:D]^T + b + nbr), nbr [BN,D] from gnnrag_aggregate_fused; score as in
  * gnnrag_update_score.  Together: reasongnn.py:161-168. */
@@ -171,7 +183,7 @@ int gnnrag_update_score_fused(const float* h, const float* nbr, const float* W_e
  * rel transform (both directions) -> aggregation -> update+score -> softmax.
  * path: GNNRAG_PATH_UNFUSED = aggregate [BN,2I*D] then one [(2I+1)D -> D] GEMM (the reference's
  * operator boundaries); GNNRAG_PATH_FUSED = relation tables -> fused aggregation -> self-block
- * GEMM (2.3x fewer flops and 4x less aggregation traffic when 2*B*R1*I < ~0.8*B*N*2I);
+ * GEMM (2.3x fewer flops and 4x less aggregation traffic when 2*rel_total*I < ~0.8*B*N*2I);
  * GNNRAG_PATH_AUTO picks by that flop model.  Results agree to fp32 rounding (re-association).
  * pos_fwd/pos_inv: pos_emb{step}.weight / pos_emb_inv{step}.weight [pos_rows,D] or NULL.
  * workspace: gnnrag_layer_workspace_bytes() bytes of device scratch. */

@@ -35,22 +35,25 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, n), "missing export: " + n
         assert n in _lib.SIGNATURES, "binding lacks a signature for " + n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.gnnrag_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.gnnrag_abi_version() == _lib.ABI_VERSION == 4
     assert b"bad argument" in lib.gnnrag_error_string(-1)
 
 
 def test_size_queries_and_struct_layout(lib):
-    assert ctypes.sizeof(_lib.CsrStruct) == 4 * 4 + 8 + 8 * 2 * 7 + 8 * 2 + 8 + 8 * 2 + 8
-    n = lib.gnnrag_csr_bytes(768000, 64, 2000, 0, 0)
-    # 2 row_ptr arrays + 2 x (edge 8 B + perm 4 B) per fact, plus small lists
-    # + one int per node for the per-question big-node lists
-    assert 3 * 128001 * 4 + 768000 * 24 <= n <= 3 * 128001 * 4 + 768000 * 24 + 64 * 1024
-    assert lib.gnnrag_csr_bytes(768000, 64, 2000, 1, 1) >= n + 4 * 768000 * 4
-    assert lib.gnnrag_csr_bytes(-1, 64, 2000, 0, 0) == 0
+    assert ctypes.sizeof(_lib.CsrStruct) == 4 * 4 + 8 + 8 * 2 * 7 + 8 * 2 + 8 + 8 * 2 + 8 + 8 * 2 + 8 * 2 + 8
+    n = lib.gnnrag_csr_bytes(768000, 64, 2000, 602, 0, 0)
+    # 2 row_ptr arrays + 2 x (edge 8 B + compact-relation edge 8 B + perm 4 B) per fact, plus small
+    # lists + one int per node for the per-question big-node lists + (question, relation) rows
+    lo = 3 * 128001 * 4 + 768000 * 40 + 64 * 602 * 8
+    assert lo <= n <= lo + 64 * 1024
+    assert lib.gnnrag_csr_bytes(768000, 64, 2000, 602, 1, 1) >= n + 4 * 768000 * 4
+    assert lib.gnnrag_csr_bytes(-1, 64, 2000, 602, 0, 0) == 0
+    assert lib.gnnrag_csr_scratch_bytes(768000, 64, 2000, 602) >= 768000 * 4 + 64 * 602 * 4
     c = _lib.CsrStruct()
     c.B, c.N, c.R1, c.F, c.max_chunks = 64, 2000, 602, 768000, 2 * 3001
+    c.rel_total, c.rel_max = 64 * 601, 601
     ws = lib.gnnrag_layer_workspace_bytes(ctypes.byref(c), 200, 2)
-    # T tables + the larger of {agg [BN,2I*D]} / {P [2,B,R1,D] + nbr [BN,D]} + heavy-chunk partials
+    # T tables + the larger of {agg [BN,2I*D]} / {P [2,rel_total,D] + nbr [BN,D]} + heavy-chunk partials
     assert ws >= 2 * 602 * 200 * 4 + 128000 * 800 * 4 + 2 * c.max_chunks * 2 * 200 * 4
     assert lib.gnnrag_aggregate_workspace_bytes(ctypes.byref(c), 200, 2) >= 2 * c.max_chunks * 2 * 200 * 4
 
@@ -59,7 +62,7 @@ def test_argument_errors_without_gpu(lib):
     assert lib.gnnrag_masked_softmax(None, None, 1, 1, None) == -1
     assert lib.gnnrag_linear(None, 1, 1, None, None, None, 0, 0, None, 1, None) == -1
     assert lib.gnnrag_aggregate(None, None, None, None, None, None, 200, 2, None, 0, None) == -1
-    assert lib.gnnrag_relation_tables(None, None, None, None, None, 1, 1, 8, 2, None) == -1
+    assert lib.gnnrag_relation_tables(None, None, None, None, None, None, 8, 2, None) == -1
 
 
 def test_module_surface_matches_reference_state_dict():

@@ -36,10 +36,10 @@ def _csr_numpy(heads, rels, tails, B, N):
     return out
 
 
-@pytest.mark.parametrize("name", ["tiny", "mid"])
+@pytest.mark.parametrize("name", ["tiny", "mid", "tinyfb"])
 def test_csr_plan_bit_exact(dev, name):
     from gnnrag_amd import ops, synth
-    cfg = synth.CONFIGS["tiny"] if name == "tiny" else synth.GraphConfig(B=3, N=2000, E=10000, R=600, seed=5)
+    cfg = synth.CONFIGS[name] if name != "mid" else synth.GraphConfig(B=3, N=2000, E=10000, R=600, seed=5)
     batch = synth.make_batch(cfg)
     h, r, t = (np.asarray(batch.edge_tuple[i]) for i in range(3))
     plan = ops.CsrPlan(h, r, t, cfg.B, cfg.N, cfg.R1, dev)
@@ -60,6 +60,17 @@ def test_csr_plan_bit_exact(dev, name):
     deg2 = np.maximum(np.diff(want["row_ptr0"]), np.diff(want["row_ptr1"])).reshape(cfg.B, cfg.N)
     for b in range(cfg.B):
         np.testing.assert_array_equal(got["big"][b], b * cfg.N + np.flatnonzero(deg2[b] > 32))
+    # per-question relation compaction: rows = sorted distinct (question, relation) pairs
+    pairs = np.unique(np.stack([h // cfg.N, r], 1), axis=0)
+    np.testing.assert_array_equal(got["rel_rows"], pairs)
+    cnt = np.bincount(pairs[:, 0], minlength=cfg.B) if len(pairs) else np.zeros(cfg.B, np.int64)
+    np.testing.assert_array_equal(got["rel_off"], np.concatenate([[0], np.cumsum(cnt)]))
+    assert plan.rel_total == len(pairs) and plan.rel_max == int(cnt.max())
+    for d in (0, 1):
+        e, el = got["edge%d" % d], got["edge_l%d" % d]
+        np.testing.assert_array_equal(el[:, 0], e[:, 0])
+        q = e[:, 0] // cfg.N
+        np.testing.assert_array_equal(got["rel_rows"][got["rel_off"][q] + el[:, 1]], np.stack([q, e[:, 1]], 1))
     if name == "mid":
         assert got["n_heavy"].sum() > 0, "the Zipf hub must exercise the heavy-row path"
 
@@ -70,6 +81,7 @@ def test_csr_plan_empty_and_validation(dev):
     plan = ops.CsrPlan(z, z, z, 2, 8, 3, dev)
     got = plan.to_host()
     assert (got["row_ptr0"] == 0).all() and (got["row_ptr1"] == 0).all()
+    assert plan.rel_total == 0 and plan.rel_max == 0 and (got["rel_off"] == 0).all()
     with pytest.raises(ValueError):
         ops.CsrPlan(np.array([0]), np.array([5]), np.array([1]), 1, 8, 3, dev)      # relation out of range
     with pytest.raises(ValueError):
@@ -220,7 +232,7 @@ def test_rearev_call_site_fixture(dev):
     assert (dist.cpu().numpy().argmax(1) == z["pred"]).all()          # Hits@1 decisions identical
 
 
-@pytest.mark.parametrize("cfgname", ["tiny", "tiny50", "hub", "huge"])
+@pytest.mark.parametrize("cfgname", ["tiny", "tiny50", "hub", "huge", "tinyfb"])
 def test_fused_kernels_vs_np64(dev, cfgname):
     """The fused path's own kernels (relation tables, fused walk incl. heavy chunks and the
     XCD-aware order, self-block update) against the float64 oracle."""
@@ -261,7 +273,7 @@ def test_fused_kernels_vs_np64(dev, cfgname):
         if cfgname == "huge":
             deg = np.bincount(np.asarray(et[0]), minlength=B * N)
             assert deg.max() > 4096, "config must exercise the workgroup-per-node class"
-        P = ops.relation_tables(T_f, T_i, ins_d, We)
+        P = ops.relation_tables(plan, T_f, T_i, ins_d, We)
         # tables vs fp64
         Tn = [feats["rel_features"].astype(np.float64) @ params["rel_linear0.weight"].astype(np.float64).T
               + params["rel_linear0.bias"], feats["rel_features_inv"].astype(np.float64)
@@ -274,6 +286,10 @@ def test_fused_kernels_vs_np64(dev, cfgname):
             for i in range(I):
                 blk = W_e[:, (1 + 2 * i + d) * D:(2 + 2 * i + d) * D]
                 Pw[d] += np.maximum(Tn[d][None] * feats["ins"][0][:, i, None, :].astype(np.float64), 0) @ blk.T
+        rows = plan.rel_rows()          # compact rows: (question, relation the question uses)
+        used = {(int(h) // N, int(r)) for h, r in zip(et[0], et[1])}
+        assert [tuple(x) for x in rows.tolist()] == sorted(used)
+        Pw = Pw[:, rows[:, 0], rows[:, 1], :]
         np.testing.assert_allclose(P.cpu().numpy(), Pw, rtol=0, atol=TOL_INTERNAL * max(1.0, np.abs(Pw).max()))
         nbr = ops.aggregate_fused(plan, dist_d, P)
         np.testing.assert_allclose(nbr.cpu().numpy(), want_nbr, rtol=0,
@@ -358,6 +374,29 @@ def test_full_size_properties_c2(dev, path):
         sd, _ = stack.run_layers(slayer, sub.cfg, sdev)
         parts.append(sd)
     assert torch.equal(torch.cat(parts, 0), dist)
+
+
+def test_freebase_vocabulary_picks_fused_path(dev):
+    """WebQSP-sized relation vocabulary (6105 ids), a few hundred used per question: the tables are built
+    over the used relations only, so the fused path stays cheaper (and fits LDS); both paths agree with the
+    torch-CPU restatement."""
+    import oracle.rearev_torch_cpu as otorch
+    from gnnrag_amd import ops, stack, synth
+    cfg = synth.GraphConfig(name="fb", B=4, N=2000, E=10000, R=6105, D=200, I=2, L=3, T=1, seed=33,
+                            rel_per_question=300)
+    batch = synth.make_batch(cfg)
+    feats = synth.make_features(cfg)
+    params = synth.make_layer_params(cfg)
+    et = batch.edge_tuple
+    plan = ops.CsrPlan(et[0], et[1], et[2], cfg.B, cfg.N, cfg.R1, dev)
+    assert plan.rel_max <= 301 and plan.rel_total <= cfg.B * 301      # 300 drawn + the self-loop relation
+    want = otorch.run_stack(batch, feats, params)
+    for path in (0, 1, 2):
+        got = stack.run_stack(batch, feats, params, dev, path=path)
+        for c in range(cfg.T * cfg.L):
+            assert np.abs(got["h"][c] - want["h"][c]).max() <= TOL_STATED, (path, c)
+            assert np.abs(got["dist"][c] - want["dist"][c]).max() <= TOL_STATED, (path, c)
+            assert (got["dist"][c].argmax(1) == want["dist"][c].argmax(1)).all()
 
 
 @pytest.mark.parametrize("B,N,E,R,D,I", [

@@ -52,9 +52,9 @@ def main():
                 if "sm" in which:
                     ops.masked_softmax(sc, B, N)
             if "tab" in which:
-                P = ops.relation_tables(Tf, Ti, devin.ins[0], e2e.weight)
+                P = ops.relation_tables(layer.plan, Tf, Ti, devin.ins[0], e2e.weight)
             if "aggf" in which:
-                P = ops.relation_tables(Tf, Ti, devin.ins[0], e2e.weight) if "tab" not in which else P
+                P = ops.relation_tables(layer.plan, Tf, Ti, devin.ins[0], e2e.weight) if "tab" not in which else P
                 nbr = ops.aggregate_fused(layer.plan, dist1, P)                 # dense prior
                 ops.aggregate_fused(layer.plan, devin.seed_dist, P)              # sparse (seed) prior
                 if "updf" in which:

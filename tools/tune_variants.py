@@ -40,13 +40,13 @@ with torch.no_grad():
     rl, e2e, sf = layer.rel_linear1, layer.e2e_linear1, layer.score_func
     h = devin.h0.reshape(B * N, D)
     Tf = ops.linear(devin.rel_features, rl.weight, rl.bias); Ti = ops.linear(devin.rel_features_inv, rl.weight, rl.bias)
-    P = ops.relation_tables(Tf, Ti, devin.ins[0], e2e.weight)
+    P = ops.relation_tables(layer.plan, Tf, Ti, devin.ins[0], e2e.weight)
     nbr = ops.aggregate_fused(layer.plan, dense, P)
     agg = ops.aggregate(layer.plan, dense, devin.ins[0], Tf, Ti)
     ms = {}
     for math in (0, 1):
         ops.set_dense_math(math)
-        fns = {"tables": lambda: ops.relation_tables(Tf, Ti, devin.ins[0], e2e.weight),
+        fns = {"tables": lambda: ops.relation_tables(layer.plan, Tf, Ti, devin.ins[0], e2e.weight),
                "upd": lambda: ops.update_score(h, agg, e2e.weight, e2e.bias, sf.weight, sf.bias, layer.local_entity_mask, I),
                "upd_fused": lambda: ops.update_score_fused(h, nbr, e2e.weight, e2e.bias, sf.weight, sf.bias, layer.local_entity_mask, I)}
         for name, fn in fns.items():
