@@ -5,10 +5,12 @@ Same class name, constructor, registered parameters (so released checkpoints loa
 and the unused-but-present ``glob_lin``, ``lin``, ``lin_m`` - reference
 ``reasongnn.py:26-44``), same ``init_reason`` / ``forward`` signatures, return values and
 side effects (``local_entity_emb``, ``local_entity_mask``, ``possible_cand``).  The body of
-``forward`` is one call into libgnnrag_hip.so (``gnnrag_reason_layer``).
+``forward`` is one call into libgnnrag_hip.so (``gnnrag_reason_layer``) under ``torch.no_grad()``.
 
-Inference only: the HIP operator has no backward yet, so calling
-it with autograd enabled raises instead of silently computing without a graph.
+With autograd enabled (``Trainer_KBQA.train_epoch``, train_model.py:222) the typed-edge
+aggregation runs as an autograd function (HIP forward ``gnnrag_aggregate``, HIP backward
+``gnnrag_aggregate_backward``); the dense projections and dropout around it are the same
+``nn.Linear`` / ``nn.Dropout`` calls as the reference's, which autograd already knows.
 """
 from __future__ import annotations
 
@@ -16,9 +18,10 @@ import os
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ... import ops
-from ..._lib import GnnragError
+from ...autograd import AggregateFn
 from .base_gnn import BaseGNNLayer
 
 VERY_NEG_NUMBER = -100000000000
@@ -77,12 +80,8 @@ class ReasonGNNLayer(BaseGNNLayer):
 
     def forward(self, current_dist, relational_ins, step=0, return_score=False):
         """Next distribution and node representations (reference: reasongnn.py:134-174)."""
-        if torch.is_grad_enabled():
-            raise GnnragError(
-                "gnnrag_amd.ReasonGNNLayer is inference-only (no backward kernel yet): call it under "
-                "torch.no_grad(), as Evaluator.evaluate does (evaluate.py:159)")
-        if self.training and self.linear_dropout > 0:
-            raise GnnragError("dropout > 0 in training mode is not supported by the HIP path")
+        if torch.is_grad_enabled() or (self.training and self.linear_dropout > 0):
+            return self._forward_autograd(current_dist, relational_ins, step, return_score)
         rel_linear = getattr(self, "rel_linear" + str(step))
         e2e_linear = getattr(self, "e2e_linear" + str(step))
         pos = pos_inv = None
@@ -101,3 +100,30 @@ class ReasonGNNLayer(BaseGNNLayer):
         if return_score:
             return score_tp, new_dist
         return new_dist, self.local_entity_emb
+
+    def _forward_autograd(self, current_dist, relational_ins, step, return_score):
+        """Differentiable form of the same layer (reasongnn.py:134-174 op for op; the per-fact
+        rel_linear / pos_emb of :71-79,98-105 applied per relation row, the four sparse products of
+        :80-84,106-111 as ONE aggregation call with a HIP backward)."""
+        rel_linear = getattr(self, "rel_linear" + str(step))
+        e2e_linear = getattr(self, "e2e_linear" + str(step))
+        B, N, D = self.batch_size, self.max_local_entity, self.entity_dim
+        T_fwd = rel_linear(self.rel_features.float())
+        T_inv = rel_linear(self.rel_features_inv.float())
+        if self.use_posemb:
+            pos = getattr(self, "pos_emb" + str(step)).weight
+            pos_inv = getattr(self, "pos_emb_inv" + str(step)).weight
+            pad = T_fwd.new_zeros(T_fwd.size(0) - pos.size(0), D)      # relation rows without a pos_emb row
+            T_fwd = T_fwd + torch.cat([pos, pad], dim=0)
+            T_inv = T_inv + torch.cat([pos_inv, pad], dim=0)
+        agg = AggregateFn.apply(self.plan, current_dist.float(), relational_ins.float(), T_fwd, T_inv)
+        next_local_entity_emb = torch.cat((self.local_entity_emb.float(), agg.view(B, N, -1)), dim=2)
+        self.local_entity_emb = F.relu(e2e_linear(self.linear_drop(next_local_entity_emb)))
+        score_tp = self.score_func(self.linear_drop(self.local_entity_emb)).squeeze(dim=2)
+        answer_mask = self.local_entity_mask
+        self.possible_cand.append(answer_mask)
+        score_tp = score_tp + (1 - answer_mask) * VERY_NEG_NUMBER
+        current_dist = self.softmax_d1(score_tp)
+        if return_score:
+            return score_tp, current_dist
+        return current_dist, self.local_entity_emb

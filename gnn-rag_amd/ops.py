@@ -301,6 +301,42 @@ def typelayer(plan: CsrPlan, T: torch.Tensor, use_w_rel: bool) -> torch.Tensor:
     return h0
 
 
+def aggregate_backward(plan: CsrPlan, dist, ins, T_fwd, T_inv, g_agg):
+    """Gradients of ``aggregate`` with respect to (dist, ins, T_fwd, T_inv)."""
+    lib = _lib.load()
+    B, N = plan.B, plan.N
+    ins = _chk(ins, "ins")
+    _, I, D = ins.shape
+    dist = _chk(dist, "dist").reshape(-1)
+    T_fwd = _chk(T_fwd, "T_fwd", shape=(plan.R1, D))
+    T_inv = _chk(T_inv, "T_inv", shape=(plan.R1, D))
+    g_agg = _chk(g_agg, "g_agg", shape=(B * N, 2 * I * D))
+    g_dist = torch.empty(B * N, dtype=torch.float32, device=dist.device)
+    g_ins = torch.empty_like(ins)
+    g_Tf = torch.empty_like(T_fwd)
+    g_Ti = torch.empty_like(T_inv)
+    with torch.cuda.device(dist.device):
+        _lib.check(lib.gnnrag_aggregate_backward(
+            C.byref(plan.c), dist.data_ptr(), ins.data_ptr(), T_fwd.data_ptr(), T_inv.data_ptr(), g_agg.data_ptr(),
+            g_dist.data_ptr(), g_ins.data_ptr(), g_Tf.data_ptr(), g_Ti.data_ptr(), D, I, _stream()),
+            "gnnrag_aggregate_backward")
+    return g_dist, g_ins, g_Tf, g_Ti
+
+
+def typelayer_backward(plan: CsrPlan, g_pre: torch.Tensor, use_w_rel: bool) -> torch.Tensor:
+    """Gradient of ``typelayer`` with respect to T; g_pre = gradient of the pre-activation [BN, D]."""
+    lib = _lib.load()
+    g_pre = _chk(g_pre, "g_pre")
+    D = g_pre.shape[1]
+    if g_pre.shape[0] != plan.B * plan.N:
+        raise ValueError("g_pre has %d rows, the plan %d nodes" % (g_pre.shape[0], plan.B * plan.N))
+    g_T = torch.empty((plan.R1, D), dtype=torch.float32, device=g_pre.device)
+    with torch.cuda.device(g_pre.device):
+        _lib.check(lib.gnnrag_typelayer_backward(C.byref(plan.c), g_pre.data_ptr(), int(use_w_rel), g_T.data_ptr(),
+                                                 D, _stream()), "gnnrag_typelayer_backward")
+    return g_T
+
+
 class LayerWorkspace:
     """Scratch of gnnrag_reason_layer (T_fwd, T_inv, agg), reused across layer calls."""
 

@@ -491,7 +491,9 @@ def test_bf16x3_mid_size_vs_torch_cpu_oracle(dev, bf16x3):
             assert (got["dist"][c].argmax(1) == want["dist"][c].argmax(1)).all()
 
 
-def test_inference_only_and_no_cpu_fallback(dev):
+def test_no_cpu_fallback_and_autograd_form_agrees(dev):
+    """CPU tensors are refused (no fallback); with autograd enabled the layer takes its differentiable
+    form (HIP aggregation + nn.Linear) and gives the same numbers as the fused inference call."""
     from gnnrag_amd import _lib, stack, synth
     cfg = synth.CONFIGS["tiny"]
     batch = synth.make_batch(cfg)
@@ -500,6 +502,12 @@ def test_inference_only_and_no_cpu_fallback(dev):
     devin = stack.DeviceInputs(batch, feats, dev)
     layer = stack.build_layer(cfg, batch, params, dev)
     stack.init_reason(layer, batch, devin, devin.h0)
+    with torch.no_grad():
+        want, _ = layer(devin.seed_dist, devin.ins[0], step=0)
+    stack.init_reason(layer, batch, devin, devin.h0)
+    with torch.enable_grad():
+        got, _ = layer(devin.seed_dist, devin.ins[0], step=0)
+    assert got.requires_grad and np.abs(got.detach().cpu().numpy() - want.cpu().numpy()).max() <= TOL_STATED
     with pytest.raises(_lib.GnnragError):
-        with torch.enable_grad():
-            layer(devin.seed_dist, devin.ins[0], step=0)
+        from gnnrag_amd import ops
+        ops.linear(torch.zeros(4, 4), torch.zeros(4, 4))

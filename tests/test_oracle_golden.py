@@ -89,3 +89,41 @@ def test_e2e_call_site_fixture_replays_through_oracle():
         np.testing.assert_allclose(h.numpy(), z["call.h_out"][c], rtol=0, atol=2e-6)
     np.testing.assert_allclose(dist.numpy(), z["pred_dist"], rtol=0, atol=1e-7)
     assert (dist.numpy().argmax(1) == z["pred"]).all()
+
+
+@pytest.mark.parametrize("name", ["layer_d200.npz", "layer_d50.npz"])
+def test_grad_oracle_matches_reference_autograd(name):
+    """The float64 autograd restatement (oracle/rearev_grad.py) against gradients recorded from the
+    live reference modules (tests/golden/make_golden_grad.py)."""
+    import oracle.rearev_grad as og
+    cfg, batch, feats, params, _ = load_golden(name)
+    z = np.load(os.path.join(GOLDEN, "grad_" + name))
+    got = og.stack_grads(batch, feats, params, z["cot.Gd"], z["cot.Gh"])
+    assert abs(got["loss"] - float(z["loss"])) <= 1e-4 * max(1.0, abs(float(z["loss"])))
+    names = [k[5:] for k in z.files if k.startswith("grad.")]
+    assert len(names) >= 12
+    for k in names:
+        want = z["grad." + k]
+        tol = 2e-4 * max(np.abs(want).max(), 1e-3)           # the reference ran in fp32
+        np.testing.assert_allclose(got[k], want, rtol=0, atol=tol, err_msg=k)
+
+
+def test_typelayer_grad_oracle_matches_reference_autograd():
+    import oracle.rearev_grad as og
+    z = np.load(os.path.join(GOLDEN, "typelayer.npz"))
+    zg = np.load(os.path.join(GOLDEN, "grad_typelayer.npz"))
+    B, N, D = int(z["B"]), int(z["N"]), int(z["D"])
+    et = (z["heads"], z["rels"], z["tails"])
+    W = z["param.type_layer.kb_self_linear.weight"].astype(np.float64)
+    b = z["param.type_layer.kb_self_linear.bias"].astype(np.float64)
+    rf = z["feat.rel_features"].astype(np.float64)
+    T = rf @ W.T + b
+    for norm_rel in (False, True):
+        h0 = z["ref.h0_norm%d" % int(norm_rel)].reshape(B * N, D)
+        g_pre = zg["cot.G"].reshape(B * N, D) * (h0 > 0)
+        g_T = og.typelayer_grad(et, B, N, T, g_pre, z["weight_rel_list"] if norm_rel else None)
+        tag = "grad.norm%d." % int(norm_rel)
+        for name, got in (("rel_features", g_T @ W), ("kb_self_linear.weight", g_T.T @ rf),
+                          ("kb_self_linear.bias", g_T.sum(0))):
+            want = zg[tag + name]
+            np.testing.assert_allclose(got, want, rtol=0, atol=2e-4 * max(np.abs(want).max(), 1e-3), err_msg=name)
