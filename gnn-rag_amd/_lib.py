@@ -51,9 +51,11 @@ SIGNATURES = {
     "gnnrag_aggregate": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32,
                                    _VP, C.c_size_t, _VP]),
     "gnnrag_aggregate_fused": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, C.c_int32, _VP, C.c_size_t, _VP]),
+    "gnnrag_backward_workspace_bytes": (C.c_size_t, [C.POINTER(CsrStruct), C.c_int32]),
     "gnnrag_aggregate_backward": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
-                                            C.c_int32, C.c_int32, _VP]),
-    "gnnrag_typelayer_backward": (C.c_int, [C.POINTER(CsrStruct), _VP, C.c_int, _VP, C.c_int32, _VP]),
+                                            C.c_int32, C.c_int32, _VP, C.c_size_t, _VP]),
+    "gnnrag_typelayer_backward": (C.c_int, [C.POINTER(CsrStruct), _VP, C.c_int, _VP, C.c_int32, _VP, C.c_size_t,
+                                            _VP]),
     "gnnrag_relation_tables": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32, _VP]),
     "gnnrag_update_score_fused": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_int32,
                                             C.c_int32, _VP]),

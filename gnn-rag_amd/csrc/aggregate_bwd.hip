@@ -17,10 +17,13 @@
 //    chunk (k_bwd_prior_heavy) and are added atomically.
 //  * k_bwd_tables: U is the transpose of the fused forward's relation tables: a workgroup owns
 //    (question, 16-column slice, instruction), keeps U[2][relations the question uses][16] in LDS,
-//    walks the question's nodes exactly like the forward LDS walk but ADDS p * g_agg[n, cols] into the
-//    row of the fact's relation (ds_add_f32) instead of reading it; the epilogue applies the ReLU gate
-//    and reduces to g_ins (exclusive store) and g_T (global fp32 atomics over the questions).  U never
-//    reaches HBM.  Sums are in atomic order: gradients are reproducible to rounding, not bit for bit.
+//    walks the question's nodes exactly like the forward LDS walk (over (p_f, relation) pairs made once
+//    per call by k_bwd_pairs) but ADDS p * g_agg[n, cols] into the row of the fact's relation
+//    (ds_add_f32) instead of reading it; the epilogue applies the ReLU gate and reduces to g_ins
+//    (exclusive store) and to the question's own gradient rows V[d][compact row] (exclusive, summed
+//    over the instructions in place); k_bwd_reduce_tables then sums V over the questions that use a
+//    relation (global atomics across XCDs go to the memory side and were 10x slower).  U never reaches
+//    HBM.  LDS sums are in atomic order: gradients are reproducible to rounding, not bit for bit.
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include "gnnrag_common.h"
@@ -29,6 +32,7 @@ namespace gnnrag {
 
 constexpr int kBwdSliceW = 16;
 constexpr int kBwdThreads = 1024;
+constexpr int kBwdTeamDeg = 128;    // rows with more facts are bucketed by the whole workgroup
 
 enum { BWD_REASON = 0, BWD_TYPE = 1 };
 
@@ -54,7 +58,7 @@ struct BwdArgs {
   float* g_dist;            // [BN]
   float* g_ins;             // [B,I,D]
   float* g_T[2];            // [R1,D] (TYPE: only [0])
-  int32_t B, N, D, I, Rmax;
+  int32_t B, N, D, I, Rmax, Rtot;
 };
 
 // facts [j0, j1) of structure o = 1 - d, all with the same source: this lane's share (columns
@@ -132,22 +136,25 @@ __global__ __launch_bounds__(256) void k_bwd_prior(const BwdArgs a) {
   if (lane == 0) a.g_dist[s] = acc;
 }
 
-// rows above heavy_deg: one wave per 256-fact chunk, added atomically (after k_bwd_prior's store)
+// rows above heavy_deg: one workgroup per 256-fact chunk (64 facts per wave), added atomically
+// (after k_bwd_prior's store)
 __global__ __launch_bounds__(256) void k_bwd_prior_heavy(const BwdArgs a) {
   const int o = blockIdx.y, d = 1 - o;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int cnt = min(a.n_heavy[o], a.heavy_cap);
   const int nch = min(a.n_chunks[o], a.max_chunks);
   const int32_t* off = a.chunk_off[o];
-  for (int c = blockIdx.x * 4 + wave; c < nch; c += gridDim.x * 4) {
+  for (int c = blockIdx.x; c < nch; c += gridDim.x) {
     int lo = 0, hi = cnt;                       // largest e with off[e] <= c
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
       if (off[mid] <= c) lo = mid; else hi = mid;
     }
     const int s = a.heavy[o][lo];
-    const int beg = a.row_ptr[o][s] + (c - off[lo]) * kHeavyDeg;
-    const int end = min(beg + kHeavyDeg, a.row_ptr[o][s + 1]);
+    const int cbeg = a.row_ptr[o][s] + (c - off[lo]) * kHeavyDeg;
+    const int cend = min(cbeg + kHeavyDeg, a.row_ptr[o][s + 1]);
+    const int beg = min(cbeg + wave * (kHeavyDeg / 4), cend);
+    const int end = min(beg + kHeavyDeg / 4, cend);
     const float* q = a.ins + (size_t)(s / a.N) * a.I * a.D;
     const float acc = wave_sum(prior_grad_range(a, q, d, beg, end, lane));
     if (lane == 0) unsafeAtomicAdd(a.g_dist + s, acc);
@@ -169,117 +176,201 @@ __device__ __forceinline__ f32x4 load_cols(const float* __restrict__ row, int c0
   return v;
 }
 
-// facts first, first+stride, ... of row n in direction d: U[d][rel][cols] += p * gv
+// (p_f, compact relation) per fact and direction, p_f = w_f * dist[src_d(f)] (REASON) or v_f (TYPE):
+// computed once per backward call, so the bucketing loop below has no dependent gather in it
 template <int MODE>
-__device__ __forceinline__ void bucket_row(const BwdArgs& a, float* __restrict__ Ud, int d, int n, int first,
-                                           int stride, int sub, const f32x4& gv) {
-  const int beg = a.row_ptr[d][n], end = a.row_ptr[d][n + 1];
-  const int2* __restrict__ edge = a.edge_l[d];
-  const float* __restrict__ w = a.w[d];
-  for (int j = beg + first; j < end; j += stride) {
-    const int2 e = edge[j];
-    float p = w ? w[j] : 1.f;
-    if constexpr (MODE == BWD_REASON) p *= a.dist[e.x];
-    if (p != 0.f) {
-      float* u = Ud + (size_t)e.y * kBwdSliceW + 4 * sub;
+__global__ __launch_bounds__(256) void k_bwd_pairs(const BwdArgs a, int64_t F, int2* __restrict__ pr) {
+  const int d = blockIdx.y;
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= F) return;
+  const int2 e = a.edge_l[d][j];
+  float p = a.w[d] ? a.w[d][j] : 1.f;
+  if constexpr (MODE == BWD_REASON) p *= a.dist[e.x];
+  pr[(size_t)d * F + j] = make_int2(__float_as_int(p), e.y);
+}
+
+// facts first, first+stride, ... of the row [beg, end): U[rel][col] += p * gv, four facts per step.
+// One lane per column (16 lanes per fact): a wave's ds_add_f32 then covers 16 consecutive banks per fact
+// and 4 facts - with float4-per-lane ownership the 64 lanes of an instruction fell on 8 banks.
+__device__ __forceinline__ void bucket_row(const int2* __restrict__ pr, float* __restrict__ Ud, int beg, int end,
+                                           int first, int stride, int sub, float gv) {
+  for (int j = beg + first; j < end; j += 4 * stride) {
+    int2 e[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) unsafeAtomicAdd(u + k, p * gv[k]);
+    for (int u = 0; u < 4; ++u) {
+      const int jj = j + u * stride;
+      e[u] = jj < end ? pr[jj] : make_int2(0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float p = __int_as_float(e[u].x);
+      if (p != 0.f) unsafeAtomicAdd(Ud + (size_t)e[u].y * kBwdSliceW + sub, p * gv);
     }
   }
 }
 
 template <int MODE, bool V4>
-__global__ __launch_bounds__(kBwdThreads) void k_bwd_tables(const BwdArgs a, int nslice) {
+__global__ __launch_bounds__(kBwdThreads) void k_bwd_tables(const BwdArgs a, const int2* __restrict__ pr, int64_t F,
+                                                            float* __restrict__ V, int nslice) {
   constexpr int ND = (MODE == BWD_REASON) ? 2 : 1;     // TYPE: both directions read the same table
   extern __shared__ __attribute__((aligned(16))) float s_u[];   // U [ND][Rg][16], then red [16 waves][16]
   float* red = s_u + (size_t)ND * a.Rmax * kBwdSliceW;
   const int NI = (MODE == BWD_REASON) ? a.I : 1;
   // XCD-aware order: the workgroups of question g land on XCD g % 8 (they share its CSR rows in L2)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int per = nslice * NI;
-  const int g = (slot / per) * 8 + xcd;
+  const int g = (slot / nslice) * 8 + xcd;
   if (g >= a.B) return;
-  const int rem = slot % per;
-  const int c = rem % nslice, i = rem / nslice;
+  const int c = slot % nslice;
   const int col0 = c * kBwdSliceW;
   const int D = a.D, N = a.N;
   const int roff = a.rel_off[g], Rg = a.rel_off[g + 1] - roff;
   const int tid = threadIdx.x;
-  for (int x = tid; x < ND * Rg * kBwdSliceW; x += kBwdThreads) s_u[x] = 0.f;
-  __syncthreads();
-
   const int lane = tid & 63, wave = tid >> 6;
-  const int grp = lane >> 2, sub = lane & 3;
-  const int c0 = col0 + 4 * sub;
+  const int grp = lane >> 4, sub = lane & 15;          // 16 lanes per node: one lane per slice column
+  const int c0 = col0 + sub;
+  const bool cok = c0 < D;
   const size_t ld = (MODE == BWD_REASON) ? (size_t)2 * a.I * D : (size_t)D;
-  // nodes with many facts (listed at plan time): a whole wave per node, lane group k takes facts k, k+16, ...
   const int nbig = a.big_cnt[g];
-  for (int h = wave; h < nbig; h += 16) {
-    const int n = a.big_nodes[(size_t)g * N + h];
-    const float* grow = a.g + (size_t)n * ld;
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-      const f32x4 gv = load_cols<V4>(grow + (MODE == BWD_REASON ? (size_t)(2 * i + d) * D : 0), c0, D);
-      bucket_row<MODE>(a, s_u + (size_t)(ND == 2 ? d : 0) * Rg * kBwdSliceW, d, n, grp, 16, sub, gv);
-    }
-  }
-  // everything else: a 4-lane group per node
-  for (int nl = tid >> 2; nl < N; nl += kBwdThreads / 4) {
-    const int n = g * N + nl;
-    const int l0 = a.row_ptr[0][n + 1] - a.row_ptr[0][n], l1 = a.row_ptr[1][n + 1] - a.row_ptr[1][n];
-    if (max(l0, l1) > a.big_deg || (l0 | l1) == 0) continue;
-    const float* grow = a.g + (size_t)n * ld;
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-      const f32x4 gv = load_cols<V4>(grow + (MODE == BWD_REASON ? (size_t)(2 * i + d) * D : 0), c0, D);
-      bucket_row<MODE>(a, s_u + (size_t)(ND == 2 ? d : 0) * Rg * kBwdSliceW, d, n, 0, 1, sub, gv);
-    }
-  }
-  __syncthreads();
-
-  // epilogue: thread t owns float4 granule k = t & 3 of the slice for the rows t/4, t/4 + 256, ...
+  // epilogue ownership: thread t holds float4 granule k = t & 3 of the slice for rows t/4, t/4 + 256, ...
   const int k = tid & 3;
   const int ce = col0 + 4 * k;
-  if constexpr (MODE == BWD_TYPE) {
-    for (int idx = tid; idx < Rg * 4; idx += kBwdThreads) {
-      const int r = idx >> 2;
-      const int rg = a.rel_rows[roff + r].y;
-      const float* u = s_u + (size_t)r * kBwdSliceW + 4 * k;
+  const size_t vdir = (size_t)a.Rtot * D;              // V [ND][Rtot][D]: per-question gradient rows
+
+  for (int i = 0; i < NI; ++i) {
+    for (int x = tid; x < ND * Rg * kBwdSliceW; x += kBwdThreads) s_u[x] = 0.f;
+    __syncthreads();
+    // nodes with many facts (listed at plan time).  Hubs (> kBwdTeamDeg facts in a direction): the whole
+    // workgroup per node, its 64 lane groups take facts k, k+64, ... (adds commute: no reduction step);
+    // the others: one wave per node, lane group k takes facts k, k+4, ...
+    for (int h = 0; h < nbig; ++h) {
+      const int n = a.big_nodes[(size_t)g * N + h];
+      const int b0 = a.row_ptr[0][n], e0 = a.row_ptr[0][n + 1], b1 = a.row_ptr[1][n], e1 = a.row_ptr[1][n + 1];
+      if (max(e0 - b0, e1 - b1) <= kBwdTeamDeg) continue;          // workgroup-uniform
+      const float* grow = a.g + (size_t)n * ld + c0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (ce + e < D && u[e] != 0.f) unsafeAtomicAdd(a.g_T[0] + (size_t)rg * D + ce + e, u[e]);
-    }
-  } else {
-    const f32x4 q = load_cols<V4>(a.ins + ((size_t)g * a.I + i) * D, ce, D);
-    f32x4 gq = {0.f, 0.f, 0.f, 0.f};
-    for (int idx = tid; idx < 2 * Rg * 4; idx += kBwdThreads) {
-      const int d = idx >= Rg * 4;
-      const int r = (idx - d * Rg * 4) >> 2;
-      const int rg = a.rel_rows[roff + r].y;
-      const float* u = s_u + ((size_t)d * Rg + r) * kBwdSliceW + 4 * k;
-      const f32x4 t = load_cols<V4>(a.T[d] + (size_t)rg * D, ce, D);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (t[e] * q[e] > 0.f && u[e] != 0.f) {        // the ReLU gate of relu(T_d[r] * ins[b,i])
-          gq[e] += u[e] * t[e];
-          unsafeAtomicAdd(a.g_T[d] + (size_t)rg * D + ce + e, u[e] * q[e]);
-        }
+      for (int d = 0; d < 2; ++d) {
+        const float gv = cok ? grow[MODE == BWD_REASON ? (size_t)(2 * i + d) * D : 0] : 0.f;
+        bucket_row(pr + (size_t)d * F, s_u + (size_t)(ND == 2 ? d : 0) * Rg * kBwdSliceW, d ? b1 : b0,
+                   d ? e1 : e0, tid >> 4, kBwdThreads / 16, sub, gv);
       }
     }
-    // g_ins[g,i,slice]: sum gq over the threads that own the same granule
+    for (int h = wave; h < nbig; h += 16) {
+      const int n = a.big_nodes[(size_t)g * N + h];
+      const int b0 = a.row_ptr[0][n], e0 = a.row_ptr[0][n + 1], b1 = a.row_ptr[1][n], e1 = a.row_ptr[1][n + 1];
+      if (max(e0 - b0, e1 - b1) > kBwdTeamDeg) continue;
+      const float* grow = a.g + (size_t)n * ld + c0;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-#pragma unroll
-      for (int o = 4; o < 64; o <<= 1) gq[e] += __shfl_xor(gq[e], o, 64);
+      for (int d = 0; d < 2; ++d) {
+        const float gv = cok ? grow[MODE == BWD_REASON ? (size_t)(2 * i + d) * D : 0] : 0.f;
+        bucket_row(pr + (size_t)d * F, s_u + (size_t)(ND == 2 ? d : 0) * Rg * kBwdSliceW, d ? b1 : b0,
+                   d ? e1 : e0, grp, 4, sub, gv);
+      }
     }
-    if (lane < 4) *reinterpret_cast<f32x4*>(red + wave * 16 + 4 * lane) = gq;   // lane = k here
+    // everything else: a 16-lane group per node
+    for (int nl = tid >> 4; nl < N; nl += kBwdThreads / 16) {
+      const int n = g * N + nl;
+      const int b0 = a.row_ptr[0][n], e0 = a.row_ptr[0][n + 1], b1 = a.row_ptr[1][n], e1 = a.row_ptr[1][n + 1];
+      const int l0 = e0 - b0, l1 = e1 - b1;
+      if (max(l0, l1) > a.big_deg || (l0 | l1) == 0) continue;
+      const float* grow = a.g + (size_t)n * ld + c0;
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const float gv = cok ? grow[MODE == BWD_REASON ? (size_t)(2 * i + d) * D : 0] : 0.f;
+        bucket_row(pr + (size_t)d * F, s_u + (size_t)(ND == 2 ? d : 0) * Rg * kBwdSliceW, d ? b1 : b0,
+                   d ? e1 : e0, 0, 1, sub, gv);
+      }
+    }
     __syncthreads();
-    if (tid < 16) {
-      float t = 0.f;
+
+    // epilogue of instruction i.  The rows of V this workgroup owns (question g, its slice) are touched by
+    // nobody else and by the same thread for every i: plain read-modify-write, no atomics.
+    if constexpr (MODE == BWD_TYPE) {
+      for (int idx = tid; idx < Rg * 4; idx += kBwdThreads) {
+        const int r = idx >> 2;
+        const float* u = s_u + (size_t)r * kBwdSliceW + 4 * k;
+        float* v = V + (size_t)(roff + r) * D + ce;
 #pragma unroll
-      for (int w = 0; w < 16; ++w) t += red[w * 16 + tid];
-      if (col0 + tid < D) a.g_ins[((size_t)g * a.I + i) * D + col0 + tid] = t;
+        for (int e = 0; e < 4; ++e)
+          if (ce + e < D) v[e] = u[e];
+      }
+    } else {
+      const f32x4 q = load_cols<V4>(a.ins + ((size_t)g * a.I + i) * D, ce, D);
+      f32x4 gq = {0.f, 0.f, 0.f, 0.f};
+      for (int idx = tid; idx < 2 * Rg * 4; idx += kBwdThreads) {
+        const int d = idx >= Rg * 4;
+        const int r = (idx - d * Rg * 4) >> 2;
+        const int rg = a.rel_rows[roff + r].y;
+        const float* u = s_u + ((size_t)d * Rg + r) * kBwdSliceW + 4 * k;
+        const f32x4 t = load_cols<V4>(a.T[d] + (size_t)rg * D, ce, D);
+        float* v = V + (size_t)d * vdir + (size_t)(roff + r) * D + ce;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float add = 0.f;
+          if (t[e] * q[e] > 0.f) {                       // the ReLU gate of relu(T_d[r] * ins[b,i])
+            gq[e] += u[e] * t[e];
+            add = u[e] * q[e];
+          }
+          if (ce + e < D) v[e] = (i == 0) ? add : v[e] + add;
+        }
+      }
+      // g_ins[g,i,slice]: sum gq over the threads that own the same granule
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) gq[e] += __shfl_xor(gq[e], o, 64);
+      }
+      if (lane < 4) *reinterpret_cast<f32x4*>(red + wave * 16 + 4 * lane) = gq;   // lane = k here
+      __syncthreads();
+      if (tid < 16) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w * 16 + tid];
+        if (col0 + tid < D) a.g_ins[((size_t)g * a.I + i) * D + col0 + tid] = t;
+      }
     }
+    __syncthreads();                                   // U and red are reused by the next instruction
+  }
+}
+
+// g_T_d[r,:] = sum over the questions that use relation r of their row of V: one workgroup per
+// (relation, direction); the rows are found by binary search in each question's sorted relation list.
+// Fixed order over questions: deterministic given V.
+__global__ __launch_bounds__(256) void k_bwd_reduce_tables(const BwdArgs a, const float* __restrict__ V, int nd) {
+  __shared__ int rows[256];
+  const int r = blockIdx.x, d = blockIdx.y;
+  const int D = a.D;
+  const float* Vd = V + (size_t)d * a.Rtot * D;
+  float* out = a.g_T[d] + (size_t)r * D;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};                // columns tid, tid + 256, ... (D <= 1024)
+  for (int b0 = 0; b0 < a.B; b0 += 256) {
+    const int b = b0 + (int)threadIdx.x;
+    int row = -1;
+    if (b < a.B) {
+      int lo = a.rel_off[b], hi = a.rel_off[b + 1];   // first row with relation >= r
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a.rel_rows[mid].y < r) lo = mid + 1; else hi = mid;
+      }
+      if (lo < a.rel_off[b + 1] && a.rel_rows[lo].y == r) row = lo;
+    }
+    rows[threadIdx.x] = row;
+    __syncthreads();
+    const int nb = min(256, a.B - b0);
+    for (int j = 0; j < nb; ++j) {
+      const int rw = rows[j];
+      if (rw < 0) continue;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int c = (int)threadIdx.x + 256 * m;
+        if (c < D) acc[m] += Vd[(size_t)rw * D + c];
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int c = (int)threadIdx.x + 256 * m;
+    if (c < D) out[c] = acc[m];
   }
 }
 
@@ -311,16 +402,34 @@ static void fill_bwd(BwdArgs& a, const gnnrag_csr* csr, int D, int I) {
   a.D = D;
   a.I = I;
   a.Rmax = csr->rel_max;
+  a.Rtot = csr->rel_total;
+}
+
+static size_t bwd_pairs_bytes(const gnnrag_csr* csr) {
+  return align_up((size_t)2 * (size_t)(csr->F > 0 ? csr->F : 1) * sizeof(int2), 256);
+}
+// (p, relation) pairs of both directions + V [2][rel_total][D]
+static size_t bwd_ws_bytes(const gnnrag_csr* csr, int D) {
+  return bwd_pairs_bytes(csr) +
+         align_up((size_t)2 * (size_t)(csr->rel_total > 0 ? csr->rel_total : 1) * D * sizeof(float), 256);
 }
 
 template <int MODE>
-static int launch_tables(const BwdArgs& a, const gnnrag_csr* csr, hipStream_t stream) {
+static int launch_tables(const BwdArgs& a, const gnnrag_csr* csr, void* ws, size_t ws_bytes, hipStream_t stream) {
   const int nd = MODE == BWD_REASON ? 2 : 1;
+  if (!ws || ws_bytes < bwd_ws_bytes(csr, a.D)) return GNNRAG_E_WORKSPACE;
+  if (a.D > 1024) return GNNRAG_E_UNSUPPORTED;
+  int2* pr = (int2*)ws;
+  float* V = (float*)((char*)ws + bwd_pairs_bytes(csr));
+  const int64_t F = csr->F;
+  if (F > 0) {
+    hipLaunchKernelGGL(k_bwd_pairs<MODE>, dim3((unsigned)((F + 255) / 256), 2), dim3(256), 0, stream, a, F, pr);
+    GNNRAG_LAUNCH_CHECK();
+  }
   const size_t lds = bwd_lds_bytes(nd, csr->rel_max);
   if (lds > 160 * 1024 - 1024) return GNNRAG_E_UNSUPPORTED;   // a question uses too many relations for one CU's LDS
   const int nslice = (a.D + kBwdSliceW - 1) / kBwdSliceW;
-  const int ni = MODE == BWD_REASON ? a.I : 1;
-  const int nblk = 8 * ((csr->B + 7) / 8) * nslice * ni;
+  const int nblk = 8 * ((csr->B + 7) / 8) * nslice;
   const bool v4 = a.D % 4 == 0;
   static bool attr_set = false;
   if (!attr_set) {
@@ -330,8 +439,12 @@ static int launch_tables(const BwdArgs& a, const gnnrag_csr* csr, hipStream_t st
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  if (v4) hipLaunchKernelGGL((k_bwd_tables<MODE, true>), dim3(nblk), dim3(kBwdThreads), lds, stream, a, nslice);
-  else hipLaunchKernelGGL((k_bwd_tables<MODE, false>), dim3(nblk), dim3(kBwdThreads), lds, stream, a, nslice);
+  if (v4) hipLaunchKernelGGL((k_bwd_tables<MODE, true>), dim3(nblk), dim3(kBwdThreads), lds, stream, a,
+                             (const int2*)pr, F, V, nslice);
+  else hipLaunchKernelGGL((k_bwd_tables<MODE, false>), dim3(nblk), dim3(kBwdThreads), lds, stream, a,
+                          (const int2*)pr, F, V, nslice);
+  GNNRAG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bwd_reduce_tables, dim3(csr->R1, nd), dim3(256), 0, stream, a, (const float*)V, nd);
   GNNRAG_LAUNCH_CHECK();
   return 0;
 }
@@ -343,15 +456,13 @@ using namespace gnnrag;
 extern "C" int gnnrag_aggregate_backward(const gnnrag_csr* csr, const float* dist, const float* ins,
                                          const float* T_fwd, const float* T_inv, const float* g_agg,
                                          float* g_dist, float* g_ins, float* g_T_fwd, float* g_T_inv,
-                                         int32_t D, int32_t I, gnnrag_stream_t stream_) {
+                                         int32_t D, int32_t I, void* workspace, size_t workspace_bytes,
+                                         gnnrag_stream_t stream_) {
   if (!csr || !dist || !ins || !T_fwd || !T_inv || !g_agg || !g_dist || !g_ins || !g_T_fwd || !g_T_inv ||
       D <= 0 || I <= 0 || csr->rel_total < 0)
     return GNNRAG_E_BADARG;
   hipStream_t stream = (hipStream_t)stream_;
   if (bwd_lds_bytes(2, csr->rel_max) > 160 * 1024 - 1024) return GNNRAG_E_UNSUPPORTED;
-  const size_t tbytes = (size_t)csr->R1 * D * sizeof(float);
-  GNNRAG_HIP(hipMemsetAsync(g_T_fwd, 0, tbytes, stream));
-  GNNRAG_HIP(hipMemsetAsync(g_T_inv, 0, tbytes, stream));
   BwdArgs a;
   fill_bwd(a, csr, D, I);
   a.w[0] = csr->w_gnn[0];
@@ -368,25 +479,29 @@ extern "C" int gnnrag_aggregate_backward(const gnnrag_csr* csr, const float* dis
   hipLaunchKernelGGL(k_bwd_prior, dim3((csr->N + 3) / 4, csr->B), dim3(256), (size_t)I * D * sizeof(float), stream, a);
   GNNRAG_LAUNCH_CHECK();
   if (csr->F > 0) {
-    const int nb = csr->max_chunks < 4096 ? (csr->max_chunks + 3) / 4 : 1024;
+    const int nb = csr->max_chunks < 4096 ? csr->max_chunks : 4096;
     hipLaunchKernelGGL(k_bwd_prior_heavy, dim3(nb > 0 ? nb : 1, 2), dim3(256), 0, stream, a);
     GNNRAG_LAUNCH_CHECK();
   }
-  return launch_tables<BWD_REASON>(a, csr, stream);
+  return launch_tables<BWD_REASON>(a, csr, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t gnnrag_backward_workspace_bytes(const gnnrag_csr* csr, int32_t D) {
+  return (csr && D > 0) ? bwd_ws_bytes(csr, D) : 0;
 }
 
 extern "C" int gnnrag_typelayer_backward(const gnnrag_csr* csr, const float* g_pre, int use_w_rel, float* g_T,
-                                         int32_t D, gnnrag_stream_t stream_) {
+                                         int32_t D, void* workspace, size_t workspace_bytes,
+                                         gnnrag_stream_t stream_) {
   if (!csr || !g_pre || !g_T || D <= 0 || csr->rel_total < 0) return GNNRAG_E_BADARG;
   if (use_w_rel && (!csr->w_rel[0] || !csr->w_rel[1])) return GNNRAG_E_BADARG;
   hipStream_t stream = (hipStream_t)stream_;
   if (bwd_lds_bytes(1, csr->rel_max) > 160 * 1024 - 1024) return GNNRAG_E_UNSUPPORTED;
-  GNNRAG_HIP(hipMemsetAsync(g_T, 0, (size_t)csr->R1 * D * sizeof(float), stream));
   BwdArgs a;
   fill_bwd(a, csr, D, 1);
   a.w[0] = use_w_rel ? csr->w_rel[0] : nullptr;
   a.w[1] = use_w_rel ? csr->w_rel[1] : nullptr;
   a.g = g_pre;
   a.g_T[0] = g_T;
-  return launch_tables<BWD_TYPE>(a, csr, stream);
+  return launch_tables<BWD_TYPE>(a, csr, workspace, workspace_bytes, stream);
 }

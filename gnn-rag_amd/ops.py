@@ -88,6 +88,13 @@ class CsrPlan:
             self._w[key] = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
         return self._w[key]
 
+    def backward_workspace(self, D: int) -> torch.Tensor:
+        """Scratch of the backward kernels ((p, relation) pairs + per-question table gradients), cached."""
+        if ("bws", D) not in self._w:
+            nbytes = _lib.load().gnnrag_backward_workspace_bytes(C.byref(self.c), D)
+            self._w[("bws", D)] = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+        return self._w[("bws", D)]
+
     # -- lazily attached per-fact weights ----------------------------------------------------
     def _attach(self, key: str, w_per_fact, square: bool):
         if key in self._w:
@@ -315,11 +322,12 @@ def aggregate_backward(plan: CsrPlan, dist, ins, T_fwd, T_inv, g_agg):
     g_ins = torch.empty_like(ins)
     g_Tf = torch.empty_like(T_fwd)
     g_Ti = torch.empty_like(T_inv)
+    ws = plan.backward_workspace(D)
     with torch.cuda.device(dist.device):
         _lib.check(lib.gnnrag_aggregate_backward(
             C.byref(plan.c), dist.data_ptr(), ins.data_ptr(), T_fwd.data_ptr(), T_inv.data_ptr(), g_agg.data_ptr(),
-            g_dist.data_ptr(), g_ins.data_ptr(), g_Tf.data_ptr(), g_Ti.data_ptr(), D, I, _stream()),
-            "gnnrag_aggregate_backward")
+            g_dist.data_ptr(), g_ins.data_ptr(), g_Tf.data_ptr(), g_Ti.data_ptr(), D, I, ws.data_ptr(), ws.numel(),
+            _stream()), "gnnrag_aggregate_backward")
     return g_dist, g_ins, g_Tf, g_Ti
 
 
@@ -331,9 +339,11 @@ def typelayer_backward(plan: CsrPlan, g_pre: torch.Tensor, use_w_rel: bool) -> t
     if g_pre.shape[0] != plan.B * plan.N:
         raise ValueError("g_pre has %d rows, the plan %d nodes" % (g_pre.shape[0], plan.B * plan.N))
     g_T = torch.empty((plan.R1, D), dtype=torch.float32, device=g_pre.device)
+    ws = plan.backward_workspace(D)
     with torch.cuda.device(g_pre.device):
         _lib.check(lib.gnnrag_typelayer_backward(C.byref(plan.c), g_pre.data_ptr(), int(use_w_rel), g_T.data_ptr(),
-                                                 D, _stream()), "gnnrag_typelayer_backward")
+                                                 D, ws.data_ptr(), ws.numel(), _stream()),
+                   "gnnrag_typelayer_backward")
     return g_T
 
 

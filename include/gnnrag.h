@@ -169,18 +169,21 @@ int gnnrag_typelayer(const gnnrag_csr* csr, const float* T, int use_w_rel, float
  * (train_model.py:209-233) runs on the HIP operator.  g_agg [BN,2I*D] is the gradient of agg;
  *   g_dist [BN], g_ins [B,I,D], g_T_fwd / g_T_inv [R1,D]  are fully written (not accumulated into).
  * Sums use hardware fp32 atomics: reproducible to rounding, not bit for bit.
- * GNNRAG_E_UNSUPPORTED when one question uses more relations than one CU's LDS holds (~1200). */
+ * GNNRAG_E_UNSUPPORTED when one question uses more relations than one CU's LDS holds (~1200).
+ * workspace: gnnrag_backward_workspace_bytes(csr, D) bytes of device scratch.  D <= 1024. */
+size_t gnnrag_backward_workspace_bytes(const gnnrag_csr* csr, int32_t D);
 int gnnrag_aggregate_backward(const gnnrag_csr* csr, const float* dist, const float* ins,
                               const float* T_fwd, const float* T_inv, const float* g_agg,
                               float* g_dist, float* g_ins, float* g_T_fwd, float* g_T_inv,
-                              int32_t D, int32_t I, gnnrag_stream_t stream);
+                              int32_t D, int32_t I, void* workspace, size_t workspace_bytes,
+                              gnnrag_stream_t stream);
 
 /* Backward of gnnrag_typelayer with respect to T (layer_init.py:47-57):
  *   g_T[r,:] = sum_{f: rel_f=r} v_f (g_pre[tail_f,:] + g_pre[head_f,:]),
  * g_pre [BN,D] = gradient of the pre-activation (= g_h0 where h0 > 0, else 0).  g_T [R1,D] is fully
  * written. */
 int gnnrag_typelayer_backward(const gnnrag_csr* csr, const float* g_pre, int use_w_rel, float* g_T,
-                              int32_t D, gnnrag_stream_t stream);
+                              int32_t D, void* workspace, size_t workspace_bytes, gnnrag_stream_t stream);
 
 /* Per-question relation tables of the fused path, one row per (question b, relation r used by b):
  *   P[d,row(b,r),:] = sum_i W_e2e[:, (1+2i+d)D : (2+2i+d)D] . relu(T_d[r,:] * ins[b,i,:])   [2,rel_total,D]
