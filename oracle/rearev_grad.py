@@ -48,9 +48,10 @@ def aggregate(edge_tuple, B, N, dist, ins, T_fwd, T_inv, weight=None):
 
 def aggregate_grads(edge_tuple, B, N, dist, ins, T_fwd, T_inv, g_agg, weight=None):
     """numpy in, numpy out: (agg, g_dist [B*N], g_ins, g_T_fwd, g_T_inv) for the cotangent g_agg."""
-    t = [torch.tensor(np.asarray(x, np.float64), requires_grad=True) for x in (dist, ins, T_fwd, T_inv)]
-    agg = aggregate(edge_tuple, B, N, t[0].reshape(B, N), t[1], t[2], t[3], weight)
-    agg.backward(torch.as_tensor(np.asarray(g_agg, np.float64)).reshape(agg.shape))
+    with torch.enable_grad():            # callable from inside another backward pass (grad mode is off there)
+        t = [torch.tensor(np.asarray(x, np.float64), requires_grad=True) for x in (dist, ins, T_fwd, T_inv)]
+        agg = aggregate(edge_tuple, B, N, t[0].reshape(B, N), t[1], t[2], t[3], weight)
+        agg.backward(torch.as_tensor(np.asarray(g_agg, np.float64)).reshape(agg.shape))
     return (agg.detach().numpy(), t[0].grad.reshape(-1).numpy(), t[1].grad.numpy(), t[2].grad.numpy(),
             t[3].grad.numpy())
 
@@ -65,8 +66,9 @@ def typelayer_pre(edge_tuple, B, N, T, weight_rel=None):
 
 
 def typelayer_grad(edge_tuple, B, N, T, g_pre, weight_rel=None):
-    t = torch.tensor(np.asarray(T, np.float64), requires_grad=True)
-    typelayer_pre(edge_tuple, B, N, t, weight_rel).backward(torch.as_tensor(np.asarray(g_pre, np.float64)))
+    with torch.enable_grad():
+        t = torch.tensor(np.asarray(T, np.float64), requires_grad=True)
+        typelayer_pre(edge_tuple, B, N, t, weight_rel).backward(torch.as_tensor(np.asarray(g_pre, np.float64)))
     return t.grad.numpy()
 
 
