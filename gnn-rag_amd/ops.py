@@ -61,8 +61,13 @@ class CsrPlan:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.GnnragError("CsrPlan needs a GPU device, got %s" % self.device)
-        hrt = np.empty((3, max(F, 1)), dtype=np.int32)
-        hrt[0, :F], hrt[1, :F], hrt[2, :F] = heads, rels, tails
+        base = heads.base
+        if (F and base is not None and heads.dtype == np.int32 and base is rels.base and base is tails.base
+                and base.shape == (3, F) and base.flags.c_contiguous and heads.ctypes.data == base.ctypes.data):
+            hrt = base                  # the batch builder's own [3,F] int32 block (data/fact_mat.py): no copy
+        else:
+            hrt = np.empty((3, max(F, 1)), dtype=np.int32)
+            hrt[0, :F], hrt[1, :F], hrt[2, :F] = heads, rels, tails
         with torch.cuda.device(self.device):
             self._hrt = torch.from_numpy(hrt).to(self.device, non_blocking=False)   # ONE int32 upload
             nbytes = lib.gnnrag_csr_bytes(F, B, N, R1, 0, 0)

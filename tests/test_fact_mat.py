@@ -67,6 +67,61 @@ def test_patched_loader_feeds_get_batch(loaders):
     np.testing.assert_array_equal(a[0], b[0])
 
 
+def test_cached_batches_hold_the_reference_facts_and_weights(loaders):
+    """fact_dropout = 0 through the per-question cache: the same facts with the same two weights as the
+    reference's tuple (which differs only by its random permutation inside each question), and the
+    reference's own layer gives the same answer distribution on either tuple."""
+    import copy
+    import torch
+    from gnnrag_amd.data.fact_mat import patch_loader
+    ref_loader = loaders["test"]
+    fast = patch_loader(copy.copy(ref_loader), cache=True)
+    for ld in (ref_loader, fast):
+        ld.reset_batches(is_sequential=True)
+    np.random.seed(5)
+    state = np.random.get_state()[1].copy()
+    b = fast.get_batch(1, 8, fact_dropout=0.0, test=True)
+    assert (np.random.get_state()[1] == state).all()                # the cached path leaves the RNG alone
+    a = ref_loader.get_batch(1, 8, fact_dropout=0.0, test=True)
+    ta, tb = a[2], b[2]
+
+    def canon(t):
+        rows = np.stack([np.asarray(t[0], np.int64), np.asarray(t[1], np.int64), np.asarray(t[2], np.int64),
+                         np.asarray(t[3], np.int64)], 1)
+        order = np.lexsort(rows.T[::-1])
+        return rows[order], np.asarray(t[5], np.float64)[order], np.asarray(t[6], np.float64)[order]
+
+    for x, y in zip(canon(ta), canon(tb)):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(tb[4], np.arange(len(tb[0])))
+    # second call is served from the cache and is identical
+    b2 = fast.get_batch(1, 8, fact_dropout=0.0, test=True)
+    for x, y in zip(b[2], b2[2]):
+        np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+    # the reference layer on both tuples
+    from modules.kg_reasoning.reasongnn import ReasonGNNLayer
+    from modules.layer_init import TypeLayer
+    Bq, N = a[0].shape
+    D, R1 = 16, ref_loader.num_kb_relation + 1
+    torch.manual_seed(0)
+    largs = dict(use_cuda=False, normalized_gnn=True, num_ins=2, num_gnn=2, pos_emb=False, linear_dropout=0.0)
+    layer = ReasonGNNLayer(largs, 10 ** 6, ref_loader.num_kb_relation, D, "bfs").eval()
+    tl = TypeLayer(D, D, torch.nn.Dropout(0.0), torch.device("cpu"), True).eval()
+    rf, rfi, ins = torch.randn(R1, D), torch.randn(R1, D), torch.randn(Bq, 2, D)
+    outs = []
+    with torch.no_grad():
+        for t in (ta, tb):
+            le = torch.from_numpy(a[0])
+            h0 = tl(local_entity=le, edge_list=t, rel_features=rf)
+            layer.init_reason(local_entity=le, kb_adj_mat=t, local_entity_emb=h0, rel_features=rf,
+                              rel_features_inv=rfi, query_entities=torch.from_numpy(a[1]).float())
+            d = torch.from_numpy(a[4]).float()
+            for j in range(2):
+                d, _ = layer(d, ins, step=j)
+            outs.append(d.numpy())
+    np.testing.assert_allclose(outs[0], outs[1], rtol=0, atol=1e-6)
+
+
 def test_scales_linearly_where_the_reference_is_quadratic():
     """C2-shaped synthetic loader stub (64 questions x 10k edges): the vectorised builder takes well
     under a second; (the reference takes > 1 s on its np.append / Counter path at this size)."""
@@ -82,3 +137,11 @@ def test_scales_linearly_where_the_reference_is_quadratic():
     out = build_fact_mat(ld, np.arange(Bq), 0.0)
     dt = time.perf_counter() - t0
     assert len(out[0]) == Bq * (E + N) and dt < 5.0, dt      # generous: shared CI cores
+    from gnnrag_amd.data.fact_mat import FactCache
+    fc = FactCache(ld)
+    fc.batch(np.arange(Bq))                                  # fills the cache
+    t0 = time.perf_counter()
+    got = fc.batch(np.arange(Bq))
+    dtc = time.perf_counter() - t0
+    assert len(got[0]) == Bq * (E + N) and dtc < dt, (dtc, dt)
+    print("vectorised %.3f s, cached %.4f s" % (dt, dtc))
