@@ -412,6 +412,22 @@ def reason_layer(plan: CsrPlan, h, dist, ins, relfeat, relfeat_inv, W_rel, b_rel
     return h_out, score, dist_out
 
 
+def topp_candidates(pred_dist: torch.Tensor, eligible: torch.Tensor, ignore_prob: float, eps: float):
+    """Per question: slots kept by the Evaluator's filter, sorted by probability (descending, stable), and
+    how many of them the top-p cut retrieves.  Returns (slots int32 [B,N] (-1 padded), counts int32 [B,2])."""
+    lib = _lib.load()
+    pred_dist = _chk(pred_dist, "pred_dist")
+    B, N = pred_dist.shape
+    eligible = _chk(eligible, "eligible", dtype=torch.uint8, shape=(B, N))
+    slots = torch.empty((B, N), dtype=torch.int32, device=pred_dist.device)
+    cnt = torch.empty((B, 2), dtype=torch.int32, device=pred_dist.device)
+    with torch.cuda.device(pred_dist.device):
+        _lib.check(lib.gnnrag_topp_candidates(pred_dist.data_ptr(), eligible.data_ptr(), B, N, float(ignore_prob),
+                                              float(eps), slots.data_ptr(), cnt.data_ptr(), _stream()),
+                   "gnnrag_topp_candidates")
+    return slots, cnt
+
+
 MATH_FP32, MATH_BF16X3 = 0, 1
 
 

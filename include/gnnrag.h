@@ -222,6 +222,16 @@ int gnnrag_reason_layer(const gnnrag_csr* csr,
                         void* workspace, size_t workspace_bytes,
                         int32_t D, int32_t I, int32_t path, gnnrag_stream_t stream);
 
+/* Candidate selection of Evaluator.evaluate (evaluate.py:188-207) + the sort and top-p cut of
+ * f1_and_hits (evaluate.py:34-51), one workgroup per question:
+ *   keep slot j iff eligible[b,j] (host: query_entities != 1 and local_entity != pad id) and
+ *   (double)pred_dist[b,j] >= ignore_prob;  order: probability descending, ties by ascending slot;
+ *   out_slot [B,N]: the kept slots in that order, then -1;  out_cnt [B,2]: (kept, retrieved) where
+ *   retrieved = shortest prefix whose running fp64 sum exceeds eps (or all kept).  N <= 16384. */
+int gnnrag_topp_candidates(const float* pred_dist, const uint8_t* eligible, int32_t B, int32_t N,
+                           double ignore_prob, double eps, int32_t* out_slot, int32_t* out_cnt,
+                           gnnrag_stream_t stream);
+
 /* Plain HBM copy kernel (float4 per lane) used by bench.py to measure the achievable
  * streaming ceiling next to the 8 TB/s spec.  n = number of floats (multiple of 4). */
 int gnnrag_stream_copy(const float* src, float* dst, int64_t n, gnnrag_stream_t stream);

@@ -107,6 +107,11 @@ def _patch_backend(monkeypatch):
 
 @pytest.fixture(scope="module")
 def reference_setup():
+    return build_reference_setup()
+
+
+def build_reference_setup():
+    """(args, dataset, model): the reference's ReaRev on a synthetic on-disk dataset (CPU)."""
     sys.path.insert(0, REF)
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
     import make_golden                      # dataset writer only

@@ -1,0 +1,92 @@
+"""Evaluator tail: the top-p candidate kernel against the plain-Python
+restatement (GPU, bit-exact), and the patched ``Evaluator.evaluate`` against the live reference's
+(build container only; natives replaced by the restatement there)."""
+import copy
+import filecmp
+import os
+
+import numpy as np
+import pytest
+import torch
+
+REF = "/root/reference/gnn"
+
+
+def _random_case(rng, B, N, quantise):
+    logits = rng.standard_normal((B, N)) * 3
+    p = np.exp(logits - logits.max(1, keepdims=True))
+    p = (p / p.sum(1, keepdims=True)).astype(np.float32)
+    if quantise:                                   # many exact ties: the stable order matters
+        p = (np.round(p * 64) / 64).astype(np.float32)
+    seeds = (rng.random((B, N)) < 0.05).astype(np.float64)
+    pad = 10 ** 6
+    cands = rng.integers(0, 1000, size=(B, N))
+    cands[rng.random((B, N)) < 0.2] = pad
+    if B > 2:
+        seeds[1] = 1.0                             # a question with nothing eligible
+        p[2] = 0.0                                 # a question whose probabilities are all below the threshold
+    return p, cands, seeds, pad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [1, 5, 37, 1000, 2000, 2048, 2500])
+@pytest.mark.parametrize("quantise", [False, True])
+def test_topp_kernel_bit_exact_vs_python(N, quantise):
+    import gnnrag_amd  # noqa: F401
+    import oracle.eval_tail as oe
+    from gnnrag_amd import eval_tail, ops
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(N + int(quantise))
+    B = 7
+    p, cands, seeds, pad = _random_case(rng, B, N, quantise)
+    for eps in (0.95, 0.5, 1.5):
+        ignore = (1 - min(eps, 0.99)) / N
+        elig = (seeds.astype(np.int64) != 1) & (cands != pad)
+        slots, cnt = ops.topp_candidates(torch.from_numpy(p).to(dev), torch.from_numpy(elig.astype(np.uint8)).to(dev),
+                                         ignore, eps)
+        slots, cnt = slots.cpu().numpy(), cnt.cpu().numpy()
+        picked = eval_tail.retrieved_candidates(torch.from_numpy(p).to(dev), cands, seeds, pad, ignore, eps)
+        for b in range(B):
+            kept, cut = oe.select(p[b].tolist(), cands[b].tolist(), seeds[b].tolist(), pad, ignore, eps)
+            assert cnt[b, 0] == len(kept) and cnt[b, 1] == cut
+            assert slots[b, :len(kept)].tolist() == kept and (slots[b, len(kept):] == -1).all()
+            want = [(int(cands[b, j]), float(p[b, j])) for j in kept[:cut]]
+            assert picked[b] == (want, len(kept))
+
+
+def test_patched_evaluator_matches_reference(monkeypatch, tmp_path):
+    if not os.path.isdir(REF):
+        pytest.skip("live reference not available")
+    import test_dropin_with_reference as td
+    args, dataset, model = td.build_reference_setup()
+    import oracle.eval_tail as oe
+    from evaluate import Evaluator
+    from gnnrag_amd import eval_tail, ops
+
+    def fake_topp(pred_dist, eligible, ignore_prob, eps):
+        B, N = pred_dist.shape
+        slots = np.full((B, N), -1, np.int32)
+        cnt = np.zeros((B, 2), np.int32)
+        for b in range(B):
+            el = eligible[b].numpy().astype(bool)
+            kept, cut = oe.select(pred_dist[b].tolist(), np.where(el, 0, 1).tolist(), [0] * N, 1, ignore_prob, eps)
+            slots[b, :len(kept)] = kept
+            cnt[b] = (len(kept), cut)
+        return torch.from_numpy(slots), torch.from_numpy(cnt)
+
+    monkeypatch.setattr(ops, "topp_candidates", fake_topp)
+    outs = []
+    for tag, patch in (("ref", False), ("fast", True)):
+        ev_args = dict(args)
+        ev_args["checkpoint_dir"] = str(tmp_path) + "/"
+        ev_args["experiment_name"] = tag
+        ev = Evaluator(args=ev_args, model=copy.deepcopy(model), entity2id=dataset["entity2id"],
+                       relation2id=dataset["relation2id"], device=torch.device("cpu"))
+        if patch:
+            eval_tail.patch_evaluator(ev)
+        np.random.seed(5)
+        outs.append(ev.evaluate(dataset["test"], 4, write_info=True))
+    assert tuple(outs[0]) == tuple(outs[1])
+    assert filecmp.cmp(os.path.join(str(tmp_path), "ref_test.info"), os.path.join(str(tmp_path), "fast_test.info"),
+                       shallow=False)
+    assert os.path.getsize(os.path.join(str(tmp_path), "fast_test.info")) > 100
