@@ -7,10 +7,10 @@ Two ways:
 1. ``install()`` BEFORE the reference imports its model code: registers this package's
    modules under the names the reference imports
    (``modules.kg_reasoning.reasongnn``, ``modules.kg_reasoning.base_gnn``,
-   ``modules.layer_init``), so ``from modules.kg_reasoning.reasongnn import
+   ``modules.layer_init``, ``modules.query_update``), so ``from modules.kg_reasoning.reasongnn import
    ReasonGNNLayer`` (rearev.py:8) resolves to the HIP-backed class.
-2. ``swap(model)`` AFTER construction: replaces ``model.reasoning`` / ``model.type_layer``
-   of an existing ReaRev instance, carrying the parameters over.
+2. ``swap(model)`` AFTER construction: replaces ``model.reasoning`` / ``model.type_layer`` /
+   ``model.reform{j}`` of an existing ReaRev instance, carrying the parameters over.
 """
 from __future__ import annotations
 
@@ -21,6 +21,7 @@ _TARGETS = {
     "modules.kg_reasoning.reasongnn": "gnnrag_amd.modules.kg_reasoning.reasongnn",
     "modules.kg_reasoning.base_gnn": "gnnrag_amd.modules.kg_reasoning.base_gnn",
     "modules.layer_init": "gnnrag_amd.modules.layer_init",
+    "modules.query_update": "gnnrag_amd.modules.query_update",
 }
 
 
@@ -61,4 +62,14 @@ def swap(model, args: dict):
         tl.load_state_dict(tl_old.state_dict(), strict=True)
         tl.to(next(tl_old.parameters()).device)
         model.type_layer = tl
+    from .modules.query_update import QueryReform
+    j = 0
+    while getattr(model, "reform" + str(j), None) is not None:       # rearev.py:46-47
+        old_r = getattr(model, "reform" + str(j))
+        new_r = QueryReform(old_r.q_ent_attn.in_features)
+        new_r.load_state_dict(old_r.state_dict(), strict=True)
+        new_r.to(next(old_r.parameters()).device)
+        new_r.train(old_r.training)
+        setattr(model, "reform" + str(j), new_r)
+        j += 1
     return model

@@ -412,6 +412,22 @@ def reason_layer(plan: CsrPlan, h, dist, ins, relfeat, relfeat_inv, W_rel, b_rel
     return h_out, score, dist_out
 
 
+def seed_retrieve(seed_info: torch.Tensor, ent_emb: torch.Tensor) -> torch.Tensor:
+    """sum_n seed_info[b,n] * ent_emb[b,n,:]  ->  [B,D] (query_update.py:40), reading only flagged rows."""
+    lib = _lib.load()
+    seed_info = _chk(seed_info, "seed_info")
+    B, N = seed_info.shape
+    ent_emb = _chk(ent_emb, "ent_emb")
+    if ent_emb.dim() != 3 or ent_emb.shape[0] != B or ent_emb.shape[1] != N:
+        raise ValueError("ent_emb must be [B,N,D] matching seed_info [B,N]")
+    D = ent_emb.shape[2]
+    out = torch.empty((B, D), dtype=torch.float32, device=ent_emb.device)
+    with torch.cuda.device(ent_emb.device):
+        _lib.check(lib.gnnrag_seed_retrieve(seed_info.data_ptr(), ent_emb.data_ptr(), out.data_ptr(), B, N, D,
+                                            _stream()), "gnnrag_seed_retrieve")
+    return out
+
+
 def topp_candidates(pred_dist: torch.Tensor, eligible: torch.Tensor, ignore_prob: float, eps: float):
     """Per question: slots kept by the Evaluator's filter, sorted by probability (descending, stable), and
     how many of them the top-p cut retrieves.  Returns (slots int32 [B,N] (-1 padded), counts int32 [B,2])."""

@@ -232,6 +232,12 @@ int gnnrag_topp_candidates(const float* pred_dist, const uint8_t* eligible, int3
                            double ignore_prob, double eps, int32_t* out_slot, int32_t* out_cnt,
                            gnnrag_stream_t stream);
 
+/* out[b,:] = sum_n seed_info[b,n] * ent_emb[b,n,:]  - the seed retrieval of QueryReform.forward
+ * (gnn/modules/query_update.py:40, torch.bmm over all N rows); only rows with a non-zero flag are
+ * read, in ascending n.  seed_info [B,N], ent_emb [B,N,D], out [B,D]. */
+int gnnrag_seed_retrieve(const float* seed_info, const float* ent_emb, float* out, int32_t B, int32_t N,
+                         int32_t D, gnnrag_stream_t stream);
+
 /* Plain HBM copy kernel (float4 per lane) used by bench.py to measure the achievable
  * streaming ceiling next to the 8 TB/s spec.  n = number of floats (multiple of 4). */
 int gnnrag_stream_copy(const float* src, float* dst, int64_t n, gnnrag_stream_t stream);

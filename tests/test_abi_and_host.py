@@ -120,6 +120,12 @@ def test_install_substitutes_reference_module_names():
         from modules.layer_init import TypeLayer                       # noqa
         assert ReasonGNNLayer.__module__.startswith("gnnrag_amd.")
         assert TypeLayer.__module__.startswith("gnnrag_amd.")
+        from modules.query_update import AttnEncoder, Fusion, QueryReform   # noqa: rearev.py:12
+        assert all(c.__module__.startswith("gnnrag_amd.") for c in (AttnEncoder, Fusion, QueryReform))
+        # parameter names of the reference classes (query_update.py:9-10,23-24,50)
+        assert sorted(QueryReform(8).state_dict()) == ["fusion.g.weight", "fusion.r.weight", "q_ent_attn.bias",
+                                                       "q_ent_attn.weight"]
+        assert sorted(AttnEncoder(8).state_dict()) == ["attn_linear.weight"]
     finally:
         install.uninstall()
         sys.modules.update(saved)

@@ -162,6 +162,8 @@ def test_swapped_model_reproduces_reference_forward(reference_setup, monkeypatch
     mine = install.swap(copy.deepcopy(model), args)
     assert type(mine.reasoning).__module__.startswith("gnnrag_amd.")
     assert type(mine.type_layer).__module__.startswith("gnnrag_amd.")
+    assert all(type(getattr(mine, "reform%d" % j)).__module__.startswith("gnnrag_amd.")
+               for j in range(args["num_ins"]))
     with torch.no_grad():
         _, pred, dist, _ = mine(batch[:-1])
     np.testing.assert_allclose(dist.numpy(), dist_ref.numpy(), rtol=0, atol=1e-6)

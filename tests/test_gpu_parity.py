@@ -511,3 +511,72 @@ def test_no_cpu_fallback_and_autograd_form_agrees(dev):
     with pytest.raises(_lib.GnnragError):
         from gnnrag_amd import ops
         ops.linear(torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+@pytest.mark.parametrize("B,N,D", [(3, 70, 50), (64, 2000, 200), (2, 130, 300)])
+def test_query_reform_seed_retrieve(dev, B, N, D):
+    """QueryReform drop-in (query_update.py:26-44): the seed retrieval kernel against torch.bmm, and the
+    module's output against fusion(q, bmm) with the same parameters (the reference's attention over all
+    nodes does not enter its return value)."""
+    from gnnrag_amd import ops
+    from gnnrag_amd.modules.query_update import QueryReform
+    g = torch.Generator().manual_seed(B + N)
+    ent = torch.randn(B, N, D, generator=g).to(dev)
+    seed = torch.zeros(B, N)
+    seed[:, 0] = 1.0
+    if B > 1:
+        seed[1, N - 1] = 0.5                     # two seeds with fractional weights (seed_dist-style input)
+        seed[1, 0] = 0.5
+    if B > 2:
+        seed[2] = 0.0                            # a question without a seed
+    seed = seed.to(dev)
+    want = torch.bmm(seed.unsqueeze(1), ent).squeeze(1)
+    got = ops.seed_retrieve(seed, ent)
+    assert torch.equal(got, want) or (got - want).abs().max().item() <= 1e-6
+    torch.manual_seed(0)
+    qr = QueryReform(D).to(dev).eval()
+    q = torch.randn(B, D, generator=g).to(dev)
+    with torch.no_grad():
+        out = qr(q, ent, seed, (seed == 0).float())
+        ref = qr.fusion(q, want)
+    assert (out - ref).abs().max().item() <= 1e-6
+
+
+def test_query_reform_equals_reference_op_sequence_at_c2(dev, capsys):
+    """C2-sized node state: the drop-in against the reference's full op sequence (incl. its unused attention
+    over all nodes, restated in oracle/query_update_torch.py) run on the same GPU; prints both times."""
+    import oracle.query_update_torch as oq
+    from gnnrag_amd.modules.query_update import QueryReform
+    B, N, D = 64, 2000, 200
+    g = torch.Generator().manual_seed(1)
+    ent = torch.randn(B, N, D, generator=g).to(dev)
+    q = torch.randn(B, D, generator=g).to(dev)
+    seed = torch.zeros(B, N)
+    seed[:, 0] = 1.0
+    seed = seed.to(dev)
+    local_entity = torch.randint(0, 1000, (B, N), generator=g).to(dev)        # rearev.py:219 passes entity IDS as "mask"
+    torch.manual_seed(0)
+    qr = QueryReform(D).to(dev).eval()
+
+    def ref():
+        return oq.query_reform(q, ent, seed, local_entity, qr.q_ent_attn.weight, qr.q_ent_attn.bias,
+                               qr.fusion.r.weight, qr.fusion.g.weight)
+
+    def mine():
+        return qr(q, ent, seed, local_entity)
+
+    with torch.no_grad():
+        assert (mine() - ref()).abs().max().item() <= 1e-6
+        times = []
+        for fn in (ref, mine):
+            fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(10):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            times.append(a.elapsed_time(b) / 10)
+    with capsys.disabled():
+        print("\nQueryReform at C2: reference op sequence %.3f ms, drop-in %.3f ms" % tuple(times))
