@@ -262,7 +262,7 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
             pmc = json.load(open(ppath))
         except Exception:
             pmc = {}
-    r_fused = hbm("gnnrag_aggregate_fused (k_walk_light<FUSED> + heavy chunks)", ms["aggregate_fused_dense"],
+    r_fused = hbm("gnnrag_aggregate_fused (k_fact_prior + k_walk_slice<FUSED>: LDS walk over per-question relation-table slices)", ms["aggregate_fused_dense"],
                   ms["aggregate_fused_seed"],
                   {"note": "fused walk: e2e_linear is pushed into per-question relation tables, so agg [BN,2I*D] is "
                            "never written; `achieved` still uses the pinned unfused byte count (SURVEY 8d), i.e. it "
