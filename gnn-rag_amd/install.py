@@ -20,6 +20,7 @@ import sys
 _TARGETS = {
     "modules.kg_reasoning.reasongnn": "gnnrag_amd.modules.kg_reasoning.reasongnn",
     "modules.kg_reasoning.base_gnn": "gnnrag_amd.modules.kg_reasoning.base_gnn",
+    "modules.kg_reasoning.nsm_gnn": "gnnrag_amd.modules.kg_reasoning.nsm_gnn",
     "modules.layer_init": "gnnrag_amd.modules.layer_init",
     "modules.query_update": "gnnrag_amd.modules.query_update",
 }
