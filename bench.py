@@ -156,6 +156,9 @@ def main():
                    "D": cfg.D, "I": cfg.I, "L": cfg.L, "parallelism": "question-sharded x%d" % world},
         "fact_layers_per_sec": facts / (elapsed / args.steps),
         "csr_build_ms": csr_build_ms, "csr_first_call_ms": csr_first_ms,
+        # host-buffer boundary: int64 tuple -> int32 upload over PCIe + device structure build, once per batch,
+        # amortised over ONE step (a ReaRev forward runs num_iter steps on the same structure); never `value`
+        "value_incl_upload_and_build": world * cfg.B * cfg.E * cfg.L / (elapsed / args.steps + csr_build_ms * 1e-3),
         "dense_math": math_name,
     }
 
