@@ -117,13 +117,10 @@ class ReasonGNNLayer(BaseGNNLayer):
             T_fwd = T_fwd + torch.cat([pos, pad], dim=0)
             T_inv = T_inv + torch.cat([pos_inv, pad], dim=0)
         agg = AggregateFn.apply(self.plan, current_dist.float(), relational_ins.float(), T_fwd, T_inv)
-        next_local_entity_emb = torch.cat((self.local_entity_emb.float(), agg.view(B, N, -1)), dim=2)
-        self.local_entity_emb = F.relu(e2e_linear(self.linear_drop(next_local_entity_emb)))
-        score_tp = self.score_func(self.linear_drop(self.local_entity_emb)).squeeze(dim=2)
-        answer_mask = self.local_entity_mask
-        self.possible_cand.append(answer_mask)
-        score_tp = score_tp + (1 - answer_mask) * VERY_NEG_NUMBER
-        current_dist = self.softmax_d1(score_tp)
-        if return_score:
-            return score_tp, current_dist
-        return current_dist, self.local_entity_emb
+        state = torch.cat((self.local_entity_emb.float(), agg.view(B, N, -1)), dim=2)      # [h | fwd_0 | inv_0 | ...]
+        self.local_entity_emb = F.relu(e2e_linear(self.linear_drop(state)))
+        mask = self.local_entity_mask
+        self.possible_cand.append(mask)
+        score = self.score_func(self.linear_drop(self.local_entity_emb)).squeeze(dim=2) + (1 - mask) * VERY_NEG_NUMBER
+        new_dist = self.softmax_d1(score)
+        return (score, new_dist) if return_score else (new_dist, self.local_entity_emb)
