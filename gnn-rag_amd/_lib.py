@@ -33,6 +33,12 @@ class CsrStruct(C.Structure):
     ]
 
 
+class RelorderStruct(C.Structure):
+    """Mirror of ``struct gnnrag_relorder`` (include/gnnrag.h)."""
+    _fields_ = [("F", C.c_int64), ("rel_total", C.c_int32), ("n_chunks", C.c_int32),
+                ("ht", C.c_void_p), ("w", C.c_void_p), ("row_ptr", C.c_void_p), ("chunk_ptr", C.c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/gnnrag.h declares
 _VP = C.c_void_p
 SIGNATURES = {
@@ -51,9 +57,14 @@ SIGNATURES = {
     "gnnrag_aggregate": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32,
                                    _VP, C.c_size_t, _VP]),
     "gnnrag_aggregate_fused": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, C.c_int32, _VP, C.c_size_t, _VP]),
-    "gnnrag_backward_workspace_bytes": (C.c_size_t, [C.POINTER(CsrStruct), C.c_int32]),
-    "gnnrag_aggregate_backward": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
-                                            C.c_int32, C.c_int32, _VP, C.c_size_t, _VP]),
+    "gnnrag_relorder_bytes": (C.c_size_t, [C.POINTER(CsrStruct), C.c_int]),
+    "gnnrag_relorder_scratch_bytes": (C.c_size_t, [C.POINTER(CsrStruct)]),
+    "gnnrag_relorder_build": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP, C.c_size_t,
+                                        C.POINTER(RelorderStruct), _VP]),
+    "gnnrag_backward_workspace_bytes": (C.c_size_t, [C.POINTER(CsrStruct), C.POINTER(RelorderStruct), C.c_int32,
+                                                     C.c_int32]),
+    "gnnrag_aggregate_backward": (C.c_int, [C.POINTER(CsrStruct), C.POINTER(RelorderStruct), _VP, _VP, _VP, _VP, _VP,
+                                            _VP, _VP, _VP, _VP, C.c_int32, C.c_int32, _VP, C.c_size_t, _VP]),
     "gnnrag_typelayer_backward": (C.c_int, [C.POINTER(CsrStruct), _VP, C.c_int, _VP, C.c_int32, _VP, C.c_size_t,
                                             _VP]),
     "gnnrag_seed_retrieve": (C.c_int, [_VP, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, _VP]),

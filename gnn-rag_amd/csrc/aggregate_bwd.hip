@@ -61,9 +61,11 @@ struct BwdArgs {
   int32_t B, N, D, I, Rmax, Rtot;
 };
 
-// facts [j0, j1) of structure o = 1 - d, all with the same source: this lane's share (columns
-// lane, lane + 64, ...) of  sum_f w_f sum_i < g_agg[dst_f, 2i+d, :], relu(T_d[rel_f,:] * q_i) >.
+// facts [j0, j1) of structure o = 1 - d, all with the same source: this lane's share of
+//   sum_f w_f sum_i < g_agg[dst_f, 2i+d, :], relu(T_d[rel_f,:] * q_i) >.
+// V4: the lane owns float4 columns lane, lane + 64, ... (D % 4 == 0); else scalar columns lane, lane + 64, ...
 // Two facts per step so their row loads overlap.
+template <bool V4>
 __device__ __forceinline__ float prior_grad_range(const BwdArgs& a, const float* __restrict__ q, int d, int j0,
                                                   int j1, int lane) {
   const int o = 1 - d;
@@ -73,36 +75,42 @@ __device__ __forceinline__ float prior_grad_range(const BwdArgs& a, const float*
   const float* __restrict__ w = a.w[o];
   const float* __restrict__ T = a.T[d];
   const float* __restrict__ g = a.g + (size_t)d * D;
+  constexpr int W = V4 ? 4 : 1;
+  typedef float vec __attribute__((ext_vector_type(W)));
+  auto dot2 = [&](const float* t0, const float* g0, const float* t1, const float* g1, float& p0, float& p1) {
+    for (int c = W * lane; c < D; c += 64 * W) {
+      const vec tv0 = *reinterpret_cast<const vec*>(t0 + c);
+      const vec tv1 = *reinterpret_cast<const vec*>(t1 + c);
+      for (int i = 0; i < I; ++i) {
+        const vec qv = *reinterpret_cast<const vec*>(q + i * D + c);
+        const vec gv0 = *reinterpret_cast<const vec*>(g0 + (size_t)2 * i * D + c);
+        const vec gv1 = *reinterpret_cast<const vec*>(g1 + (size_t)2 * i * D + c);
+        const vec m0 = __builtin_elementwise_max(tv0 * qv, (vec)0.f);
+        const vec m1 = __builtin_elementwise_max(tv1 * qv, (vec)0.f);
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          p0 += gv0[k] * m0[k];
+          p1 += gv1[k] * m1[k];
+        }
+      }
+    }
+  };
   float acc = 0.f;
   int j = j0;
   for (; j + 1 < j1; j += 2) {
     const int2 e0 = edge[j], e1 = edge[j + 1];
     const float w0 = w ? w[j] : 1.f, w1 = w ? w[j + 1] : 1.f;
-    const float* t0 = T + (size_t)e0.y * D;
-    const float* t1 = T + (size_t)e1.y * D;
-    const float* g0 = g + (size_t)e0.x * ld;
-    const float* g1 = g + (size_t)e1.x * ld;
     float p0 = 0.f, p1 = 0.f;
-    for (int c = lane; c < D; c += 64) {
-      const float tv0 = t0[c], tv1 = t1[c];
-      for (int i = 0; i < I; ++i) {
-        const float qv = q[i * D + c];
-        p0 += g0[(size_t)2 * i * D + c] * fmaxf(tv0 * qv, 0.f);
-        p1 += g1[(size_t)2 * i * D + c] * fmaxf(tv1 * qv, 0.f);
-      }
-    }
+    dot2(T + (size_t)e0.y * D, g + (size_t)e0.x * ld, T + (size_t)e1.y * D, g + (size_t)e1.x * ld, p0, p1);
     acc += w0 * p0 + w1 * p1;
   }
   if (j < j1) {
     const int2 e0 = edge[j];
     const float w0 = w ? w[j] : 1.f;
+    float p0 = 0.f, p1 = 0.f;
     const float* t0 = T + (size_t)e0.y * D;
     const float* g0 = g + (size_t)e0.x * ld;
-    float p0 = 0.f;
-    for (int c = lane; c < D; c += 64) {
-      const float tv0 = t0[c];
-      for (int i = 0; i < I; ++i) p0 += g0[(size_t)2 * i * D + c] * fmaxf(tv0 * q[i * D + c], 0.f);
-    }
+    dot2(t0, g0, t0, g0, p0, p1);
     acc += w0 * p0;
   }
   return acc;
@@ -115,6 +123,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // one wave per source node; blockIdx.y = question (its instructions are staged in LDS once)
+template <bool V4>
 __global__ __launch_bounds__(256) void k_bwd_prior(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float q_s[];      // [I][D]
   const int b = blockIdx.y;
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(256) void k_bwd_prior(const BwdArgs a) {
     const int o = 1 - d;
     const int beg = a.row_ptr[o][s], end = a.row_ptr[o][s + 1];
     if (end - beg > a.heavy_deg) continue;           // k_bwd_prior_heavy adds these
-    acc += prior_grad_range(a, q_s, d, beg, end, lane);
+    acc += prior_grad_range<V4>(a, q_s, d, beg, end, lane);
   }
   acc = wave_sum(acc);
   if (lane == 0) a.g_dist[s] = acc;
@@ -138,6 +147,7 @@ __global__ __launch_bounds__(256) void k_bwd_prior(const BwdArgs a) {
 
 // rows above heavy_deg: one workgroup per 256-fact chunk (64 facts per wave), added atomically
 // (after k_bwd_prior's store)
+template <bool V4>
 __global__ __launch_bounds__(256) void k_bwd_prior_heavy(const BwdArgs a) {
   const int o = blockIdx.y, d = 1 - o;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(256) void k_bwd_prior_heavy(const BwdArgs a) {
     const int beg = min(cbeg + wave * (kHeavyDeg / 4), cend);
     const int end = min(beg + kHeavyDeg / 4, cend);
     const float* q = a.ins + (size_t)(s / a.N) * a.I * a.D;
-    const float acc = wave_sum(prior_grad_range(a, q, d, beg, end, lane));
+    const float acc = wave_sum(prior_grad_range<V4>(a, q, d, beg, end, lane));
     if (lane == 0) unsafeAtomicAdd(a.g_dist + s, acc);
   }
 }
@@ -374,6 +384,185 @@ __global__ __launch_bounds__(256) void k_bwd_reduce_tables(const BwdArgs a, cons
   }
 }
 
+// ---- table / instruction gradients by gathering over (question, relation) rows -------------------
+// One wave per chunk (<= 256 facts of one compact relation row, gnnrag_relorder).  All facts of a row
+// share T_d[r] and the question's instructions, so the wave keeps U[d][i] (its float4 columns) in
+// registers while it streams the facts: for each fact and direction one scalar prior and NI coalesced
+// row segments of g_agg.  The ReLU gate depends on (r, b, i) only, so a chunk's partial sums are gated
+// and written on their own:  Vc[chunk][d][:] = sum_i U[d][i]*gate*q_i   (-> g_T_d[r] over chunks),
+//                            Qc[chunk][i][:] = sum_d U[d][i]*gate*t_d   (-> g_ins[b,i] over chunks).
+// No atomics: every output element has one writer and the reductions run in a fixed order.
+template <int NI, int CPL>
+__global__ __launch_bounds__(256) void k_bwd_rel_gather(const BwdArgs a, const int2* __restrict__ ht,
+                                                        const float* __restrict__ w,
+                                                        const int32_t* __restrict__ row_ptr,
+                                                        const int32_t* __restrict__ chunk_ptr, int n_chunks,
+                                                        float* __restrict__ Vc, float* __restrict__ Qc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // XCD b % 8 gets a contiguous eighth of the chunks (= a few questions): their g_agg rows share one L2
+  const int nblk = gridDim.x;
+  const int blk = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+  const int c = blk * 4 + wave;
+  if (c >= n_chunks) return;
+  int lo = 0, hi = a.Rtot;                      // row of chunk c: largest row with chunk_ptr[row] <= c
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (chunk_ptr[mid] <= c) lo = mid; else hi = mid;
+  }
+  const int row = lo;
+  const int2 br = a.rel_rows[row];              // (question, relation id)
+  const int beg = row_ptr[row] + (c - chunk_ptr[row]) * kHeavyDeg;
+  const int end = min(beg + kHeavyDeg, row_ptr[row + 1]);
+  const int D = a.D;
+  const size_t ld = (size_t)2 * NI * D;
+  f32x4 U[2][NI][CPL];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int m = 0; m < CPL; ++m) U[d][i][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bool cv[CPL];
+  int col[CPL];
+#pragma unroll
+  for (int m = 0; m < CPL; ++m) {
+    col[m] = 4 * (lane + 64 * m);
+    cv[m] = col[m] < D;
+  }
+  for (int j0 = beg; j0 < end; j0 += 4) {
+    int2 e[4];
+    float wf[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = min(j0 + u, end - 1);
+      e[u] = ht[j];
+      wf[u] = (j0 + u < end) ? (w ? w[j] : 1.f) : 0.f;
+    }
+    float p[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      p[u][0] = wf[u] * a.dist[e[u].x];         // forward: prior of the head, gradient row of the tail
+      p[u][1] = wf[u] * a.dist[e[u].y];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const float pv = p[u][d];
+        if (pv == 0.f) continue;                // wave-uniform
+        const float* grow = a.g + (size_t)(d == 0 ? e[u].y : e[u].x) * ld + (size_t)d * D;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int m = 0; m < CPL; ++m)
+            if (cv[m]) U[d][i][m] += pv * *reinterpret_cast<const f32x4*>(grow + (size_t)2 * i * D + col[m]);
+      }
+    }
+  }
+  float* vout = Vc + (size_t)c * 2 * D;
+  float* qout = Qc + (size_t)c * NI * D;
+  const float* qin = a.ins + (size_t)br.x * NI * D;
+#pragma unroll
+  for (int m = 0; m < CPL; ++m) {
+    if (!cv[m]) continue;
+    f32x4 t[2], q[NI];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) t[d] = *reinterpret_cast<const f32x4*>(a.T[d] + (size_t)br.y * D + col[m]);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) q[i] = *reinterpret_cast<const f32x4*>(qin + (size_t)i * D + col[m]);
+    f32x4 v[2], gq[NI];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) v[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NI; ++i) gq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (t[d][k] * q[i][k] > 0.f) {        // the ReLU gate of relu(T_d[r] * ins[b,i])
+            v[d][k] += U[d][i][m][k] * q[i][k];
+            gq[i][k] += U[d][i][m][k] * t[d][k];
+          }
+#pragma unroll
+    for (int d = 0; d < 2; ++d) *reinterpret_cast<f32x4*>(vout + (size_t)d * D + col[m]) = v[d];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<f32x4*>(qout + (size_t)i * D + col[m]) = gq[i];
+  }
+}
+
+// g_T_d[r,:] = sum over the questions that use r (found by binary search in each question's sorted relation
+// list) and the chunks of their row of Vc.  One workgroup per (relation, direction); thread group k of 4 takes
+// the k-th, (k+4)-th, ... question, the four partial sums are combined in group order (fixed order).
+__global__ __launch_bounds__(1024) void k_bwd_reduce_tables_chunks(const BwdArgs a, const float* __restrict__ Vc,
+                                                                   const int32_t* __restrict__ chunk_ptr) {
+  __shared__ int cbs[256], ces[256];
+  __shared__ float part[4][256];
+  const int r = blockIdx.x, d = blockIdx.y;
+  const int D = a.D;
+  const int grp = threadIdx.x >> 8, t = threadIdx.x & 255;
+  for (int col0 = 0; col0 < D; col0 += 256) {
+    const int col = col0 + t;
+    float acc = 0.f;
+    for (int b0 = 0; b0 < a.B; b0 += 256) {
+      __syncthreads();
+      if (threadIdx.x < 256) {                  // thread b: chunk range of row (b, r), empty if b does not use r
+        int cb = 0, ce = 0;
+        const int b = b0 + (int)threadIdx.x;
+        if (b < a.B) {
+          int lo = a.rel_off[b], hi = a.rel_off[b + 1];
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (a.rel_rows[mid].y < r) lo = mid + 1; else hi = mid;
+          }
+          if (lo < a.rel_off[b + 1] && a.rel_rows[lo].y == r) {
+            cb = chunk_ptr[lo];
+            ce = chunk_ptr[lo + 1];
+          }
+        }
+        cbs[threadIdx.x] = cb;
+        ces[threadIdx.x] = ce;
+      }
+      __syncthreads();
+      if (col < D)
+        for (int j = grp; j < 256; j += 4)
+          for (int c = cbs[j]; c < ces[j]; ++c) acc += Vc[((size_t)c * 2 + d) * D + col];
+    }
+    part[grp][t] = acc;
+    __syncthreads();
+    if (grp == 0 && col < D) a.g_T[d][(size_t)r * D + col] = ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
+  }
+}
+
+// g_ins[b,i,:] = sum over the chunks of question b of Qc: one workgroup per (question, instruction), four
+// thread groups over the chunks, combined in group order
+__global__ __launch_bounds__(1024) void k_bwd_reduce_ins_chunks(const BwdArgs a, const float* __restrict__ Qc,
+                                                                const int32_t* __restrict__ chunk_ptr) {
+  __shared__ float part[4][256];
+  const int b = blockIdx.x, i = blockIdx.y;
+  const int D = a.D, NI = a.I;
+  const int grp = threadIdx.x >> 8, t = threadIdx.x & 255;
+  const int c0 = chunk_ptr[a.rel_off[b]], c1 = chunk_ptr[a.rel_off[b + 1]];
+  for (int col0 = 0; col0 < D; col0 += 256) {
+    const int col = col0 + t;
+    float acc0 = 0.f, acc1 = 0.f;
+    if (col < D) {
+      int c = c0 + grp;
+      for (; c + 4 < c1; c += 8) {
+        acc0 += Qc[((size_t)c * NI + i) * D + col];
+        acc1 += Qc[((size_t)(c + 4) * NI + i) * D + col];
+      }
+      if (c < c1) acc0 += Qc[((size_t)c * NI + i) * D + col];
+    }
+    part[grp][t] = acc0 + acc1;
+    __syncthreads();
+    if (grp == 0 && col < D)
+      a.g_ins[((size_t)b * NI + i) * D + col] = ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
+    __syncthreads();
+  }
+}
+
 static size_t bwd_lds_bytes(int nd, int rmax) {
   return ((size_t)nd * rmax * kBwdSliceW + 16 * 16) * sizeof(float);
 }
@@ -412,6 +601,29 @@ static size_t bwd_pairs_bytes(const gnnrag_csr* csr) {
 static size_t bwd_ws_bytes(const gnnrag_csr* csr, int D) {
   return bwd_pairs_bytes(csr) +
          align_up((size_t)2 * (size_t)(csr->rel_total > 0 ? csr->rel_total : 1) * D * sizeof(float), 256);
+}
+// gather path: Vc [n_chunks][2][D] + Qc [n_chunks][I][D]
+static size_t bwd_gather_ws_bytes(const gnnrag_relorder* ro, int D, int I) {
+  return align_up((size_t)(ro->n_chunks > 0 ? ro->n_chunks : 1) * (size_t)(2 + I) * D * sizeof(float), 256);
+}
+static bool gather_ok(const gnnrag_relorder* ro, int D, int I) {
+  return ro && D % 4 == 0 && D <= 1024 && I >= 1 && I <= 4;
+}
+
+template <int NI>
+static int launch_gather(const BwdArgs& a, const gnnrag_relorder* ro, float* Vc, float* Qc, hipStream_t stream) {
+  const int nblk = 8 * ((ro->n_chunks + 31) / 32);          // 4 chunks per workgroup, multiple of 8 workgroups
+  const int cpl = (a.D / 4 + 63) / 64;
+#define GNNRAG_GATHER(C)                                                                                       \
+  hipLaunchKernelGGL((k_bwd_rel_gather<NI, C>), dim3(nblk), dim3(256), 0, stream, a, (const int2*)ro->ht,    \
+                     (const float*)ro->w, (const int32_t*)ro->row_ptr, (const int32_t*)ro->chunk_ptr,        \
+                     ro->n_chunks, Vc, Qc)
+  if (cpl == 1) GNNRAG_GATHER(1);
+  else if (cpl == 2) GNNRAG_GATHER(2);
+  else GNNRAG_GATHER(4);
+#undef GNNRAG_GATHER
+  GNNRAG_LAUNCH_CHECK();
+  return 0;
 }
 
 template <int MODE>
@@ -453,7 +665,8 @@ static int launch_tables(const BwdArgs& a, const gnnrag_csr* csr, void* ws, size
 
 using namespace gnnrag;
 
-extern "C" int gnnrag_aggregate_backward(const gnnrag_csr* csr, const float* dist, const float* ins,
+extern "C" int gnnrag_aggregate_backward(const gnnrag_csr* csr, const gnnrag_relorder* relorder,
+                                         const float* dist, const float* ins,
                                          const float* T_fwd, const float* T_inv, const float* g_agg,
                                          float* g_dist, float* g_ins, float* g_T_fwd, float* g_T_inv,
                                          int32_t D, int32_t I, void* workspace, size_t workspace_bytes,
@@ -462,7 +675,9 @@ extern "C" int gnnrag_aggregate_backward(const gnnrag_csr* csr, const float* dis
       D <= 0 || I <= 0 || csr->rel_total < 0)
     return GNNRAG_E_BADARG;
   hipStream_t stream = (hipStream_t)stream_;
-  if (bwd_lds_bytes(2, csr->rel_max) > 160 * 1024 - 1024) return GNNRAG_E_UNSUPPORTED;
+  const bool gather = gather_ok(relorder, D, I);
+  if (relorder && (relorder->F != csr->F || relorder->rel_total != csr->rel_total)) return GNNRAG_E_BADARG;
+  if (!gather && bwd_lds_bytes(2, csr->rel_max) > 160 * 1024 - 1024) return GNNRAG_E_UNSUPPORTED;
   BwdArgs a;
   fill_bwd(a, csr, D, I);
   a.w[0] = csr->w_gnn[0];
@@ -476,18 +691,48 @@ extern "C" int gnnrag_aggregate_backward(const gnnrag_csr* csr, const float* dis
   a.g_ins = g_ins;
   a.g_T[0] = g_T_fwd;
   a.g_T[1] = g_T_inv;
-  hipLaunchKernelGGL(k_bwd_prior, dim3((csr->N + 3) / 4, csr->B), dim3(256), (size_t)I * D * sizeof(float), stream, a);
+  const bool v4 = D % 4 == 0 && ((uintptr_t)g_agg & 15) == 0 && ((uintptr_t)T_fwd & 15) == 0 &&
+                  ((uintptr_t)T_inv & 15) == 0 && ((uintptr_t)ins & 15) == 0;
+  const dim3 pgrid((csr->N + 3) / 4, csr->B);
+  const size_t plds = (size_t)I * D * sizeof(float);
+  if (v4) hipLaunchKernelGGL(k_bwd_prior<true>, pgrid, dim3(256), plds, stream, a);
+  else hipLaunchKernelGGL(k_bwd_prior<false>, pgrid, dim3(256), plds, stream, a);
   GNNRAG_LAUNCH_CHECK();
   if (csr->F > 0) {
     const int nb = csr->max_chunks < 4096 ? csr->max_chunks : 4096;
-    hipLaunchKernelGGL(k_bwd_prior_heavy, dim3(nb > 0 ? nb : 1, 2), dim3(256), 0, stream, a);
+    if (v4) hipLaunchKernelGGL(k_bwd_prior_heavy<true>, dim3(nb > 0 ? nb : 1, 2), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(k_bwd_prior_heavy<false>, dim3(nb > 0 ? nb : 1, 2), dim3(256), 0, stream, a);
     GNNRAG_LAUNCH_CHECK();
   }
-  return launch_tables<BWD_REASON>(a, csr, workspace, workspace_bytes, stream);
+  if (!gather) return launch_tables<BWD_REASON>(a, csr, workspace, workspace_bytes, stream);
+  if (!workspace || workspace_bytes < bwd_gather_ws_bytes(relorder, D, I)) return GNNRAG_E_WORKSPACE;
+  float* Vc = (float*)workspace;
+  float* Qc = Vc + (size_t)(relorder->n_chunks > 0 ? relorder->n_chunks : 1) * 2 * D;
+  if (relorder->n_chunks > 0) {
+    int rc = 0;
+    switch (I) {
+      case 1: rc = launch_gather<1>(a, relorder, Vc, Qc, stream); break;
+      case 2: rc = launch_gather<2>(a, relorder, Vc, Qc, stream); break;
+      case 3: rc = launch_gather<3>(a, relorder, Vc, Qc, stream); break;
+      default: rc = launch_gather<4>(a, relorder, Vc, Qc, stream); break;
+    }
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_bwd_reduce_tables_chunks, dim3(csr->R1, 2), dim3(1024), 0, stream, a, (const float*)Vc,
+                     (const int32_t*)relorder->chunk_ptr);
+  GNNRAG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bwd_reduce_ins_chunks, dim3(csr->B, I), dim3(1024), 0, stream, a, (const float*)Qc,
+                     (const int32_t*)relorder->chunk_ptr);
+  GNNRAG_LAUNCH_CHECK();
+  return 0;
 }
 
-extern "C" size_t gnnrag_backward_workspace_bytes(const gnnrag_csr* csr, int32_t D) {
-  return (csr && D > 0) ? bwd_ws_bytes(csr, D) : 0;
+extern "C" size_t gnnrag_backward_workspace_bytes(const gnnrag_csr* csr, const gnnrag_relorder* relorder, int32_t D,
+                                                  int32_t I) {
+  if (!csr || D <= 0 || I <= 0) return 0;
+  const size_t lds_path = bwd_ws_bytes(csr, D);
+  const size_t gather_path = gather_ok(relorder, D, I) ? bwd_gather_ws_bytes(relorder, D, I) : 0;
+  return lds_path > gather_path ? lds_path : gather_path;
 }
 
 extern "C" int gnnrag_typelayer_backward(const gnnrag_csr* csr, const float* g_pre, int use_w_rel, float* g_T,

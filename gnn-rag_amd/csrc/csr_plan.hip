@@ -277,6 +277,56 @@ __global__ __launch_bounds__(256) void k_rel_rows(const int32_t* __restrict__ g2
   rel_rows[rel_off[b] + l] = make_int2(b, (int)(idx - (int64_t)b * R1));
 }
 
+// ---- facts ordered by (question, relation): the backward's gather structure ----------------------
+// key[f] = compact relation row of fact f: position of rel_f in its question's sorted relation list
+__global__ __launch_bounds__(256) void k_rel_key(const int32_t* __restrict__ heads, const int32_t* __restrict__ rels,
+                                                 int64_t F, int32_t N, const int32_t* __restrict__ rel_off,
+                                                 const int2* __restrict__ rel_rows, uint32_t* __restrict__ key) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  const int b = heads[f] / N, r = rels[f];
+  int lo = rel_off[b], hi = rel_off[b + 1];
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (rel_rows[mid].y < r) lo = mid + 1; else hi = mid;
+  }
+  key[f] = (uint32_t)lo;
+}
+
+__global__ __launch_bounds__(256) void k_relorder_fill(const int32_t* __restrict__ perm,
+                                                       const int32_t* __restrict__ heads,
+                                                       const int32_t* __restrict__ tails,
+                                                       const float* __restrict__ w, int64_t F,
+                                                       int2* __restrict__ ht, float* __restrict__ w_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F) return;
+  const int32_t f = perm[i];
+  ht[i] = make_int2(heads[f], tails[f]);
+  if (w_out) {
+    const float v = w[f];
+    w_out[i] = v * v;
+  }
+}
+
+// chunk_ptr = exclusive prefix of ceil(len/256) over the rows (single workgroup; rows <= a few 10^5)
+__global__ __launch_bounds__(1024) void k_relorder_chunks(const int32_t* __restrict__ row_ptr, int32_t R,
+                                                          int32_t* __restrict__ chunk_ptr, int32_t* __restrict__ total) {
+  __shared__ int wsum[16];
+  int carry = 0;
+  for (int base = 0; base < R; base += 1024) {
+    const int i = base + (int)threadIdx.x;
+    const int v = (i < R) ? (row_ptr[i + 1] - row_ptr[i] + kHeavyDeg - 1) / kHeavyDeg : 0;
+    int tot;
+    const int ex = block_scan_excl(v, wsum, tot);
+    if (i < R) chunk_ptr[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) {
+    chunk_ptr[R] = carry;
+    *total = carry;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_csr_permute_weight(const int32_t* __restrict__ perm,
                                                             const float* __restrict__ w, int64_t F, int square,
                                                             float* __restrict__ out) {
@@ -302,6 +352,91 @@ extern "C" int gnnrag_csr_permute_weight(const gnnrag_csr* csr, const float* w_p
                        w_per_fact, csr->F, square, outs[d]);
     GNNRAG_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+struct RelLayout { size_t ht, w, row_ptr, chunk_ptr, total_cnt, total; };
+
+static RelLayout rel_layout(const gnnrag_csr* csr, int has_w) {
+  RelLayout L;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  const size_t Fp = (size_t)(csr->F > 0 ? csr->F : 1);
+  const size_t R = (size_t)(csr->rel_total > 0 ? csr->rel_total : 0);
+  L.ht = take(Fp * 2 * sizeof(int32_t));
+  L.w = has_w ? take(Fp * sizeof(float)) : 0;
+  L.row_ptr = take((R + 1) * sizeof(int32_t));
+  L.chunk_ptr = take((R + 1) * sizeof(int32_t));
+  L.total_cnt = take(sizeof(int32_t));
+  L.total = off;
+  return L;
+}
+
+extern "C" size_t gnnrag_relorder_bytes(const gnnrag_csr* csr, int has_w) {
+  return csr ? rel_layout(csr, has_w).total : 0;
+}
+
+extern "C" size_t gnnrag_relorder_scratch_bytes(const gnnrag_csr* csr) {
+  if (!csr) return 0;
+  const size_t Fp = (size_t)(csr->F > 0 ? csr->F : 1);
+  const unsigned bits = key_bits((size_t)(csr->rel_total > 1 ? csr->rel_total : 2));
+  // unsorted keys, sorted keys, permutation, sort temporaries
+  return 3 * align_up(Fp * sizeof(uint32_t), 256) + align_up(sort_temp_bytes(csr->F, bits), 256);
+}
+
+extern "C" int gnnrag_relorder_build(const gnnrag_csr* csr, const int32_t* heads, const int32_t* rels,
+                                     const int32_t* tails, const float* w_per_fact, void* mem, size_t mem_bytes,
+                                     void* scratch, size_t scratch_bytes, gnnrag_relorder* out,
+                                     gnnrag_stream_t stream_) {
+  if (!csr || !out || !mem || csr->rel_total < 0) return GNNRAG_E_BADARG;
+  const int64_t F = csr->F;
+  if (F > 0 && (!heads || !rels || !tails || !scratch)) return GNNRAG_E_BADARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  const RelLayout L = rel_layout(csr, w_per_fact != nullptr);
+  if (mem_bytes < L.total) return GNNRAG_E_WORKSPACE;
+  if (scratch_bytes < gnnrag_relorder_scratch_bytes(csr)) return GNNRAG_E_WORKSPACE;
+  char* base = (char*)mem;
+  memset(out, 0, sizeof(*out));
+  out->F = F;
+  out->rel_total = csr->rel_total;
+  out->ht = (int32_t*)(base + L.ht);
+  out->w = w_per_fact ? (float*)(base + L.w) : nullptr;
+  out->row_ptr = (int32_t*)(base + L.row_ptr);
+  out->chunk_ptr = (int32_t*)(base + L.chunk_ptr);
+  int32_t* total = (int32_t*)(base + L.total_cnt);
+  const int32_t R = csr->rel_total;
+  if (F == 0 || R == 0) {
+    GNNRAG_HIP(hipMemsetAsync(out->row_ptr, 0, ((size_t)R + 1) * sizeof(int32_t), stream));
+    GNNRAG_HIP(hipMemsetAsync(out->chunk_ptr, 0, ((size_t)R + 1) * sizeof(int32_t), stream));
+    out->n_chunks = 0;
+    return 0;
+  }
+  const size_t kb = align_up((size_t)F * sizeof(uint32_t), 256);
+  uint32_t* key = (uint32_t*)scratch;
+  uint32_t* key_sorted = (uint32_t*)((char*)scratch + kb);
+  int32_t* perm = (int32_t*)((char*)scratch + 2 * kb);
+  void* temp = (char*)scratch + 3 * kb;
+  const unsigned bits = key_bits((size_t)(R > 1 ? R : 2));
+  const int nb = (int)((F + 255) / 256);
+  hipLaunchKernelGGL(k_rel_key, dim3(nb), dim3(256), 0, stream, heads, rels, F, csr->N, csr->rel_off,
+                     (const int2*)csr->rel_rows, key);
+  GNNRAG_LAUNCH_CHECK();
+  rocprim::counting_iterator<int32_t> iota(0);
+  size_t tb = align_up(sort_temp_bytes(F, bits), 256);
+  GNNRAG_HIP(rocprim::radix_sort_pairs(temp, tb, (const uint32_t*)key, key_sorted, iota, perm, (size_t)F, 0u, bits,
+                                       stream, false));
+  hipLaunchKernelGGL(k_relorder_fill, dim3(nb), dim3(256), 0, stream, perm, heads, tails, w_per_fact, F,
+                     (int2*)out->ht, out->w);
+  GNNRAG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_csr_row_ptr, dim3((R + 1 + 255) / 256), dim3(256), 0, stream, key_sorted, F, (int64_t)R,
+                     out->row_ptr);
+  GNNRAG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_relorder_chunks, dim3(1), dim3(1024), 0, stream, out->row_ptr, R, out->chunk_ptr, total);
+  GNNRAG_LAUNCH_CHECK();
+  int32_t n = 0;
+  GNNRAG_HIP(hipMemcpyAsync(&n, total, sizeof(n), hipMemcpyDeviceToHost, stream));
+  GNNRAG_HIP(hipStreamSynchronize(stream));
+  out->n_chunks = n;
   return 0;
 }
 

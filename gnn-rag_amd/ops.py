@@ -93,12 +93,34 @@ class CsrPlan:
             self._w[key] = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
         return self._w[key]
 
-    def backward_workspace(self, D: int) -> torch.Tensor:
-        """Scratch of the backward kernels ((p, relation) pairs + per-question table gradients), cached."""
-        if ("bws", D) not in self._w:
-            nbytes = _lib.load().gnnrag_backward_workspace_bytes(C.byref(self.c), D)
-            self._w[("bws", D)] = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
-        return self._w[("bws", D)]
+    def relorder(self):
+        """Facts ordered by (question, relation) for the backward's gather kernels; built on first use
+        (training only).  Returns the ctypes struct (device arrays are owned by the plan)."""
+        if ("relorder",) not in self._w:
+            lib = _lib.load()
+            w = self._w.get(("w_gnn_src",))
+            with torch.cuda.device(self.device):
+                mem = torch.empty(max(lib.gnnrag_relorder_bytes(C.byref(self.c), int(w is not None)), 256),
+                                  dtype=torch.uint8, device=self.device)
+                scratch = torch.empty(max(lib.gnnrag_relorder_scratch_bytes(C.byref(self.c)), 256),
+                                      dtype=torch.uint8, device=self.device)
+                ro = _lib.RelorderStruct()
+                row = self._hrt
+                _lib.check(lib.gnnrag_relorder_build(
+                    C.byref(self.c), row[0].data_ptr(), row[1].data_ptr(), row[2].data_ptr(), _ptr(w),
+                    mem.data_ptr(), mem.numel(), scratch.data_ptr(), scratch.numel(), C.byref(ro), _stream()),
+                    "gnnrag_relorder_build")
+            self._w[("relorder",)] = (ro, mem)
+        return self._w[("relorder",)][0]
+
+    def backward_workspace(self, D: int, I: int, ro=None) -> torch.Tensor:
+        """Scratch of the backward kernels, cached per (D, I)."""
+        key = ("bws", D, I, ro is not None)
+        if key not in self._w:
+            nbytes = _lib.load().gnnrag_backward_workspace_bytes(C.byref(self.c), None if ro is None else C.byref(ro),
+                                                                 D, I)
+            self._w[key] = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+        return self._w[key]
 
     # -- lazily attached per-fact weights ----------------------------------------------------
     def _attach(self, key: str, w_per_fact, square: bool):
@@ -115,6 +137,10 @@ class CsrPlan:
                                                      out[0].data_ptr(), out[1].data_ptr(), _stream()),
                        "gnnrag_csr_permute_weight")
         self._w[key] = out
+        if key == "w_gnn":
+            if ("relorder",) in self._w:
+                raise RuntimeError("attach_w_gnn after the backward structure was built")
+            self._w[("w_gnn_src",)] = src            # original fact order: the (question, relation) ordering permutes it too
         arr = getattr(self.c, key)
         arr[0], arr[1] = out[0].data_ptr(), out[1].data_ptr()
 
@@ -313,8 +339,10 @@ def typelayer(plan: CsrPlan, T: torch.Tensor, use_w_rel: bool) -> torch.Tensor:
     return h0
 
 
-def aggregate_backward(plan: CsrPlan, dist, ins, T_fwd, T_inv, g_agg):
-    """Gradients of ``aggregate`` with respect to (dist, ins, T_fwd, T_inv)."""
+def aggregate_backward(plan: CsrPlan, dist, ins, T_fwd, T_inv, g_agg, gather: bool = True):
+    """Gradients of ``aggregate`` with respect to (dist, ins, T_fwd, T_inv).  ``gather``: table / instruction
+    gradients by the atomic-free gather over (question, relation) rows (needs D % 4 == 0, I <= 4; builds the
+    ordering on first use) instead of relation-bucketed LDS sums."""
     lib = _lib.load()
     B, N = plan.B, plan.N
     ins = _chk(ins, "ins")
@@ -327,10 +355,12 @@ def aggregate_backward(plan: CsrPlan, dist, ins, T_fwd, T_inv, g_agg):
     g_ins = torch.empty_like(ins)
     g_Tf = torch.empty_like(T_fwd)
     g_Ti = torch.empty_like(T_inv)
-    ws = plan.backward_workspace(D)
+    ro = plan.relorder() if (gather and D % 4 == 0 and I <= 4) else None
+    ws = plan.backward_workspace(D, I, ro)
     with torch.cuda.device(dist.device):
         _lib.check(lib.gnnrag_aggregate_backward(
-            C.byref(plan.c), dist.data_ptr(), ins.data_ptr(), T_fwd.data_ptr(), T_inv.data_ptr(), g_agg.data_ptr(),
+            C.byref(plan.c), None if ro is None else C.byref(ro), dist.data_ptr(), ins.data_ptr(), T_fwd.data_ptr(),
+            T_inv.data_ptr(), g_agg.data_ptr(),
             g_dist.data_ptr(), g_ins.data_ptr(), g_Tf.data_ptr(), g_Ti.data_ptr(), D, I, ws.data_ptr(), ws.numel(),
             _stream()), "gnnrag_aggregate_backward")
     return g_dist, g_ins, g_Tf, g_Ti
@@ -344,7 +374,7 @@ def typelayer_backward(plan: CsrPlan, g_pre: torch.Tensor, use_w_rel: bool) -> t
     if g_pre.shape[0] != plan.B * plan.N:
         raise ValueError("g_pre has %d rows, the plan %d nodes" % (g_pre.shape[0], plan.B * plan.N))
     g_T = torch.empty((plan.R1, D), dtype=torch.float32, device=g_pre.device)
-    ws = plan.backward_workspace(D)
+    ws = plan.backward_workspace(D, 1)
     with torch.cuda.device(g_pre.device):
         _lib.check(lib.gnnrag_typelayer_backward(C.byref(plan.c), g_pre.data_ptr(), int(use_w_rel), g_T.data_ptr(),
                                                  D, ws.data_ptr(), ws.numel(), _stream()),

@@ -165,14 +165,40 @@ int gnnrag_masked_softmax(const float* score, float* dist, int32_t B, int32_t N,
 int gnnrag_typelayer(const gnnrag_csr* csr, const float* T, int use_w_rel, float* h0,
                      int32_t D, void* workspace, size_t workspace_bytes, gnnrag_stream_t stream);
 
+/* Facts of a batch ordered by (question, relation), for the backward's table gradients: row = compact
+ * relation row of gnnrag_csr (rel_rows), facts of a row in ascending fact id, rows cut into chunks of
+ * at most 256 facts.  Built on first use (training only) from the same int32 tuple as the structure. */
+typedef struct gnnrag_relorder {
+  int64_t  F;
+  int32_t  rel_total;
+  int32_t  n_chunks;    /* host copy, filled by gnnrag_relorder_build                                */
+  int32_t* ht;          /* [F][2]  (head node, tail node) per fact in (question, relation) order     */
+  float*   w;           /* [F]     v_f^2 in that order (normalized_gnn) or NULL                      */
+  int32_t* row_ptr;     /* [rel_total+1] first position of each compact relation row                 */
+  int32_t* chunk_ptr;   /* [rel_total+1] first chunk of each row (prefix of ceil(len/256))           */
+} gnnrag_relorder;
+size_t gnnrag_relorder_bytes(const gnnrag_csr* csr, int has_w);
+size_t gnnrag_relorder_scratch_bytes(const gnnrag_csr* csr);
+/* heads/rels/tails: the tuple the structure was built from; w_per_fact: weight_list (squared inside) or
+ * NULL.  Synchronises `stream` once (n_chunks is returned in *out). */
+int gnnrag_relorder_build(const gnnrag_csr* csr, const int32_t* heads, const int32_t* rels,
+                          const int32_t* tails, const float* w_per_fact,
+                          void* mem, size_t mem_bytes, void* scratch, size_t scratch_bytes,
+                          gnnrag_relorder* out, gnnrag_stream_t stream);
+
 /* Backward of gnnrag_aggregate (what autograd derives for reasongnn.py:61-116), so that training
  * (train_model.py:209-233) runs on the HIP operator.  g_agg [BN,2I*D] is the gradient of agg;
  *   g_dist [BN], g_ins [B,I,D], g_T_fwd / g_T_inv [R1,D]  are fully written (not accumulated into).
- * Sums use hardware fp32 atomics: reproducible to rounding, not bit for bit.
- * GNNRAG_E_UNSUPPORTED when one question uses more relations than one CU's LDS holds (~1200).
- * workspace: gnnrag_backward_workspace_bytes(csr, D) bytes of device scratch.  D <= 1024. */
-size_t gnnrag_backward_workspace_bytes(const gnnrag_csr* csr, int32_t D);
-int gnnrag_aggregate_backward(const gnnrag_csr* csr, const float* dist, const float* ins,
+ * relorder != NULL (and D % 4 == 0, I <= 4): the table / instruction gradients are gathered over the
+ * facts of each (question, relation) row - no atomics, one fixed summation order, any number of
+ * relations per question.  relorder == NULL: relation-bucketed sums in LDS (ds_add_f32; reproducible
+ * to rounding only; GNNRAG_E_UNSUPPORTED when one question uses more relations than one CU's LDS
+ * holds, ~1200).  g_dist of rows with > 256 facts is summed with one atomic per 64-fact piece.
+ * workspace: gnnrag_backward_workspace_bytes(csr, relorder, D, I) bytes of device scratch.  D <= 1024. */
+size_t gnnrag_backward_workspace_bytes(const gnnrag_csr* csr, const gnnrag_relorder* relorder, int32_t D,
+                                       int32_t I);
+int gnnrag_aggregate_backward(const gnnrag_csr* csr, const gnnrag_relorder* relorder,
+                              const float* dist, const float* ins,
                               const float* T_fwd, const float* T_inv, const float* g_agg,
                               float* g_dist, float* g_ins, float* g_T_fwd, float* g_T_inv,
                               int32_t D, int32_t I, void* workspace, size_t workspace_bytes,
