@@ -170,6 +170,10 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        # RCCL writes its version banner to C stdio (flushed at exit): flush it now so the JSON line is the last one
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
         print(json.dumps(out))
 
 
