@@ -72,10 +72,13 @@ def gather_rows(local: torch.Tensor, B: int, group: Optional[dist.ProcessGroup] 
         raise ValueError("rank %d holds %d rows, expected %d" % (rank, local.shape[0], hi - lo))
     rows = (B + world - 1) // world
     tail = tuple(local.shape[1:])
-    send = local.new_zeros((rows,) + tail)
-    send[: hi - lo] = local
+    if hi - lo == rows:
+        send = local.contiguous()                        # even split: the shard goes out as it is
+    else:
+        send = local.new_zeros((rows,) + tail)
+        send[: hi - lo] = local
     recv = local.new_empty((world * rows,) + tail)
-    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    dist.all_gather_into_tensor(recv, send, group=group)
     if B % world == 0:
         return recv
     parts = []
