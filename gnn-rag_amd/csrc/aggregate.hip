@@ -39,6 +39,13 @@
                                  // (4 per node and slice) lose to the gather walk's full 3200-byte rows, so it is off
 #endif
 
+#ifndef GNNRAG_SLICE_HALFSTEP
+#define GNNRAG_SLICE_HALFSTEP 1     // LDS walk: facts 4..7 of a step are skipped when no node of the set has them (-2.5 us)
+#endif
+#ifndef GNNRAG_SLICE_SPLIT_TAIL
+#define GNNRAG_SLICE_SPLIT_TAIL 1   // LDS walk: work items of the last, partial round of workgroup slots are cut in two
+#endif
+
 namespace gnnrag {
 
 template <int VEC> struct VecT;
@@ -565,7 +572,7 @@ __device__ __forceinline__ float* slice_out(const WalkArgs& a, int n, int i, int
 // accumulators allow (one float4 per lane in FUSED mode).
 template <int MODE, int NI>
 __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k_walk_slice(const WalkArgs a, const int2* __restrict__ pr,
-                                                              int64_t F, int nslice) {
+                                                              int64_t F, int nslice, int nfull) {
   typedef SliceAcc<MODE, NI> Acc;
   constexpr int NA = Acc::n;
   constexpr int ND = (MODE == MODE_REASON) ? 2 : 1;     // output slots per node: per direction / summed
@@ -574,11 +581,21 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
   int* ctl = reinterpret_cast<int*>(s_mem + (size_t)2 * a.R1 * kSliceW);   // [0] the ticket
   int* blist = ctl + 16;                               // [kSliceBigCap][5]: node, beg0, len0, beg1, len1
   float* red = reinterpret_cast<float*>(blist + 5 * kSliceBigCap);   // [16 waves][NA][16 floats]
-  // XCD-aware order: the nslice workgroups of question g all land on XCD g % 8
+  // XCD-aware order: the nslice workgroups of question g all land on XCD g % 8.  An XCD's work items
+  // (question, slice) are dispatched in order; the first nfull fill whole rounds of its workgroup slots, the
+  // rest (the last, partial round) are cut in two halves of the question's nodes so that the tail of the
+  // launch is made of half-length workgroups.
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int g = (slot / nslice) * 8 + xcd;
+  int item = slot, part = 0, nparts = 1;
+  if (slot >= nfull) {
+    const int hslot = slot - nfull;
+    item = nfull + (hslot >> 1);
+    part = hslot & 1;
+    nparts = 2;
+  }
+  const int g = (item / nslice) * 8 + xcd;
   if (g >= a.B) return;
-  const int c = slot % nslice;
+  const int c = item % nslice;
   const int col0 = c * kSliceW;
   const int D = a.D, N = a.N;
   // rows of this question's tables: FUSED tables hold only the relations the question uses
@@ -636,6 +653,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
     for (int h = 0; h < nlist; ++h) {
       const int* e = blist + 5 * h;
       if (e[2] <= kSliceTeamDeg && e[4] <= kSliceTeamDeg) continue;     // workgroup-uniform
+      if ((h & (nparts - 1)) != part) continue;                         // the other half's node
       Acc acc;
       acc.zero();
 #pragma unroll
@@ -673,9 +691,10 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
       int t = 0;
       if (lane == 0) t = atomicAdd(&ctl[0], 1);
       t = __builtin_amdgcn_readfirstlane(t);
-      if (t >= nlist) return t - nlist;
+      if (t >= nlist) return (t - nlist) * nparts + part;               // this half's sets: part, part + nparts, ...
       const int* e = blist + 5 * t;
       if (e[2] > kSliceTeamDeg || e[4] > kSliceTeamDeg) continue;       // huge: already walked
+      if ((t & (nparts - 1)) != part) continue;                         // the other half's node
       Acc acc;
       acc.zero();
 #pragma unroll
@@ -720,7 +739,9 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
           if (j + 8 + sub < len) n0 = prd[d][beg + j + 8 + sub];
           if (j + 12 + sub < len) n1 = prd[d][beg + j + 12 + sub];
           slice_fma4<MODE, NI>(acc, c0, Td[d], q);
-          slice_fma4<MODE, NI>(acc, c1, Td[d], q);
+          // second half of the step only if some node of the set still has facts there (most rows of the
+          // inverse direction hold one or two facts)
+          if (!GNNRAG_SLICE_HALFSTEP || __ballot(j + 4 < len)) slice_fma4<MODE, NI>(acc, c1, Td[d], q);
           c0 = n0;
           c1 = n1;
         }
@@ -881,9 +902,20 @@ static int launch_slice(const WalkArgs& a, const gnnrag_csr* csr, void* workspac
                                    160 * 1024));
     attr_set = true;
   }
-  const int nblk = 8 * ((csr->B + 7) / 8) * nslice;
+  // per XCD: items = (questions of the XCD) x slices, slots = 2 workgroups on each of its CUs
+  static int slots_per_xcd = 0;
+  if (!slots_per_xcd) {
+    int dev = 0, cus = 0;
+    GNNRAG_HIP(hipGetDevice(&dev));
+    GNNRAG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    slots_per_xcd = cus >= 8 ? 2 * (cus / 8) : 2;
+  }
+  const int items_x = ((csr->B + 7) / 8) * nslice;
+  const int rem = items_x % slots_per_xcd;
+  const int nfull = (GNNRAG_SLICE_SPLIT_TAIL && rem != 0) ? items_x - rem : items_x;
+  const int nblk = 8 * (nfull + 2 * (items_x - nfull));
   hipLaunchKernelGGL((k_walk_slice<MODE, NI>), dim3(nblk), dim3(kSliceThreads), lds, stream, a, (const int2*)pr, F,
-                     nslice);
+                     nslice, nfull);
   GNNRAG_LAUNCH_CHECK();
   return 0;   // hubs were walked inside the kernel, nothing to add afterwards
 }

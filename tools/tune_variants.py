@@ -13,12 +13,14 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
-# name -> extra -D switches.  Switches that exist today: GNNRAG_REASON_SLICE (aggregate.hip),
-# GNNRAG_GEMM_MT1_NW (gemm_f32.hip).  Add a macro to the kernel source, list its values here, run.
+# name -> extra -D switches.  Switches that exist today: GNNRAG_REASON_SLICE, GNNRAG_SLICE_SPLIT_TAIL,
+# GNNRAG_SLICE_HALFSTEP (aggregate.hip), GNNRAG_GEMM_MT1_NW (gemm_f32.hip).  Add a macro to the kernel source, list its values here, run.
 VARIANTS = {
     "default": {},
     "reason_slice": {"GNNRAG_REASON_SLICE": 1},
     "gemm_nw4": {"GNNRAG_GEMM_MT1_NW": 4},
+    "no_split_tail": {"GNNRAG_SLICE_SPLIT_TAIL": 0},
+    "no_halfstep": {"GNNRAG_SLICE_HALFSTEP": 0},
 }
 
 CHILD = r'''
@@ -44,7 +46,12 @@ with torch.no_grad():
     nbr = ops.aggregate_fused(layer.plan, dense, P)
     agg = ops.aggregate(layer.plan, dense, devin.ins[0], Tf, Ti)
     ms = {}
-    for math in (0, 1):
+    seed = devin.seed_dist
+    for name, prior in (("aggf_dense", dense), ("aggf_seed", seed)):
+        fn = lambda: ops.aggregate_fused(layer.plan, prior, P)
+        fn()
+        ms[name] = float(np.mean(bench._events_ms(fn, 20)))
+    for math in ((0, 1) if os.environ.get("GNNRAG_TUNE_GEMM") else ()):
         ops.set_dense_math(math)
         fns = {"tables": lambda: ops.relation_tables(layer.plan, Tf, Ti, devin.ins[0], e2e.weight),
                "upd": lambda: ops.update_score(h, agg, e2e.weight, e2e.bias, sf.weight, sf.bias, layer.local_entity_mask, I),
