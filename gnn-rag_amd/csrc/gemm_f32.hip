@@ -33,6 +33,7 @@
 namespace gnnrag {
 
 constexpr int kBK = 32;    // k per LDS tile
+constexpr int kSkinnyMaxM = 16384;   // up to here a problem runs on k_gemm_skinny (one wave per 16 x 64 tile, no LDS)
 
 enum { EPI_LINEAR = 0, EPI_UPDATE = 1 };
 
@@ -518,7 +519,7 @@ static int launch_gemm(GemmArgs g, hipStream_t stream) {
                   aligned16(g.A0) && aligned16(g.W) && (g.A1 == nullptr || aligned16(g.A1)) &&
                   (g.C_b == nullptr || aligned16(g.A0b)) &&
                   (AMODE != AMODE_GEN || g.gen_D % 4 == 0);
-  if (EPI == EPI_LINEAR && AMODE == AMODE_PLAIN && g.M <= 4096 && g.n0 == 0) {
+  if (EPI == EPI_LINEAR && AMODE == AMODE_PLAIN && g.M <= kSkinnyMaxM && g.n0 == 0) {
     const dim3 grid((g.M + 15) / 16, (g.Nout + 255) / 256, g.C_b ? 2 : 1);
     if (v4) hipLaunchKernelGGL((k_gemm_skinny<true>), grid, dim3(256), 0, stream, g);
     else hipLaunchKernelGGL((k_gemm_skinny<false>), grid, dim3(256), 0, stream, g);
@@ -625,7 +626,7 @@ extern "C" int gnnrag_linear_pair(const float* A0, const float* A1, int64_t M, i
                                   float* C0, float* C1, int32_t Nout, gnnrag_stream_t stream) {
   if (!A0 || !A1 || !W || !C0 || !C1 || M < 0 || K <= 0 || Nout <= 0) return GNNRAG_E_BADARG;
   if ((add0 == nullptr) != (add1 == nullptr)) return GNNRAG_E_BADARG;
-  if (M > 4096) {            // large problems: two ordinary launches
+  if (M > kSkinnyMaxM) {     // large problems: two ordinary launches
     int rc = gnnrag_linear(A0, M, K, W, bias, add0, add_rows, 0, C0, Nout, stream);
     if (rc) return rc;
     return gnnrag_linear(A1, M, K, W, bias, add1, add_rows, 0, C1, Nout, stream);
