@@ -221,3 +221,24 @@ def test_training_step_matches_reference_autograd(reference_setup, monkeypatch):
     for k in g_ref:
         scale = max(float(g_ref[k].abs().max()), 1e-4)
         assert float((g[k] - g_ref[k]).abs().max()) <= 2e-4 * scale, k
+
+
+def test_launcher_substitutes_everything_then_refuses_the_cpu(tmp_path):
+    """tools/run_reference.py drives the reference's own main.py: modules, loaders and evaluator are
+    substituted; there is no GPU here, so the first batch must fail loudly with the no-CPU-fallback error
+    (and not silently run the reference's own layers)."""
+    import subprocess
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden
+    folder = str(tmp_path / "synth") + "/"
+    make_golden.write_dataset(folder, np.random.default_rng(3), n_ent=80, n_rel=7, n_q=6)
+    n_word = sum(1 for _ in open(os.path.join(folder, "vocab.txt")))
+    np.save(os.path.join(folder, "word_emb.npy"), np.random.default_rng(4).standard_normal((n_word, 12)).astype(np.float32))
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(repo, "tools", "run_reference.py"), REF, "ReaRev", "--data_folder", folder,
+           "--lm", "lstm", "--relation_word_emb", "False", "--entity_dim", "16", "--kg_dim", "8", "--word_dim", "12",
+           "--num_epoch", "1", "--batch_size", "2", "--checkpoint_dir", str(tmp_path) + "/", "--experiment_name", "t",
+           "--name", "synth"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "no CPU fallback" in r.stderr or "runs on the GPU only" in r.stderr, r.stderr[-1500:]

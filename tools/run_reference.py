@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Runs the UNMODIFIED reference entry point (GNN-RAG ``gnn/main.py``) with the MI355X path underneath.
+
+    python tools/run_reference.py /path/to/GNN-RAG/gnn  ReaRev --is_eval --load_experiment X.ckpt ... (main.py's own flags)
+
+What is substituted, all without touching a reference file:
+  * ``modules.kg_reasoning.{reasongnn,base_gnn,nsm_gnn}``, ``modules.layer_init``, ``modules.query_update``
+    -> this package's modules (``gnnrag_amd.install.install()``, before the reference imports its models);
+  * every data loader the reference creates -> vectorised / cached ``_build_fact_mat``
+    (``gnnrag_amd.data.fact_mat.patch_loader``; skip with GNNRAG_NO_LOADER_PATCH=1);
+  * ``Evaluator.evaluate`` -> device-side candidate selection (``gnnrag_amd.eval_tail``; skip with
+    GNNRAG_NO_EVAL_PATCH=1).
+Needs a GPU (the package has no CPU path); the reference's own two start-up bugs (an undefined
+``create_parser_nutrea`` in ``parsing.py``; ``LSTMInstruction`` not passing ``constraint``)
+are shimmed exactly as the tests do."""
+import os
+import runpy
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    if len(sys.argv) < 2 or not os.path.isfile(os.path.join(sys.argv[1], "main.py")):
+        raise SystemExit(__doc__)
+    ref = os.path.abspath(sys.argv[1])
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, ref)
+    os.chdir(ref)
+    import gnnrag_amd  # noqa: F401
+    from gnnrag_amd import install
+    install.install()
+
+    import parsing
+    if not hasattr(parsing, "create_parser_nutrea"):
+        parsing.create_parser_nutrea = lambda p: None
+
+    # second reference bug: LSTMInstruction calls BaseInstruction.__init__(args) without the
+    # `constraint` argument the base class requires; give it the default the other encoders pass
+    from modules.question_encoding import base_encoder
+    _orig_init = base_encoder.BaseInstruction.__init__
+
+    def _init(self, args, constraint=False):
+        _orig_init(self, args, constraint)
+    base_encoder.BaseInstruction.__init__ = _init
+
+    if not os.environ.get("GNNRAG_NO_LOADER_PATCH"):
+        import dataset_load
+        from gnnrag_amd.data.fact_mat import patch_loader
+        orig_load = dataset_load.load_data
+
+        def load_data(*a, **kw):
+            dataset = orig_load(*a, **kw)
+            for split in ("train", "valid", "test"):
+                if dataset.get(split) is not None:
+                    patch_loader(dataset[split], cache=(split != "train"))     # training permutes / drops facts
+            return dataset
+
+        dataset_load.load_data = load_data
+
+    if not os.environ.get("GNNRAG_NO_EVAL_PATCH"):
+        import evaluate
+        from gnnrag_amd import eval_tail
+        evaluate.Evaluator.evaluate = eval_tail.evaluate
+
+    sys.argv = [os.path.join(ref, "main.py")] + sys.argv[2:]
+    runpy.run_path(os.path.join(ref, "main.py"), run_name="__main__")
+
+
+if __name__ == "__main__":
+    main()
