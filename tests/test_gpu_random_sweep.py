@@ -1,0 +1,74 @@
+"""Seeded random shapes through the whole stack (structure, both forward paths, backward) against the float64
+oracles: odd N / D / I combinations, questions without facts, duplicate facts, large and tiny relation
+vocabularies, normalised and unnormalised weights."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+RTOL = 5e-6       # unnormalised hub sums reach 10^2: fp32 rounding of a few hundred terms is relative
+
+
+def _random_cfg(rng, k):
+    from gnnrag_amd import synth
+    D = int(rng.choice([8, 20, 48, 64, 100, 132, 200, 260]))
+    N = int(rng.integers(3, 90))
+    return synth.GraphConfig(
+        name="rand%d" % k, B=int(rng.integers(1, 6)), N=N, E=int(rng.integers(0, 6 * N)), R=int(rng.choice([1, 3, 17, 300, 2500])),
+        D=D, I=int(rng.integers(1, 6)), L=2, T=1, seed=int(rng.integers(1, 10 ** 6)),
+        zipf_heads=bool(rng.integers(0, 2)), self_loop=bool(rng.integers(0, 4) > 0),
+        normalized_gnn=bool(rng.integers(0, 2)), pos_emb=bool(rng.integers(0, 2)),
+        n_real_min=0 if rng.integers(0, 3) == 0 else None,
+        rel_per_question=int(rng.integers(2, 40)) if rng.integers(0, 2) else None)
+
+
+@pytest.mark.parametrize("k", range(48))
+def test_random_shape(k):
+    import gnnrag_amd  # noqa: F401
+    import oracle.rearev_grad as og
+    import oracle.rearev_np64 as onp
+    from gnnrag_amd import ops, stack, synth
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(1000 + k)
+    cfg = _random_cfg(rng, k)
+    batch = synth.make_batch(cfg)
+    if k % 4 == 1 and batch.F > 4:                      # duplicate a few facts (the reference sums them twice too)
+        et = list(batch.edge_tuple)
+        dup = rng.integers(0, batch.F, size=3)
+        for i in range(3):
+            et[i] = np.concatenate([et[i], et[i][dup]])
+        et[3] = np.concatenate([et[3], et[3][dup]])
+        et[4] = np.arange(len(et[0]), dtype=np.int64)
+        et[5], et[6] = synth.edge_weights(et[0], et[1], cfg.R1)
+        batch.edge_tuple = tuple(et)
+    feats = synth.make_features(cfg)
+    params = synth.make_layer_params(cfg)
+    want = onp.run_stack(batch, feats, params, use_type_layer=True, norm_rel=cfg.normalized_gnn)
+    for path in (1, 2):
+        got = stack.run_stack(batch, feats, params, dev, use_type_layer=True, norm_rel=cfg.normalized_gnn, path=path)
+        np.testing.assert_allclose(got["h0"], want["h0"], rtol=RTOL, atol=TOL, err_msg="%s h0" % cfg)
+        for c in range(cfg.T * cfg.L):
+            np.testing.assert_allclose(got["h"][c], want["h"][c], rtol=RTOL, atol=TOL, err_msg="%s h %d path %d" % (cfg, c, path))
+            np.testing.assert_allclose(got["dist"][c], want["dist"][c], rtol=RTOL, atol=TOL,
+                                       err_msg="%s dist %d path %d" % (cfg, c, path))
+    # backward of the aggregation, both forms
+    B, N, D, I = cfg.B, cfg.N, cfg.D, cfg.I
+    et = batch.edge_tuple
+    T_f = rng.standard_normal((cfg.R1, D)).astype(np.float32)
+    T_i = rng.standard_normal((cfg.R1, D)).astype(np.float32)
+    ins = rng.standard_normal((B, I, D)).astype(np.float32)
+    g_agg = rng.standard_normal((B * N, 2 * I * D)).astype(np.float32)
+    prior = rng.random((B, N)).astype(np.float32)
+    plan = ops.CsrPlan(et[0], et[1], et[2], B, N, cfg.R1, dev)
+    weight = None
+    if cfg.normalized_gnn:
+        plan.attach_w_gnn(et[5])
+        weight = et[5]
+    _, gd_w, gi_w, gtf_w, gti_w = og.aggregate_grads(et, B, N, prior, ins, T_f, T_i, g_agg, weight)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for gather in (True, False):
+        gd, gi, gtf, gti = ops.aggregate_backward(plan, t(prior), t(ins), t(T_f), t(T_i), t(g_agg), gather=gather)
+        for name, got_t, want_a in (("g_dist", gd, gd_w), ("g_ins", gi, gi_w), ("g_T_fwd", gtf, gtf_w), ("g_T_inv", gti, gti_w)):
+            np.testing.assert_allclose(got_t.cpu().numpy(), want_a, rtol=0, atol=TOL * max(np.abs(want_a).max(), 1e-6),
+                                       err_msg="%s %s gather=%s" % (cfg, name, gather))
