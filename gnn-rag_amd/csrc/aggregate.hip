@@ -39,6 +39,9 @@
                                  // (4 per node and slice) lose to the gather walk's full 3200-byte rows, so it is off
 #endif
 
+#ifndef GNNRAG_SLICE_WIDE
+#define GNNRAG_SLICE_WIDE 1         // LDS walk: 32-column slices for questions whose tables allow two of them per CU
+#endif
 #ifndef GNNRAG_SLICE_HALFSTEP
 #define GNNRAG_SLICE_HALFSTEP 1     // LDS walk: facts 4..7 of a step are skipped when no node of the set has them (-2.5 us)
 #endif
@@ -496,10 +499,15 @@ __device__ __forceinline__ int quad_bcast(int v) {
   return __builtin_amdgcn_mov_dpp(v, K * 0x55, 0xf, 0xf, true);
 }
 
-// Per-lane accumulators of the LDS walk: FUSED sums both directions into one float4; REASON keeps
-// NI float4 (one per instruction) per direction and applies relu(t * q_i) per fact.
+// Per-lane accumulators of the LDS walk.  REASON: NI float4 (one per instruction) per direction, relu(t * q_i)
+// applied per fact, 16-column slices.  FUSED: both directions summed; NI = number of 16-column groups of the
+// slice a lane owns (NI = 2: 32-column slices - half as many workgroups re-walk the question's facts; used
+// when a question's relation tables are small enough for two 32-column slices per CU).
 template <int MODE, int NI> struct SliceAcc {
-  static constexpr int n = (MODE == MODE_REASON) ? NI : 1;
+  static constexpr int n = NI;
+  static constexpr int width = (MODE == MODE_REASON) ? kSliceW : kSliceW * NI;    // floats per table row in LDS
+  // column offset of accumulator i inside the slice
+  static constexpr int coff(int i) { return (MODE == MODE_REASON) ? 0 : kSliceW * i; }
   f32x4 v[n];
   __device__ __forceinline__ void zero() {
 #pragma unroll
@@ -516,11 +524,13 @@ __device__ __forceinline__ void slice_fma4(SliceAcc<MODE, NI>& acc, int2 pairs, 
     const float pk = __int_as_float(quad_bcast<K>(pairs.x));                                        \
     const int rk = quad_bcast<K>(pairs.y);                                                          \
     if (pk != 0.f) {                                                                                \
-      const f32x4 t = *reinterpret_cast<const f32x4*>(Td + (size_t)rk * kSliceW);                   \
+      const float* trow = Td + (size_t)rk * SliceAcc<MODE, NI>::width;                             \
       if constexpr (MODE == MODE_REASON) {                                                          \
+        const f32x4 t = *reinterpret_cast<const f32x4*>(trow);                                      \
         _Pragma("unroll") for (int i = 0; i < NI; ++i) acc.v[i] += pk * vrelu(t * q[i]);            \
       } else {                                                                                      \
-        acc.v[0] += pk * t;                                                                         \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i)                                              \
+          acc.v[i] += pk * *reinterpret_cast<const f32x4*>(trow + kSliceW * i);                     \
       }                                                                                             \
     }                                                                                               \
   }
@@ -529,22 +539,23 @@ __device__ __forceinline__ void slice_fma4(SliceAcc<MODE, NI>& acc, int2 pairs, 
 }
 
 // one direction of one row, walked by a whole wave: 64 facts per step (lane group k owns facts
-// 4k..4k+3 of a step), steps first, first+stride, ...; up to 8 steps requested before consuming
+// 4k..4k+3 of a step), steps first, first+stride, ...; up to 8 (wide slices: 4) steps requested before consuming
 template <int MODE, int NI>
 __device__ __forceinline__ void slice_walk_wave(SliceAcc<MODE, NI>& acc, const int2* __restrict__ prd, int beg,
                                                 int len, int first, int stride, int lane,
                                                 const float* __restrict__ Td,
                                                 const f32x4 (&q)[SliceAcc<MODE, NI>::n]) {
   const int nsteps = (len + 63) >> 6;
-  for (int st = first; st < nsteps; st += stride * 8) {
-    int2 pairs[8];
+  constexpr int INF = (SliceAcc<MODE, NI>::n > 1 && MODE == MODE_FUSED) ? 4 : 8;   // steps in flight (register budget)
+  for (int st = first; st < nsteps; st += stride * INF) {
+    int2 pairs[INF];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < INF; ++u) {
       const int off = (st + stride * u) * 64 + lane;
       pairs[u] = (off < len) ? prd[beg + off] : make_int2(0, 0);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) slice_fma4<MODE, NI>(acc, pairs[u], Td, q);
+    for (int u = 0; u < INF; ++u) slice_fma4<MODE, NI>(acc, pairs[u], Td, q);
   }
 }
 
@@ -578,7 +589,8 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
   constexpr int ND = (MODE == MODE_REASON) ? 2 : 1;     // output slots per node: per direction / summed
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
   float* Ts = s_mem;                                   // [2][Rg][16] (room for [2][R1][16])
-  int* ctl = reinterpret_cast<int*>(s_mem + (size_t)2 * a.R1 * kSliceW);   // [0] the ticket
+  constexpr int SW = Acc::width;                       // floats per staged table row
+  int* ctl = reinterpret_cast<int*>(s_mem + (size_t)2 * a.R1 * SW);   // [0] the ticket
   int* blist = ctl + 16;                               // [kSliceBigCap][5]: node, beg0, len0, beg1, len1
   float* red = reinterpret_cast<float*>(blist + 5 * kSliceBigCap);   // [16 waves][NA][16 floats]
   // XCD-aware order: the nslice workgroups of question g all land on XCD g % 8.  An XCD's work items
@@ -596,7 +608,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
   const int g = (item / nslice) * 8 + xcd;
   if (g >= a.B) return;
   const int c = item % nslice;
-  const int col0 = c * kSliceW;
+  const int col0 = c * SW;
   const int D = a.D, N = a.N;
   // rows of this question's tables: FUSED tables hold only the relations the question uses
   int Rg = a.R1, roff = 0;
@@ -622,28 +634,31 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
   }
   // stage the two table slices (float4 granules; rows are D*4 bytes apart).  FUSED: the question's own
   // tables P[d, g]; REASON: the shared tables T_d
-  for (int idx = tid; idx < 2 * Rg * 4; idx += kSliceThreads) {
-    const int d = idx >= Rg * 4;
-    const int rem = idx - d * (Rg * 4);
-    const int r = rem >> 2, k = rem & 3;
+  constexpr int GR = SW / 4;                           // float4 granules per staged row
+  for (int idx = tid; idx < 2 * Rg * GR; idx += kSliceThreads) {
+    const int d = idx >= Rg * GR;
+    const int rem = idx - d * (Rg * GR);
+    const int r = rem / GR, k = rem % GR;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     const float* tab = a.T[d] + (size_t)roff * D;
     if (col0 + 4 * k < D) v = *reinterpret_cast<const f32x4*>(tab + (size_t)r * D + col0 + 4 * k);
-    *reinterpret_cast<f32x4*>(Ts + ((size_t)d * Rg + r) * kSliceW + 4 * k) = v;
+    *reinterpret_cast<f32x4*>(Ts + ((size_t)d * Rg + r) * SW + 4 * k) = v;
   }
   __syncthreads();
 
   const int lane = tid & 63, wave = tid >> 6;
   const int grp = lane >> 2, sub = lane & 3;
   const int nsets = (N + 15) / 16;
-  const bool col_ok = col0 + 4 * sub < D;
+  bool col_ok[NA];                                     // accumulator i covers columns col0 + coff(i) + 4*sub .. +3
+#pragma unroll
+  for (int i = 0; i < NA; ++i) col_ok[i] = col0 + Acc::coff(i) + 4 * sub < D;
   const int2* const prd[2] = {pr, pr + F};
-  const float* Td[2] = {Ts + 4 * sub, Ts + (size_t)Rg * kSliceW + 4 * sub};
+  const float* Td[2] = {Ts + 4 * sub, Ts + (size_t)Rg * SW + 4 * sub};
   f32x4 q[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     q[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (MODE == MODE_REASON && col_ok)
+    if (MODE == MODE_REASON && col_ok[i])
       q[i] = *reinterpret_cast<const f32x4*>(a.ins + ((size_t)g * a.I + a.i0 + i) * D + col0 + 4 * sub);
   }
 
@@ -671,7 +686,8 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
             f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int w = 0; w < 16; ++w) t += *reinterpret_cast<const f32x4*>(red + (w * NA + i) * 16 + 4 * sb);
-            if (col0 + 4 * sb < D) *reinterpret_cast<f32x4*>(slice_out<MODE>(a, e[0], i, d, col0 + 4 * sb)) = t;
+            const int cc = col0 + Acc::coff(i) + 4 * sb;
+            if (cc < D) *reinterpret_cast<f32x4*>(slice_out<MODE>(a, e[0], i, d, cc)) = t;
           }
           __syncthreads();
           acc.zero();
@@ -702,10 +718,11 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
         slice_walk_wave<MODE, NI>(acc, prd[d], e[1 + 2 * d], e[2 + 2 * d], 0, 1, lane, Td[d], q);
         if (ND == 2 || d == 1) {
           slice_wave_reduce<MODE, NI>(acc);
-          if (grp == 0 && col_ok) {
+          if (grp == 0) {
 #pragma unroll
             for (int i = 0; i < NA; ++i)
-              *reinterpret_cast<f32x4*>(slice_out<MODE>(a, e[0], i, d, col0 + 4 * sub)) = acc.v[i];
+              if (col_ok[i])
+                *reinterpret_cast<f32x4*>(slice_out<MODE>(a, e[0], i, d, col0 + Acc::coff(i) + 4 * sub)) = acc.v[i];
           }
           acc.zero();
         }
@@ -746,11 +763,10 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
           c1 = n1;
         }
         if (ND == 2 || d == 1) {
-          if (col_ok) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i)
-              *reinterpret_cast<f32x4*>(slice_out<MODE>(a, s0.n, i, d, col0 + 4 * sub)) = acc.v[i];
-          }
+          for (int i = 0; i < NA; ++i)
+            if (col_ok[i])
+              *reinterpret_cast<f32x4*>(slice_out<MODE>(a, s0.n, i, d, col0 + Acc::coff(i) + 4 * sub)) = acc.v[i];
           acc.zero();
         }
       }
@@ -845,8 +861,8 @@ static size_t partial_bytes(const gnnrag_csr* csr, int D, int na) {
 static size_t prior_bytes(const gnnrag_csr* csr) {
   return align_up((size_t)2 * (size_t)(csr->F > 0 ? csr->F : 1) * sizeof(int2), 256);
 }
-static size_t slice_lds_bytes(int R1, int na = 3) {
-  return (size_t)2 * R1 * kSliceW * sizeof(float) + (16 + 5 * kSliceBigCap) * sizeof(int) +
+static size_t slice_lds_bytes(int R1, int na = 3, int width = kSliceW) {
+  return (size_t)2 * R1 * width * sizeof(float) + (16 + 5 * kSliceBigCap) * sizeof(int) +
          (size_t)na * 16 * 16 * sizeof(float);
 }
 // the LDS variant needs the two table slices of a question in one CU's LDS (160 KB); rows = table rows
@@ -894,8 +910,9 @@ static int launch_slice(const WalkArgs& a, const gnnrag_csr* csr, void* workspac
                        a.edge[1], a.w[0], a.w[1], a.dist, F, pr);
     GNNRAG_LAUNCH_CHECK();
   }
-  const int nslice = (D + kSliceW - 1) / kSliceW;
-  const size_t lds = slice_lds_bytes(a.R1, SliceAcc<MODE, NI>::n);
+  constexpr int SW = SliceAcc<MODE, NI>::width;
+  const int nslice = (D + SW - 1) / SW;
+  const size_t lds = slice_lds_bytes(a.R1, SliceAcc<MODE, NI>::n, SW);
   static bool attr_set = false;   // raising the dynamic-LDS cap is idempotent; once per kernel and process
   if (!attr_set) {
     GNNRAG_HIP(hipFuncSetAttribute((const void*)k_walk_slice<MODE, NI>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -983,6 +1000,10 @@ extern "C" int gnnrag_aggregate_fused(const gnnrag_csr* csr, const float* dist, 
   a.out = out;
   a.I = 1;
   if (!slice_walk_fits(csr->rel_max, D)) return launch_walk<MODE_FUSED>(a, 1, stream);   // tables too big for LDS
+  // 32-column slices when two of them still fit a CU's LDS (questions that use up to ~300 relations): half as
+  // many workgroups re-walk the question's facts
+  if (GNNRAG_SLICE_WIDE && D > kSliceW && slice_lds_bytes(csr->rel_max, 2, 2 * kSliceW) <= 79 * 1024)
+    return launch_slice<MODE_FUSED, 2>(a, csr, workspace, workspace_bytes, 1, stream);
   return launch_slice<MODE_FUSED, 1>(a, csr, workspace, workspace_bytes, 1, stream);
 }
 
