@@ -42,6 +42,9 @@
 #ifndef GNNRAG_SLICE_WIDE
 #define GNNRAG_SLICE_WIDE 1         // LDS walk: 32-column slices for questions whose tables allow two of them per CU
 #endif
+#ifndef GNNRAG_SLICE_WIDE_LDS_KB
+#define GNNRAG_SLICE_WIDE_LDS_KB 79   // ... as long as two wide workgroups fit one CU's 160 KB
+#endif
 #ifndef GNNRAG_SLICE_HALFSTEP
 #define GNNRAG_SLICE_HALFSTEP 1     // LDS walk: facts 4..7 of a step are skipped when no node of the set has them (-2.5 us)
 #endif
@@ -1002,7 +1005,7 @@ extern "C" int gnnrag_aggregate_fused(const gnnrag_csr* csr, const float* dist, 
   if (!slice_walk_fits(csr->rel_max, D)) return launch_walk<MODE_FUSED>(a, 1, stream);   // tables too big for LDS
   // 32-column slices when two of them still fit a CU's LDS (questions that use up to ~300 relations): half as
   // many workgroups re-walk the question's facts
-  if (GNNRAG_SLICE_WIDE && D > kSliceW && slice_lds_bytes(csr->rel_max, 2, 2 * kSliceW) <= 79 * 1024)
+  if (GNNRAG_SLICE_WIDE && D > kSliceW && slice_lds_bytes(csr->rel_max, 2, 2 * kSliceW) <= GNNRAG_SLICE_WIDE_LDS_KB * 1024)
     return launch_slice<MODE_FUSED, 2>(a, csr, workspace, workspace_bytes, 1, stream);
   return launch_slice<MODE_FUSED, 1>(a, csr, workspace, workspace_bytes, 1, stream);
 }

@@ -21,6 +21,7 @@ VARIANTS = {
     "gemm_nw4": {"GNNRAG_GEMM_MT1_NW": 4},
     "no_split_tail": {"GNNRAG_SLICE_SPLIT_TAIL": 0},
     "no_halfstep": {"GNNRAG_SLICE_HALFSTEP": 0},
+    "wide_always": {"GNNRAG_SLICE_WIDE_LDS_KB": 159},
 }
 
 CHILD = r'''
