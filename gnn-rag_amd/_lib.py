@@ -36,7 +36,8 @@ class CsrStruct(C.Structure):
 class RelorderStruct(C.Structure):
     """Mirror of ``struct gnnrag_relorder`` (include/gnnrag.h)."""
     _fields_ = [("F", C.c_int64), ("rel_total", C.c_int32), ("n_chunks", C.c_int32),
-                ("ht", C.c_void_p), ("w", C.c_void_p), ("row_ptr", C.c_void_p), ("chunk_ptr", C.c_void_p)]
+                ("ht", C.c_void_p), ("perm", C.c_void_p), ("w", C.c_void_p), ("row_ptr", C.c_void_p),
+                ("chunk_ptr", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/gnnrag.h declares
@@ -65,8 +66,8 @@ SIGNATURES = {
                                                      C.c_int32]),
     "gnnrag_aggregate_backward": (C.c_int, [C.POINTER(CsrStruct), C.POINTER(RelorderStruct), _VP, _VP, _VP, _VP, _VP,
                                             _VP, _VP, _VP, _VP, C.c_int32, C.c_int32, _VP, C.c_size_t, _VP]),
-    "gnnrag_typelayer_backward": (C.c_int, [C.POINTER(CsrStruct), _VP, C.c_int, _VP, C.c_int32, _VP, C.c_size_t,
-                                            _VP]),
+    "gnnrag_typelayer_backward": (C.c_int, [C.POINTER(CsrStruct), C.POINTER(RelorderStruct), _VP, _VP, C.c_int, _VP,
+                                            C.c_int32, _VP, C.c_size_t, _VP]),
     "gnnrag_seed_retrieve": (C.c_int, [_VP, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, _VP]),
     "gnnrag_topp_candidates": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_double, C.c_double, _VP, _VP, _VP]),
     "gnnrag_relation_tables": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32, _VP]),

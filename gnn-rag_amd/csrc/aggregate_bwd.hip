@@ -492,6 +492,58 @@ __global__ __launch_bounds__(256) void k_bwd_rel_gather(const BwdArgs a, const i
   }
 }
 
+// TypeLayer: Vc[chunk][0][:] = sum over the chunk's facts of v_f (g_pre[tail_f,:] + g_pre[head_f,:])
+template <int CPL>
+__global__ __launch_bounds__(256) void k_bwd_type_gather(const BwdArgs a, const int2* __restrict__ ht,
+                                                         const int32_t* __restrict__ perm,
+                                                         const float* __restrict__ w_fact,
+                                                         const int32_t* __restrict__ row_ptr,
+                                                         const int32_t* __restrict__ chunk_ptr, int n_chunks,
+                                                         float* __restrict__ Vc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nblk = gridDim.x;
+  const int blk = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+  const int c = blk * 4 + wave;
+  if (c >= n_chunks) return;
+  int lo = 0, hi = a.Rtot;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (chunk_ptr[mid] <= c) lo = mid; else hi = mid;
+  }
+  const int beg = row_ptr[lo] + (c - chunk_ptr[lo]) * kHeavyDeg;
+  const int end = min(beg + kHeavyDeg, row_ptr[lo + 1]);
+  const int D = a.D;
+  f32x4 U[CPL];
+#pragma unroll
+  for (int m = 0; m < CPL; ++m) U[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int j0 = beg; j0 < end; j0 += 4) {
+    int2 e[4];
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = min(j0 + u, end - 1);
+      e[u] = ht[j];
+      v[u] = (j0 + u < end) ? (w_fact ? w_fact[perm[j]] : 1.f) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (v[u] == 0.f) continue;
+#pragma unroll
+      for (int m = 0; m < CPL; ++m) {
+        const int col = 4 * (lane + 64 * m);
+        if (col < D)
+          U[m] += v[u] * (*reinterpret_cast<const f32x4*>(a.g + (size_t)e[u].y * D + col) +
+                          *reinterpret_cast<const f32x4*>(a.g + (size_t)e[u].x * D + col));
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < CPL; ++m) {
+    const int col = 4 * (lane + 64 * m);
+    if (col < D) *reinterpret_cast<f32x4*>(Vc + (size_t)c * 2 * D + col) = U[m];
+  }
+}
+
 // g_T_d[r,:] = sum over the questions that use r (found by binary search in each question's sorted relation
 // list) and the chunks of their row of Vc.  One workgroup per (relation, direction); thread group k of 4 takes
 // the k-th, (k+4)-th, ... question, the four partial sums are combined in group order (fixed order).
@@ -735,12 +787,40 @@ extern "C" size_t gnnrag_backward_workspace_bytes(const gnnrag_csr* csr, const g
   return lds_path > gather_path ? lds_path : gather_path;
 }
 
-extern "C" int gnnrag_typelayer_backward(const gnnrag_csr* csr, const float* g_pre, int use_w_rel, float* g_T,
+extern "C" int gnnrag_typelayer_backward(const gnnrag_csr* csr, const gnnrag_relorder* relorder, const float* g_pre,
+                                         const float* w_rel_per_fact, int use_w_rel, float* g_T,
                                          int32_t D, void* workspace, size_t workspace_bytes,
                                          gnnrag_stream_t stream_) {
   if (!csr || !g_pre || !g_T || D <= 0 || csr->rel_total < 0) return GNNRAG_E_BADARG;
-  if (use_w_rel && (!csr->w_rel[0] || !csr->w_rel[1])) return GNNRAG_E_BADARG;
   hipStream_t stream = (hipStream_t)stream_;
+  if (gather_ok(relorder, D, 1) && (!use_w_rel || w_rel_per_fact)) {
+    if (relorder->F != csr->F || relorder->rel_total != csr->rel_total) return GNNRAG_E_BADARG;
+    if (!workspace || workspace_bytes < bwd_gather_ws_bytes(relorder, D, 1)) return GNNRAG_E_WORKSPACE;
+    BwdArgs a;
+    fill_bwd(a, csr, D, 1);
+    a.g = g_pre;
+    a.g_T[0] = g_T;
+    float* Vc = (float*)workspace;
+    if (relorder->n_chunks > 0) {
+      const int nblk = 8 * ((relorder->n_chunks + 31) / 32);
+      const int cpl = (D / 4 + 63) / 64;
+      const float* wf = use_w_rel ? w_rel_per_fact : nullptr;
+#define GNNRAG_TGATHER(C)                                                                                       \
+  hipLaunchKernelGGL((k_bwd_type_gather<C>), dim3(nblk), dim3(256), 0, stream, a, (const int2*)relorder->ht,     \
+                     (const int32_t*)relorder->perm, wf, (const int32_t*)relorder->row_ptr,                     \
+                     (const int32_t*)relorder->chunk_ptr, relorder->n_chunks, Vc)
+      if (cpl == 1) GNNRAG_TGATHER(1);
+      else if (cpl == 2) GNNRAG_TGATHER(2);
+      else GNNRAG_TGATHER(4);
+#undef GNNRAG_TGATHER
+      GNNRAG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_bwd_reduce_tables_chunks, dim3(csr->R1, 1), dim3(1024), 0, stream, a, (const float*)Vc,
+                       (const int32_t*)relorder->chunk_ptr);
+    GNNRAG_LAUNCH_CHECK();
+    return 0;
+  }
+  if (use_w_rel && (!csr->w_rel[0] || !csr->w_rel[1])) return GNNRAG_E_BADARG;
   if (bwd_lds_bytes(1, csr->rel_max) > 160 * 1024 - 1024) return GNNRAG_E_UNSUPPORTED;
   BwdArgs a;
   fill_bwd(a, csr, D, 1);

@@ -355,7 +355,7 @@ extern "C" int gnnrag_csr_permute_weight(const gnnrag_csr* csr, const float* w_p
   return 0;
 }
 
-struct RelLayout { size_t ht, w, row_ptr, chunk_ptr, total_cnt, total; };
+struct RelLayout { size_t ht, perm, w, row_ptr, chunk_ptr, total_cnt, total; };
 
 static RelLayout rel_layout(const gnnrag_csr* csr, int has_w) {
   RelLayout L;
@@ -364,6 +364,7 @@ static RelLayout rel_layout(const gnnrag_csr* csr, int has_w) {
   const size_t Fp = (size_t)(csr->F > 0 ? csr->F : 1);
   const size_t R = (size_t)(csr->rel_total > 0 ? csr->rel_total : 0);
   L.ht = take(Fp * 2 * sizeof(int32_t));
+  L.perm = take(Fp * sizeof(int32_t));
   L.w = has_w ? take(Fp * sizeof(float)) : 0;
   L.row_ptr = take((R + 1) * sizeof(int32_t));
   L.chunk_ptr = take((R + 1) * sizeof(int32_t));
@@ -380,8 +381,8 @@ extern "C" size_t gnnrag_relorder_scratch_bytes(const gnnrag_csr* csr) {
   if (!csr) return 0;
   const size_t Fp = (size_t)(csr->F > 0 ? csr->F : 1);
   const unsigned bits = key_bits((size_t)(csr->rel_total > 1 ? csr->rel_total : 2));
-  // unsorted keys, sorted keys, permutation, sort temporaries
-  return 3 * align_up(Fp * sizeof(uint32_t), 256) + align_up(sort_temp_bytes(csr->F, bits), 256);
+  // unsorted keys, sorted keys, sort temporaries
+  return 2 * align_up(Fp * sizeof(uint32_t), 256) + align_up(sort_temp_bytes(csr->F, bits), 256);
 }
 
 extern "C" int gnnrag_relorder_build(const gnnrag_csr* csr, const int32_t* heads, const int32_t* rels,
@@ -400,6 +401,7 @@ extern "C" int gnnrag_relorder_build(const gnnrag_csr* csr, const int32_t* heads
   out->F = F;
   out->rel_total = csr->rel_total;
   out->ht = (int32_t*)(base + L.ht);
+  out->perm = (int32_t*)(base + L.perm);
   out->w = w_per_fact ? (float*)(base + L.w) : nullptr;
   out->row_ptr = (int32_t*)(base + L.row_ptr);
   out->chunk_ptr = (int32_t*)(base + L.chunk_ptr);
@@ -414,8 +416,8 @@ extern "C" int gnnrag_relorder_build(const gnnrag_csr* csr, const int32_t* heads
   const size_t kb = align_up((size_t)F * sizeof(uint32_t), 256);
   uint32_t* key = (uint32_t*)scratch;
   uint32_t* key_sorted = (uint32_t*)((char*)scratch + kb);
-  int32_t* perm = (int32_t*)((char*)scratch + 2 * kb);
-  void* temp = (char*)scratch + 3 * kb;
+  int32_t* perm = out->perm;
+  void* temp = (char*)scratch + 2 * kb;
   const unsigned bits = key_bits((size_t)(R > 1 ? R : 2));
   const int nb = (int)((F + 255) / 256);
   hipLaunchKernelGGL(k_rel_key, dim3(nb), dim3(256), 0, stream, heads, rels, F, csr->N, csr->rel_off,

@@ -141,6 +141,8 @@ class CsrPlan:
             if ("relorder",) in self._w:
                 raise RuntimeError("attach_w_gnn after the backward structure was built")
             self._w[("w_gnn_src",)] = src            # original fact order: the (question, relation) ordering permutes it too
+        if key == "w_rel":
+            self._w[("w_rel_src",)] = src            # read through relorder.perm by the TypeLayer backward
         arr = getattr(self.c, key)
         arr[0], arr[1] = out[0].data_ptr(), out[1].data_ptr()
 
@@ -366,19 +368,24 @@ def aggregate_backward(plan: CsrPlan, dist, ins, T_fwd, T_inv, g_agg, gather: bo
     return g_dist, g_ins, g_Tf, g_Ti
 
 
-def typelayer_backward(plan: CsrPlan, g_pre: torch.Tensor, use_w_rel: bool) -> torch.Tensor:
-    """Gradient of ``typelayer`` with respect to T; g_pre = gradient of the pre-activation [BN, D]."""
+def typelayer_backward(plan: CsrPlan, g_pre: torch.Tensor, use_w_rel: bool, gather: bool = True) -> torch.Tensor:
+    """Gradient of ``typelayer`` with respect to T; g_pre = gradient of the pre-activation [BN, D].
+    ``gather``: atomic-free gather over (question, relation) rows (D % 4 == 0) instead of LDS sums."""
     lib = _lib.load()
     g_pre = _chk(g_pre, "g_pre")
     D = g_pre.shape[1]
     if g_pre.shape[0] != plan.B * plan.N:
         raise ValueError("g_pre has %d rows, the plan %d nodes" % (g_pre.shape[0], plan.B * plan.N))
     g_T = torch.empty((plan.R1, D), dtype=torch.float32, device=g_pre.device)
-    ws = plan.backward_workspace(D, 1)
+    ro = plan.relorder() if (gather and D % 4 == 0) else None
+    w_src = plan._w.get(("w_rel_src",)) if use_w_rel else None
+    if use_w_rel and w_src is None:
+        raise ValueError("use_w_rel needs attach_w_rel first")
+    ws = plan.backward_workspace(D, 1, ro)
     with torch.cuda.device(g_pre.device):
-        _lib.check(lib.gnnrag_typelayer_backward(C.byref(plan.c), g_pre.data_ptr(), int(use_w_rel), g_T.data_ptr(),
-                                                 D, ws.data_ptr(), ws.numel(), _stream()),
-                   "gnnrag_typelayer_backward")
+        _lib.check(lib.gnnrag_typelayer_backward(C.byref(plan.c), None if ro is None else C.byref(ro), g_pre.data_ptr(),
+                                                 _ptr(w_src), int(use_w_rel), g_T.data_ptr(), D, ws.data_ptr(),
+                                                 ws.numel(), _stream()), "gnnrag_typelayer_backward")
     return g_T
 
 

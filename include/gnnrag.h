@@ -173,6 +173,7 @@ typedef struct gnnrag_relorder {
   int32_t  rel_total;
   int32_t  n_chunks;    /* host copy, filled by gnnrag_relorder_build                                */
   int32_t* ht;          /* [F][2]  (head node, tail node) per fact in (question, relation) order     */
+  int32_t* perm;        /* [F]     position in that order -> fact id of the caller's tuple           */
   float*   w;           /* [F]     v_f^2 in that order (normalized_gnn) or NULL                      */
   int32_t* row_ptr;     /* [rel_total+1] first position of each compact relation row                 */
   int32_t* chunk_ptr;   /* [rel_total+1] first chunk of each row (prefix of ceil(len/256))           */
@@ -207,8 +208,12 @@ int gnnrag_aggregate_backward(const gnnrag_csr* csr, const gnnrag_relorder* relo
 /* Backward of gnnrag_typelayer with respect to T (layer_init.py:47-57):
  *   g_T[r,:] = sum_{f: rel_f=r} v_f (g_pre[tail_f,:] + g_pre[head_f,:]),
  * g_pre [BN,D] = gradient of the pre-activation (= g_h0 where h0 > 0, else 0).  g_T [R1,D] is fully
- * written. */
-int gnnrag_typelayer_backward(const gnnrag_csr* csr, const float* g_pre, int use_w_rel, float* g_T,
+ * written.  relorder != NULL and D % 4 == 0: atomic-free gather over the (question, relation) rows, v_f read
+ * from w_rel_per_fact (weight_rel_list in the caller's fact order) when use_w_rel; else the LDS form with the
+ * structure's own w_rel (limits as for gnnrag_aggregate_backward).
+ * workspace: gnnrag_backward_workspace_bytes(csr, relorder, D, 1). */
+int gnnrag_typelayer_backward(const gnnrag_csr* csr, const gnnrag_relorder* relorder, const float* g_pre,
+                              const float* w_rel_per_fact, int use_w_rel, float* g_T,
                               int32_t D, void* workspace, size_t workspace_bytes, gnnrag_stream_t stream);
 
 /* Per-question relation tables of the fused path, one row per (question b, relation r used by b):

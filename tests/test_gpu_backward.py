@@ -82,9 +82,10 @@ def test_aggregate_backward_vs_f64_autograd(dev, name, gather):
         assert not gtf.cpu().numpy()[unused].any() and not gti.cpu().numpy()[unused].any()
 
 
+@pytest.mark.parametrize("gather", [True, False], ids=["gather", "lds"])
 @pytest.mark.parametrize("name", ["tiny50", "tinyfb", "hub", "odd"])
 @pytest.mark.parametrize("norm_rel", [False, True])
-def test_typelayer_backward_vs_f64_autograd(dev, name, norm_rel):
+def test_typelayer_backward_vs_f64_autograd(dev, name, norm_rel, gather):
     import oracle.rearev_grad as og
     from gnnrag_amd import ops, synth
     cfg = _cfg(name)
@@ -99,8 +100,10 @@ def test_typelayer_backward_vs_f64_autograd(dev, name, norm_rel):
         plan.attach_w_rel(et[6])
     want = og.typelayer_grad(et, B, N, T, g_pre, et[6] if norm_rel else None)
     (d_g,) = _dev(dev, g_pre)
-    got = ops.typelayer_backward(plan, d_g, norm_rel).cpu().numpy()
-    _close(got, want, TOL_KERNEL, "g_T")
+    got = ops.typelayer_backward(plan, d_g, norm_rel, gather=gather)
+    _close(got.cpu().numpy(), want, TOL_KERNEL, "g_T")
+    if gather and D % 4 == 0:
+        assert torch.equal(got, ops.typelayer_backward(plan, d_g, norm_rel, gather=True))   # no atomics: same bits
 
 
 def test_empty_batch_backward(dev):
