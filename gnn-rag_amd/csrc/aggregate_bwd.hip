@@ -10,20 +10,21 @@
 //   g_T_d[r,:]   = sum_b sum_i U[d,b,r,i,:] * [T_d[r,:]*ins[b,i,:] > 0] * ins[b,i,:]
 //   g_ins[b,i,:] = sum_d sum_r U[d,b,r,i,:] * [T_d[r,:]*ins[b,i,:] > 0] * T_d[r,:]
 //
-// Two kernels, both walks of the same destination-sorted structure the forward uses:
+// Kernels:
 //  * k_bwd_prior: the facts with source s in direction d are row s of the OTHER direction's structure
 //    (its records hold (dst_d(f), rel_f)), so g_dist is a gather - one wave per node, lanes across the
-//    D columns, one cross-lane reduction per node; rows above heavy_deg go to one wave per 256-fact
-//    chunk (k_bwd_prior_heavy) and are added atomically.
-//  * k_bwd_tables: U is the transpose of the fused forward's relation tables: a workgroup owns
-//    (question, 16-column slice, instruction), keeps U[2][relations the question uses][16] in LDS,
-//    walks the question's nodes exactly like the forward LDS walk (over (p_f, relation) pairs made once
-//    per call by k_bwd_pairs) but ADDS p * g_agg[n, cols] into the row of the fact's relation
-//    (ds_add_f32) instead of reading it; the epilogue applies the ReLU gate and reduces to g_ins
-//    (exclusive store) and to the question's own gradient rows V[d][compact row] (exclusive, summed
-//    over the instructions in place); k_bwd_reduce_tables then sums V over the questions that use a
-//    relation (global atomics across XCDs go to the memory side and were 10x slower).  U never reaches
-//    HBM.  LDS sums are in atomic order: gradients are reproducible to rounding, not bit for bit.
+//    D columns, one cross-lane reduction per node; rows above heavy_deg go to one workgroup per 256-fact
+//    chunk (k_bwd_prior_heavy), added with one atomic per 64 facts.
+//  * gather form of U (default): k_bwd_rel_gather / k_bwd_type_gather over the facts ordered by (question,
+//    relation) (gnnrag_relorder, csr_plan.hip), one wave per chunk of a relation row, partial sums per chunk,
+//    then k_bwd_reduce_tables_chunks / k_bwd_reduce_ins_chunks in a fixed order.  No atomics.
+//  * LDS form of U (fallback for D % 4 != 0): k_bwd_tables - U is the transpose of the fused forward's
+//    relation tables: a workgroup owns (question, 16-column slice), keeps U[2][relations the question
+//    uses][16] in LDS, walks the question's nodes like the forward LDS walk (over (p_f, relation) pairs made
+//    once per call by k_bwd_pairs) but ADDS p * g_agg[n, cols] into the row of the fact's relation
+//    (ds_add_f32); the epilogue applies the ReLU gate and writes g_ins and the question's own gradient rows
+//    V[d][compact row]; k_bwd_reduce_tables sums V over the questions that use a relation (global atomics
+//    across XCDs go to the memory side and were no faster).  LDS sums are in atomic order.
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include "gnnrag_common.h"
