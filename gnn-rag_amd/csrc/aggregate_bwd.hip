@@ -14,7 +14,7 @@
 //  * k_bwd_prior: the facts with source s in direction d are row s of the OTHER direction's structure
 //    (its records hold (dst_d(f), rel_f)), so g_dist is a gather - one wave per node, lanes across the
 //    D columns, one cross-lane reduction per node; rows above heavy_deg go to one workgroup per 256-fact
-//    chunk (k_bwd_prior_heavy), added with one atomic per 64 facts.
+//    chunk (k_bwd_prior_heavy), pieces added in chunk order by k_bwd_prior_heavy_reduce.
 //  * gather form of U (default): k_bwd_rel_gather / k_bwd_type_gather over the facts ordered by (question,
 //    relation) (gnnrag_relorder, csr_plan.hip), one wave per chunk of a relation row, partial sums per chunk,
 //    then k_bwd_reduce_tables_chunks / k_bwd_reduce_ins_chunks in a fixed order.  No atomics.
@@ -146,10 +146,10 @@ __global__ __launch_bounds__(256) void k_bwd_prior(const BwdArgs a) {
   if (lane == 0) a.g_dist[s] = acc;
 }
 
-// rows above heavy_deg: one workgroup per 256-fact chunk (64 facts per wave), added atomically
-// (after k_bwd_prior's store)
+// rows above heavy_deg: one workgroup per 256-fact chunk (64 facts per wave) -> part[o][chunk][wave];
+// k_bwd_prior_heavy_reduce adds a row's pieces in order onto k_bwd_prior's store (no atomics)
 template <bool V4>
-__global__ __launch_bounds__(256) void k_bwd_prior_heavy(const BwdArgs a) {
+__global__ __launch_bounds__(256) void k_bwd_prior_heavy(const BwdArgs a, float* __restrict__ part) {
   const int o = blockIdx.y, d = 1 - o;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int cnt = min(a.n_heavy[o], a.heavy_cap);
@@ -168,7 +168,24 @@ __global__ __launch_bounds__(256) void k_bwd_prior_heavy(const BwdArgs a) {
     const int end = min(beg + kHeavyDeg / 4, cend);
     const float* q = a.ins + (size_t)(s / a.N) * a.I * a.D;
     const float acc = wave_sum(prior_grad_range<V4>(a, q, d, beg, end, lane));
-    if (lane == 0) unsafeAtomicAdd(a.g_dist + s, acc);
+    if (lane == 0) part[((size_t)o * a.max_chunks + c) * 4 + wave] = acc;
+  }
+}
+
+// one thread per heavy row of structure o: g_dist[s] += its chunk pieces, in chunk order.  Launched for
+// o = 0 and then o = 1 (a node can be heavy in both structures).
+__global__ __launch_bounds__(256) void k_bwd_prior_heavy_reduce(const BwdArgs a, const float* __restrict__ part, int o) {
+  const int cnt = min(a.n_heavy[o], a.heavy_cap);
+  const int nch = min(a.n_chunks[o], a.max_chunks);
+  const int32_t* off = a.chunk_off[o];
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < cnt; e += gridDim.x * 256) {
+    float t = 0.f;
+    const int c1 = min(off[e + 1], nch);
+    for (int c = off[e]; c < c1; ++c) {
+      const float* p = part + ((size_t)o * a.max_chunks + c) * 4;
+      t += ((p[0] + p[1]) + p[2]) + p[3];
+    }
+    a.g_dist[a.heavy[o][e]] += t;
   }
 }
 
@@ -752,10 +769,20 @@ extern "C" int gnnrag_aggregate_backward(const gnnrag_csr* csr, const gnnrag_rel
   else hipLaunchKernelGGL(k_bwd_prior<false>, pgrid, dim3(256), plds, stream, a);
   GNNRAG_LAUNCH_CHECK();
   if (csr->F > 0) {
+    // the heavy rows' pieces borrow the head of the workspace: they are consumed before the table-gradient
+    // kernels (same stream) write there
+    const size_t hbytes = (size_t)2 * csr->max_chunks * 4 * sizeof(float);
+    if (!workspace || workspace_bytes < hbytes) return GNNRAG_E_WORKSPACE;
+    float* part = (float*)workspace;
     const int nb = csr->max_chunks < 4096 ? csr->max_chunks : 4096;
-    if (v4) hipLaunchKernelGGL(k_bwd_prior_heavy<true>, dim3(nb > 0 ? nb : 1, 2), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(k_bwd_prior_heavy<false>, dim3(nb > 0 ? nb : 1, 2), dim3(256), 0, stream, a);
+    if (v4) hipLaunchKernelGGL(k_bwd_prior_heavy<true>, dim3(nb > 0 ? nb : 1, 2), dim3(256), 0, stream, a, part);
+    else hipLaunchKernelGGL(k_bwd_prior_heavy<false>, dim3(nb > 0 ? nb : 1, 2), dim3(256), 0, stream, a, part);
     GNNRAG_LAUNCH_CHECK();
+    for (int o = 0; o < 2; ++o) {
+      hipLaunchKernelGGL(k_bwd_prior_heavy_reduce, dim3((csr->heavy_cap + 255) / 256 < 64 ? (csr->heavy_cap + 255) / 256 : 64),
+                         dim3(256), 0, stream, a, (const float*)part, o);
+      GNNRAG_LAUNCH_CHECK();
+    }
   }
   if (!gather) return launch_tables<BWD_REASON>(a, csr, workspace, workspace_bytes, stream);
   if (!workspace || workspace_bytes < bwd_gather_ws_bytes(relorder, D, I)) return GNNRAG_E_WORKSPACE;
@@ -785,7 +812,9 @@ extern "C" size_t gnnrag_backward_workspace_bytes(const gnnrag_csr* csr, const g
   if (!csr || D <= 0 || I <= 0) return 0;
   const size_t lds_path = bwd_ws_bytes(csr, D);
   const size_t gather_path = gather_ok(relorder, D, I) ? bwd_gather_ws_bytes(relorder, D, I) : 0;
-  return lds_path > gather_path ? lds_path : gather_path;
+  const size_t heavy = align_up((size_t)2 * csr->max_chunks * 4 * sizeof(float), 256);
+  size_t need = lds_path > gather_path ? lds_path : gather_path;
+  return need > heavy ? need : heavy;
 }
 
 extern "C" int gnnrag_typelayer_backward(const gnnrag_csr* csr, const gnnrag_relorder* relorder, const float* g_pre,

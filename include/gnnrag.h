@@ -194,7 +194,7 @@ int gnnrag_relorder_build(const gnnrag_csr* csr, const int32_t* heads, const int
  * facts of each (question, relation) row - no atomics, one fixed summation order, any number of
  * relations per question.  relorder == NULL: relation-bucketed sums in LDS (ds_add_f32; reproducible
  * to rounding only; GNNRAG_E_UNSUPPORTED when one question uses more relations than one CU's LDS
- * holds, ~1200).  g_dist of rows with > 256 facts is summed with one atomic per 64-fact piece.
+ * holds, ~1200).
  * workspace: gnnrag_backward_workspace_bytes(csr, relorder, D, I) bytes of device scratch.  D <= 1024. */
 size_t gnnrag_backward_workspace_bytes(const gnnrag_csr* csr, const gnnrag_relorder* relorder, int32_t D,
                                        int32_t I);
