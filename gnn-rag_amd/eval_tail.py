@@ -53,6 +53,9 @@ def evaluate(self, valid_data, test_batch_size=20, write_info=False):
     from evaluate import f1_and_hits            # the reference's own metric code (on sys.path with main.py)
     from tqdm import tqdm
     write_info = True                           # evaluate.py:148
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+        write_info = False                      # question-sharded run: every rank scores, rank 0 reports
     self.model.eval()
     self.count = 0
     eps = self.eps
@@ -92,6 +95,8 @@ def evaluate(self, valid_data, test_batch_size=20, write_info=False):
             ems.append(em)
             precisions.append(precision)
             recalls.append(recall)
+    if not write_info:
+        return np.mean(f1s), np.mean(hits), np.mean(ems)
     print("evaluation.......")
     print("how many eval samples......", len(f1s))
     print("avg_em", np.mean(ems))

@@ -86,3 +86,32 @@ def gather_rows(local: torch.Tensor, B: int, group: Optional[dist.ProcessGroup] 
         l, h = question_range(B, r, world)
         parts.append(recv[r * rows: r * rows + (h - l)])
     return torch.cat(parts, dim=0)
+
+
+def shard_model(model, group: Optional[dist.ProcessGroup] = None):
+    """Question-sharded evaluation of a reference model (``ReaRev`` / ``NSM``): ``model(batch)`` then runs
+    this rank's contiguous question range only and all-gathers the scored nodes, so that every rank hands
+    the full ``pred_dist [B, N]`` to the unchanged ``Evaluator`` (BASELINE config "dev set batched across
+    8 GPUs, question-sharded, RCCL gather").  Returns the same 4-tuple as ``Model.forward``
+    (rearev.py:243): the loss is the batch mean (per-rank means weighted by their question counts,
+    all-reduced), ``pred`` the argmax of the gathered distribution.  Training calls, single-process runs and
+    batches with fewer questions than ranks pass through unchanged."""
+    inner = model.forward
+
+    def forward(batch, training=False):
+        if training or not dist.is_available() or not dist.is_initialized():
+            return inner(batch, training=training)
+        world = dist.get_world_size(group)
+        B = batch[0].shape[0]
+        if world == 1 or B < world:
+            return inner(batch, training=training)
+        rank = dist.get_rank(group)
+        lo, hi = question_range(B, rank, world)
+        loss, _, pred_dist, tp_list = inner(shard_batch(batch, rank, world), training=training)
+        full = gather_rows(pred_dist, B, group)
+        total = loss.detach().float().reshape(1) * float(hi - lo)       # calc_loss_label divides by the local batch size
+        dist.all_reduce(total, group=group)
+        return total[0] / B, torch.max(full, dim=1)[1], full, tp_list
+
+    model.forward = forward
+    return model

@@ -82,3 +82,50 @@ def test_question_range_partition():
             assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
             sizes = [h - l for l, h in rs]
             assert max(sizes) - min(sizes) <= 1
+
+
+REF = "/root/reference/gnn"
+
+
+def _model_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        import test_dropin_with_reference as td
+        from gnnrag_amd import shard
+        args, dataset, model = td.build_reference_setup()       # same seeds in every process: same model, same data
+        test = dataset["test"]
+        test.reset_batches(is_sequential=True)
+        np.random.seed(11)
+        batch = test.get_batch(0, 5, fact_dropout=0.0, test=True)
+        with torch.no_grad():
+            loss_ref, pred_ref, dist_ref, _ = model(batch[:-1])
+            shard.shard_model(model)
+            loss, pred, full, _ = model(batch[:-1])
+        ok = (full.shape == dist_ref.shape and float((full - dist_ref).abs().max()) <= 1e-6 and
+              torch.equal(pred, pred_ref) and abs(float(loss) - float(loss_ref)) <= 1e-5 * max(1.0, abs(float(loss_ref))))
+        q.put((rank, bool(ok), float((full - dist_ref).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="live reference not available")
+def test_sharded_reference_model_world2():
+    """The live reference ReaRev (CPU) behind shard.shard_model on 2 gloo ranks with a ragged split (5 questions):
+    gathered pred_dist, pred and the batch-mean loss equal the unsharded forward on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_model_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, err in res:
+        assert ok, "rank %d: sharded forward differs (max err %g)" % (rank, err)

@@ -10,6 +10,9 @@ What is substituted, all without touching a reference file:
     (``gnnrag_amd.data.fact_mat.patch_loader``; skip with GNNRAG_NO_LOADER_PATCH=1);
   * ``Evaluator.evaluate`` -> device-side candidate selection (``gnnrag_amd.eval_tail``; skip with
     GNNRAG_NO_EVAL_PATCH=1).
+Under ``python -m torch.distributed.run --nproc-per-node G ... tools/run_reference.py ... --is_eval ...`` every
+evaluation batch is question-sharded over the G GPUs (``gnnrag_amd.shard.shard_model``: local forward, one RCCL
+all-gather of the scored nodes); rank 0 writes the ``.info`` file and prints the metrics.
 Needs a GPU (the package has no CPU path); the reference's own two start-up bugs (an undefined
 ``create_parser_nutrea`` in ``parsing.py``; ``LSTMInstruction`` not passing ``constraint``)
 are shimmed exactly as the tests do."""
@@ -30,6 +33,13 @@ def main():
     import gnnrag_amd  # noqa: F401
     from gnnrag_amd import install
     install.install()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:                                        # one process per GPU (torchrun), RCCL over xGMI
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
 
     import parsing
     if not hasattr(parsing, "create_parser_nutrea"):
@@ -58,10 +68,19 @@ def main():
 
         dataset_load.load_data = load_data
 
+    import evaluate
     if not os.environ.get("GNNRAG_NO_EVAL_PATCH"):
-        import evaluate
         from gnnrag_amd import eval_tail
         evaluate.Evaluator.evaluate = eval_tail.evaluate
+    if world > 1:
+        from gnnrag_amd import shard
+        _ev_init = evaluate.Evaluator.__init__
+
+        def _init_sharded(self, *a, **kw):
+            _ev_init(self, *a, **kw)
+            shard.shard_model(self.model)                # evaluation batches are split over the ranks
+
+        evaluate.Evaluator.__init__ = _init_sharded
 
     sys.argv = [os.path.join(ref, "main.py")] + sys.argv[2:]
     runpy.run_path(os.path.join(ref, "main.py"), run_name="__main__")
