@@ -87,6 +87,7 @@ SIGNATURES = {
 
 ABI_VERSION = 4
 PATH_AUTO, PATH_UNFUSED, PATH_FUSED = 0, 1, 2
+E_TUPLE = -4
 _lib = None
 
 

@@ -81,8 +81,8 @@ __global__ __launch_bounds__(256) void k_csr_fill(const int32_t* __restrict__ pe
                                                   const int32_t* __restrict__ rels,
                                                   const float* __restrict__ wg,
                                                   const float* __restrict__ wr, int64_t F,
-                                                  const int32_t* __restrict__ g2l, int32_t N, int32_t R1,
-                                                  int2* __restrict__ edge, int2* __restrict__ edge_l,
+                                                  const int32_t* __restrict__ g2l, int64_t g2l_len, int32_t N,
+                                                  int32_t R1, int2* __restrict__ edge, int2* __restrict__ edge_l,
                                                   float* __restrict__ wg_out, float* __restrict__ wr_out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= F) return;
@@ -90,7 +90,13 @@ __global__ __launch_bounds__(256) void k_csr_fill(const int32_t* __restrict__ pe
   const int32_t s = src[f], r = rels[f];
   edge[i] = make_int2(s, r);
   // the same fact with its relation renumbered inside its question (fused path)
-  edge_l[i] = make_int2(s, (unsigned)r < (unsigned)R1 ? g2l[(size_t)(s / N) * R1 + r] : 0);
+  // (an invalid tuple is rejected by the build after these kernels; keep the lookup in bounds meanwhile)
+  int rl = 0;
+  if ((unsigned)r < (unsigned)R1 && s >= 0) {
+    const int64_t idx = (int64_t)(s / N) * R1 + r;
+    if (idx < g2l_len) rl = g2l[idx];
+  }
+  edge_l[i] = make_int2(s, rl);
   if (wg_out) {
     const float v = wg[f];
     wg_out[i] = v * v;  // the weight enters head2fact AND fact2tail (base_gnn.py:44-47)
@@ -214,14 +220,24 @@ __device__ __forceinline__ int block_scan_excl(int v, int* wsum, int& total) {
 }
 
 // g2l[b*R1 + r] = 1 for every (question, relation) pair that occurs (benign write race)
+// The same pass validates the tuple (the host no longer does: 1.2 ms of numpy per C2 batch): node ids in
+// [0, B*N), relation ids in [0, R1), head and tail in the same question -> error bits, checked by the build.
 __global__ __launch_bounds__(256) void k_rel_flag(const int32_t* __restrict__ heads,
-                                                  const int32_t* __restrict__ rels, int64_t F, int32_t N,
-                                                  int32_t R1, int32_t B, int32_t* __restrict__ g2l) {
+                                                  const int32_t* __restrict__ rels,
+                                                  const int32_t* __restrict__ tails, int64_t F, int32_t N,
+                                                  int32_t R1, int32_t B, int32_t* __restrict__ g2l,
+                                                  int32_t* __restrict__ err) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= F) return;
-  const int32_t r = rels[i];
-  const int32_t b = heads[i] / N;
-  if ((unsigned)r < (unsigned)R1 && (unsigned)b < (unsigned)B) g2l[(size_t)b * R1 + r] = 1;
+  const int32_t r = rels[i], h = heads[i], t = tails[i];
+  const int64_t BN = (int64_t)B * N;
+  int bad = 0;
+  if (h < 0 || h >= BN || t < 0 || t >= BN) bad |= 1;
+  if ((unsigned)r >= (unsigned)R1) bad |= 2;
+  const int32_t b = h / N;
+  if (!bad && b != t / N) bad |= 4;
+  if (bad) atomicOr(err, bad);
+  else g2l[(size_t)b * R1 + r] = 1;
 }
 
 // one workgroup per question: flags -> compact index (or -1), number of used relations -> cnt[b]
@@ -511,8 +527,8 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
   if (F > 0) {
     const int64_t BR = (int64_t)B * R1;
     GNNRAG_HIP(hipMemsetAsync(g2l, 0, (size_t)BR * sizeof(int32_t), stream));
-    hipLaunchKernelGGL(k_rel_flag, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, stream, heads, rels, F, N,
-                       R1, B, g2l);
+    hipLaunchKernelGGL(k_rel_flag, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, stream, heads, rels, tails, F,
+                       N, R1, B, g2l, rel_stats + 2);
     GNNRAG_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_rel_scan, dim3(B), dim3(1024), 0, stream, g2l, R1, out->rel_off + 1);
     GNNRAG_LAUNCH_CHECK();
@@ -534,8 +550,8 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
                                            out->perm[d], (size_t)F, 0u, bits, stream, false));
       const int nb = (int)((F + 255) / 256);
       hipLaunchKernelGGL(k_csr_fill, dim3(nb), dim3(256), 0, stream, out->perm[d], src, rels, w_gnn,
-                         w_rel, F, g2l, N, R1, (int2*)out->edge[d], (int2*)out->edge_l[d], out->w_gnn[d],
-                         out->w_rel[d]);
+                         w_rel, F, g2l, (int64_t)B * R1, N, R1, (int2*)out->edge[d], (int2*)out->edge_l[d],
+                         out->w_gnn[d], out->w_rel[d]);
       GNNRAG_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_csr_row_ptr, dim3(nb_rows), dim3(256), 0, stream, keys_sorted, F, BN,
@@ -554,9 +570,13 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
                      out->row_ptr[1], BN, N, (int32_t)kBigDeg, out->big_cnt, out->big_nodes);
   GNNRAG_LAUNCH_CHECK();
   // the relation counts size the fused path's tables and launches: hand them to the host
-  int32_t stats[2] = {0, 0};
+  int32_t stats[3] = {0, 0, 0};     // rel_total, rel_max, validation error bits
   GNNRAG_HIP(hipMemcpyAsync(stats, rel_stats, sizeof(stats), hipMemcpyDeviceToHost, stream));
   GNNRAG_HIP(hipStreamSynchronize(stream));
+  if (stats[2]) {                   // out-of-range ids or a fact that connects two questions
+    out->rel_total = -1;            // the structure must not be used
+    return GNNRAG_E_TUPLE;
+  }
   out->rel_total = stats[0];
   out->rel_max = stats[1];
   return 0;

@@ -194,6 +194,9 @@ extern "C" const char* gnnrag_error_string(int code) {
     case GNNRAG_E_BADARG: return "gnnrag: bad argument (null pointer, negative or inconsistent size)";
     case GNNRAG_E_UNSUPPORTED: return "gnnrag: shape outside the compiled kernel set";
     case GNNRAG_E_WORKSPACE: return "gnnrag: caller-provided buffer too small";
+    case GNNRAG_E_TUPLE:
+      return "gnnrag: edge tuple out of range: node ids must lie in [0, B*N), relation ids in [0, R1), and a fact "
+             "may not connect two questions";
   }
   if (code > 0) return hipGetErrorString((hipError_t)code);
   return "gnnrag: unknown error";

@@ -50,13 +50,8 @@ class CsrPlan:
             raise ValueError("B, N, R1 must be positive")
         if B * N >= 2 ** 31 or F >= 2 ** 31:
             raise ValueError("batch too large for int32 indices")
-        if validate and F:
-            lo = min(int(heads.min()), int(tails.min()), int(rels.min()))
-            if lo < 0 or max(int(heads.max()), int(tails.max())) >= B * N or int(rels.max()) >= R1:
-                raise ValueError("edge tuple out of range: node ids must lie in [0, B*N), relation ids in [0, R1)")
-            # edges never cross questions (heads/tails are offset per sample, dataset_load.py:483)
-            if ((heads // N) != (tails // N)).any():
-                raise ValueError("a fact connects two different questions")
+        # ranges and the no-fact-across-questions rule are checked on the device during the build, on the
+        # int32-narrowed ids (GNNRAG_E_TUPLE -> ValueError below); `validate` is kept for API compatibility
         self.B, self.N, self.R1, self.F = int(B), int(N), int(R1), F
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -76,10 +71,14 @@ class CsrPlan:
             scratch = torch.empty(max(sbytes, 256), dtype=torch.uint8, device=self.device)
             self.c = _lib.CsrStruct()
             row = self._hrt
-            _lib.check(lib.gnnrag_csr_build(
+            rc = lib.gnnrag_csr_build(
                 row[0].data_ptr(), row[1].data_ptr(), row[2].data_ptr(), None, None,
                 F, B, N, R1, self._mem.data_ptr(), self._mem.numel(),
-                scratch.data_ptr(), scratch.numel(), C.byref(self.c), _stream()), "gnnrag_csr_build")
+                scratch.data_ptr(), scratch.numel(), C.byref(self.c), _stream())
+            if rc == _lib.E_TUPLE:
+                raise ValueError("edge tuple out of range: node ids must lie in [0, B*N), relation ids in [0, R1), "
+                                 "and a fact may not connect two different questions")
+            _lib.check(rc, "gnnrag_csr_build")
             # the build waits for its stream once (it returns the relation counts), so scratch is free
         self._w = {}
         # compact relation rows: question b's tables are rows rel_off[b] : rel_off[b+1] of P[d]

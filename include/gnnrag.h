@@ -36,6 +36,8 @@ extern "C" {
 #define GNNRAG_E_BADARG      (-1)  /* null pointer / negative size / inconsistent sizes   */
 #define GNNRAG_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set (see DESIGN)  */
 #define GNNRAG_E_WORKSPACE   (-3)  /* caller-provided buffer too small                    */
+#define GNNRAG_E_TUPLE       (-4)  /* edge tuple invalid: node / relation id out of range,
+                                      or a fact whose head and tail lie in two questions  */
 
 typedef void* gnnrag_stream_t; /* hipStream_t */
 
@@ -86,7 +88,8 @@ size_t gnnrag_csr_scratch_bytes(int64_t F, int32_t B, int32_t N, int32_t R1);
  * arrays (dataset_load.py:527) narrowed to int32; w_gnn = weight_list (used when
  * args['normalized_gnn']), w_rel = weight_rel_list (used when norm_rel), either may be NULL.
  * Replaces BaseGNNLayer.build_matrix (base_gnn.py:19-51) and the two COO builds inside
- * TypeLayer.forward (layer_init.py:35-36,53-54).  Relation ids must lie in [0, R1).
+ * TypeLayer.forward (layer_init.py:35-36,53-54).  The tuple is validated on the device (node ids in
+ * [0, B*N), relation ids in [0, R1), no fact across two questions): GNNRAG_E_TUPLE otherwise.
  * Synchronises `stream` once at the end (rel_total / rel_max are returned in *out). */
 int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const int32_t* tails,
                      const float* w_gnn, const float* w_rel,

@@ -86,6 +86,12 @@ def test_csr_plan_empty_and_validation(dev):
         ops.CsrPlan(np.array([0]), np.array([5]), np.array([1]), 1, 8, 3, dev)      # relation out of range
     with pytest.raises(ValueError):
         ops.CsrPlan(np.array([0]), np.array([0]), np.array([9]), 2, 8, 3, dev)      # crosses questions
+    with pytest.raises(ValueError):
+        ops.CsrPlan(np.array([0, 16]), np.array([0, 1]), np.array([1, 16]), 2, 8, 3, dev)   # node id >= B*N
+    with pytest.raises(ValueError):
+        ops.CsrPlan(np.array([-1]), np.array([0]), np.array([-1]), 2, 8, 3, dev)    # negative node id
+    plan = ops.CsrPlan(np.array([0, 9]), np.array([2, 0]), np.array([7, 15]), 2, 8, 3, dev)   # valid again afterwards
+    assert plan.rel_total == 2
 
 
 @pytest.mark.parametrize("M,K,Nout,with_add,relu", [
