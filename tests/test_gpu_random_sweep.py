@@ -72,3 +72,27 @@ def test_random_shape(k):
         for name, got_t, want_a in (("g_dist", gd, gd_w), ("g_ins", gi, gi_w), ("g_T_fwd", gtf, gtf_w), ("g_T_inv", gti, gti_w)):
             np.testing.assert_allclose(got_t.cpu().numpy(), want_a, rtol=0, atol=TOL * max(np.abs(want_a).max(), 1e-6),
                                        err_msg="%s %s gather=%s" % (cfg, name, gather))
+
+
+@pytest.mark.parametrize("k", range(8))
+def test_random_shape_bf16x3_math(k):
+    """The optional exact-split bf16x3 math mode of the dense projections on random shapes (forward, both paths)."""
+    import gnnrag_amd  # noqa: F401
+    import oracle.rearev_np64 as onp
+    from gnnrag_amd import ops, stack, synth
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5000 + k)
+    cfg = _random_cfg(rng, 100 + k)
+    batch = synth.make_batch(cfg)
+    feats = synth.make_features(cfg)
+    params = synth.make_layer_params(cfg)
+    want = onp.run_stack(batch, feats, params)
+    old = ops.set_dense_math(ops.MATH_BF16X3)
+    try:
+        for path in (1, 2):
+            got = stack.run_stack(batch, feats, params, dev, path=path)
+            for c in range(cfg.T * cfg.L):
+                np.testing.assert_allclose(got["h"][c], want["h"][c], rtol=RTOL, atol=TOL, err_msg="%s h %d" % (cfg, c))
+                np.testing.assert_allclose(got["dist"][c], want["dist"][c], rtol=RTOL, atol=TOL, err_msg="%s dist %d" % (cfg, c))
+    finally:
+        ops.set_dense_math(old)
