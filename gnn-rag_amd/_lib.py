@@ -48,16 +48,15 @@ SIGNATURES = {
     "gnnrag_csr_build": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                    _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(CsrStruct), _VP]),
     "gnnrag_csr_permute_weight": (C.c_int, [C.POINTER(CsrStruct), _VP, C.c_int, _VP, _VP, _VP]),
-    "gnnrag_set_dense_math": (C.c_int, [C.c_int]),
-    "gnnrag_get_dense_math": (C.c_int, []),
     "gnnrag_linear": (C.c_int, [_VP, C.c_int64, C.c_int32, _VP, _VP, _VP, C.c_int64, C.c_int, _VP,
-                                C.c_int32, _VP]),
+                                C.c_int32, C.c_int32, _VP]),
     "gnnrag_linear_pair": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, _VP, _VP, _VP, _VP, C.c_int64, _VP, _VP,
-                                     C.c_int32, _VP]),
+                                     C.c_int32, C.c_int32, _VP]),
     "gnnrag_aggregate_workspace_bytes": (C.c_size_t, [C.POINTER(CsrStruct), C.c_int32, C.c_int32]),
     "gnnrag_aggregate": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32,
                                    _VP, C.c_size_t, _VP]),
     "gnnrag_aggregate_fused": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, C.c_int32, _VP, C.c_size_t, _VP]),
+    "gnnrag_aggregate_fused_variant": (C.c_int, [C.POINTER(CsrStruct), C.c_int32]),
     "gnnrag_relorder_bytes": (C.c_size_t, [C.POINTER(CsrStruct), C.c_int]),
     "gnnrag_relorder_scratch_bytes": (C.c_size_t, [C.POINTER(CsrStruct)]),
     "gnnrag_relorder_build": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP, C.c_size_t,
@@ -70,22 +69,23 @@ SIGNATURES = {
                                             C.c_int32, _VP, C.c_size_t, _VP]),
     "gnnrag_seed_retrieve": (C.c_int, [_VP, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, _VP]),
     "gnnrag_topp_candidates": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_double, C.c_double, _VP, _VP, _VP]),
-    "gnnrag_relation_tables": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32, _VP]),
+    "gnnrag_relation_tables": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32,
+                                         C.c_int32, _VP]),
     "gnnrag_update_score_fused": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_int32,
-                                            C.c_int32, _VP]),
+                                            C.c_int32, C.c_int32, _VP]),
     "gnnrag_update_score": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_int32,
-                                      C.c_int32, _VP]),
+                                      C.c_int32, C.c_int32, _VP]),
     "gnnrag_masked_softmax": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, _VP]),
     "gnnrag_typelayer": (C.c_int, [C.POINTER(CsrStruct), _VP, C.c_int, _VP, C.c_int32, _VP, C.c_size_t, _VP]),
     "gnnrag_layer_workspace_bytes": (C.c_size_t, [C.POINTER(CsrStruct), C.c_int32, C.c_int32]),
     "gnnrag_reason_layer": (C.c_int, [C.POINTER(CsrStruct)] + [_VP] * 9 + [C.c_int32] + [_VP] * 8 +
-                            [_VP, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, _VP]),
+                            [_VP, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP]),
     "gnnrag_stream_copy": (C.c_int, [_VP, _VP, C.c_int64, _VP]),
     "gnnrag_abi_version": (C.c_int, []),
     "gnnrag_error_string": (C.c_char_p, [C.c_int]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 PATH_AUTO, PATH_UNFUSED, PATH_FUSED = 0, 1, 2
 E_TUPLE = -4
 _lib = None
@@ -113,11 +113,6 @@ def load():
     if lib.gnnrag_abi_version() != ABI_VERSION:
         raise GnnragError("ABI mismatch: library %d, binding %d" % (lib.gnnrag_abi_version(), ABI_VERSION))
     _lib = lib
-    if "GNNRAG_MATH" in os.environ:                     # A/B runs: fp32 | bf16x3
-        mode = {"fp32": 0, "bf16x3": 1}[os.environ["GNNRAG_MATH"]]
-        check_code = lib.gnnrag_set_dense_math(mode)
-        if check_code != 0:
-            raise GnnragError("gnnrag_set_dense_math(%d) failed" % mode)
     return lib
 
 

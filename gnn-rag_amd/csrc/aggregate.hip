@@ -916,20 +916,18 @@ static int launch_slice(const WalkArgs& a, const gnnrag_csr* csr, void* workspac
   constexpr int SW = SliceAcc<MODE, NI>::width;
   const int nslice = (D + SW - 1) / SW;
   const size_t lds = slice_lds_bytes(a.R1, SliceAcc<MODE, NI>::n, SW);
-  static bool attr_set = false;   // raising the dynamic-LDS cap is idempotent; once per kernel and process
-  if (!attr_set) {
-    GNNRAG_HIP(hipFuncSetAttribute((const void*)k_walk_slice<MODE, NI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024));
-    attr_set = true;
+  static DeviceMask cap_raised;    // per kernel instantiation, per device
+  {
+    const int rc = raise_lds_cap(k_walk_slice<MODE, NI>, cap_raised);
+    if (rc) return rc;
   }
   // per XCD: items = (questions of the XCD) x slices, slots = 2 workgroups on each of its CUs
-  static int slots_per_xcd = 0;
-  if (!slots_per_xcd) {
-    int dev = 0, cus = 0;
-    GNNRAG_HIP(hipGetDevice(&dev));
-    GNNRAG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    slots_per_xcd = cus >= 8 ? 2 * (cus / 8) : 2;
+  int cus = 0;
+  {
+    const int rc = device_cu_count(&cus);
+    if (rc) return rc;
   }
+  const int slots_per_xcd = cus >= 8 ? 2 * (cus / 8) : 2;
   const int items_x = ((csr->B + 7) / 8) * nslice;
   const int rem = items_x % slots_per_xcd;
   const int nfull = (GNNRAG_SLICE_SPLIT_TAIL && rem != 0) ? items_x - rem : items_x;
@@ -1002,12 +1000,21 @@ extern "C" int gnnrag_aggregate_fused(const gnnrag_csr* csr, const float* dist, 
   a.dist = dist;
   a.out = out;
   a.I = 1;
-  if (!slice_walk_fits(csr->rel_max, D)) return launch_walk<MODE_FUSED>(a, 1, stream);   // tables too big for LDS
-  // 32-column slices when two of them still fit a CU's LDS (questions that use up to ~300 relations): half as
-  // many workgroups re-walk the question's facts
+  switch (gnnrag_aggregate_fused_variant(csr, D)) {
+    case GNNRAG_WALK_L2_GATHER: return launch_walk<MODE_FUSED>(a, 1, stream);   // tables too big for LDS
+    // 32-column slices when two of them still fit a CU's LDS (questions that use up to ~300 relations): half
+    // as many workgroups re-walk the question's facts
+    case GNNRAG_WALK_LDS_32: return launch_slice<MODE_FUSED, 2>(a, csr, workspace, workspace_bytes, 1, stream);
+    default: return launch_slice<MODE_FUSED, 1>(a, csr, workspace, workspace_bytes, 1, stream);
+  }
+}
+
+extern "C" int gnnrag_aggregate_fused_variant(const gnnrag_csr* csr, int32_t D) {
+  if (!csr || D <= 0 || csr->rel_total < 0) return GNNRAG_E_BADARG;
+  if (!slice_walk_fits(csr->rel_max, D)) return GNNRAG_WALK_L2_GATHER;
   if (GNNRAG_SLICE_WIDE && D > kSliceW && slice_lds_bytes(csr->rel_max, 2, 2 * kSliceW) <= GNNRAG_SLICE_WIDE_LDS_KB * 1024)
-    return launch_slice<MODE_FUSED, 2>(a, csr, workspace, workspace_bytes, 1, stream);
-  return launch_slice<MODE_FUSED, 1>(a, csr, workspace, workspace_bytes, 1, stream);
+    return GNNRAG_WALK_LDS_32;
+  return GNNRAG_WALK_LDS_16;
 }
 
 extern "C" int gnnrag_typelayer(const gnnrag_csr* csr, const float* T, int use_w_rel, float* h0, int32_t D,

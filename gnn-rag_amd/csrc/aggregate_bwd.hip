@@ -713,13 +713,12 @@ static int launch_tables(const BwdArgs& a, const gnnrag_csr* csr, void* ws, size
   const int nslice = (a.D + kBwdSliceW - 1) / kBwdSliceW;
   const int nblk = 8 * ((csr->B + 7) / 8) * nslice;
   const bool v4 = a.D % 4 == 0;
-  static bool attr_set = false;
-  if (!attr_set) {
-    GNNRAG_HIP(hipFuncSetAttribute((const void*)k_bwd_tables<MODE, true>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    GNNRAG_HIP(hipFuncSetAttribute((const void*)k_bwd_tables<MODE, false>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+  static DeviceMask cap_v4, cap_v1;   // per instantiation, per device
+  {
+    int rc = raise_lds_cap(k_bwd_tables<MODE, true>, cap_v4);
+    if (rc) return rc;
+    rc = raise_lds_cap(k_bwd_tables<MODE, false>, cap_v1);
+    if (rc) return rc;
   }
   if (v4) hipLaunchKernelGGL((k_bwd_tables<MODE, true>), dim3(nblk), dim3(kBwdThreads), lds, stream, a,
                              (const int2*)pr, F, V, nslice);

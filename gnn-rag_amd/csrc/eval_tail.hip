@@ -93,11 +93,10 @@ extern "C" int gnnrag_topp_candidates(const float* pred_dist, const uint8_t* eli
   const size_t lds = ((size_t)1 << log2) * sizeof(unsigned long long);
 #define GNNRAG_TOPP(L)                                                                                       \
   case L: {                                                                                                  \
-    static bool attr_set = false;                                                                            \
-    if (!attr_set && lds > 64 * 1024) {                                                                      \
-      GNNRAG_HIP(hipFuncSetAttribute((const void*)k_topp_candidates<L>,                                      \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));              \
-      attr_set = true;                                                                                       \
+    static DeviceMask cap_raised;                                                                            \
+    if (lds > 64 * 1024) {                                                                                   \
+      const int rc_ = raise_lds_cap(k_topp_candidates<L>, cap_raised);                                       \
+      if (rc_) return rc_;                                                                                   \
     }                                                                                                        \
     hipLaunchKernelGGL(k_topp_candidates<L>, dim3(B), dim3(1024), lds, stream, pred_dist, eligible, N,       \
                        ignore_prob, eps, out_slot, out_cnt);                                                 \

@@ -29,6 +29,10 @@
 // (register blow-up), direct stores from the MFMA layout instead of the LDS-staged epilogue (-25 % on the
 // self-block update).
 #define GNNRAG_GEMM_MT1_NW 8     // the one-row-tile-per-wave variant may use 8-wave (128-row) workgroups
+#ifndef GNNRAG_GEMM_ABL
+#define GNNRAG_GEMM_ABL 0        // timing-only ablation builds (tools/tune_variants.py): 1 no MFMA, 2 no epilogue
+                                 // traffic, 4 no global loads in the k loop, 8 no LDS restaging in the k loop
+#endif
 
 namespace gnnrag {
 
@@ -288,8 +292,10 @@ void k_gemm_f32(GemmArgs g) {
   const int fr = lane & 15;  // fragment row (A) / column (W) inside a 16x16 tile
   const int fg = lane >> 4;  // k group
   for (int t = 0; t < nT; ++t) {
-    if (t + 1 < nT) gload(t + 1);      // tile t+1 is in flight while tile t (in LDS) is multiplied
-    if constexpr (MATH == 0) {
+    if (t + 1 < nT && !(GNNRAG_GEMM_ABL & 4)) gload(t + 1);      // tile t+1 is in flight while tile t (in LDS) is multiplied
+    if constexpr (GNNRAG_GEMM_ABL & 1) {
+      acc[0][0][0] += As[(wave * 16 * MT + fr) * kLS + fg * 4 + (t & 3)];
+    } else if constexpr (MATH == 0) {
 #pragma unroll
       for (int c = 0; c < kBK / 16; ++c) {
         f32x4 a[MT];
@@ -343,11 +349,22 @@ void k_gemm_f32(GemmArgs g) {
                                                                            acc[mt][nt0 + q], 0, 0, 0);
       }
     }
+    if constexpr (!(GNNRAG_GEMM_ABL & 8)) {
     __syncthreads();
     if (t + 1 < nT) {
       sstore();
       __syncthreads();
     }
+    }
+  }
+  if constexpr ((GNNRAG_GEMM_ABL & 2) != 0) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) sacc += acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2] + acc[mt][nt][3];
+    if (sacc == 12345.678f) g.C[tid] = sacc;
+    return;
   }
 
   // ---- epilogue -------------------------------------------------------------------------------
@@ -456,8 +473,6 @@ __global__ __launch_bounds__(256) void k_score_rows(const float* __restrict__ h,
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-// process-wide math mode of the dense projections (like a BLAS math mode): 0 = fp32 MFMA, 1 = bf16x3
-static int g_dense_math = 0;
 
 // ---- skinny problems (M up to a few thousand rows, e.g. the [R1,D] relation transforms) ------
 // The tiled kernel would run them on M/128 workgroups (5 for R1 = 602) and be latency bound.
@@ -512,8 +527,10 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs g) {
   }
 }
 
+static bool math_ok(int math) { return math == GNNRAG_MATH_FP32 || math == GNNRAG_MATH_BF16X3; }
+
 template <int EPI, int AMODE>
-static int launch_gemm(GemmArgs g, hipStream_t stream) {
+static int launch_gemm(GemmArgs g, hipStream_t stream, int math) {
   if (g.M <= 0) return 0;
   const bool v4 = (g.K % 4 == 0) && (g.K0 % 4 == 0) && (g.ldw % 4 == 0) && (g.wc0 % 4 == 0) &&
                   aligned16(g.A0) && aligned16(g.W) && (g.A1 == nullptr || aligned16(g.A1)) &&
@@ -540,7 +557,7 @@ static int launch_gemm(GemmArgs g, hipStream_t stream) {
   const int bm = small_tiles ? (nw8 ? 128 : 64) : 128;
   const dim3 grid((g.M + bm - 1) / bm, ny);
   const int ncol = g.Nout - g.n0;
-  const bool b3 = g_dense_math == 1;
+  const bool b3 = math == GNNRAG_MATH_BF16X3;
   g.v4out = (g.Nout % 4 == 0) && (g.n0 % 4 == 0) && aligned16(g.C) && (g.add == nullptr || aligned16(g.add));
 #define GNNRAG_GEMM_LAUNCH(NT, MT, V, MATH, NW) \
   hipLaunchKernelGGL((k_gemm_f32<NT, MT, V, EPI, AMODE, MATH, NW>), grid, dim3(64 * NW), 0, stream, g)
@@ -573,18 +590,10 @@ static int launch_gemm(GemmArgs g, hipStream_t stream) {
 
 using namespace gnnrag;
 
-extern "C" int gnnrag_set_dense_math(int mode) {
-  if (mode != GNNRAG_MATH_FP32 && mode != GNNRAG_MATH_BF16X3) return GNNRAG_E_BADARG;
-  g_dense_math = mode;
-  return 0;
-}
-
-extern "C" int gnnrag_get_dense_math(void) { return g_dense_math; }
-
 extern "C" int gnnrag_linear(const float* A, int64_t M, int32_t K, const float* W, const float* bias,
                              const float* add, int64_t add_rows, int relu, float* C, int32_t Nout,
-                             gnnrag_stream_t stream) {
-  if (!A || !W || !C || M < 0 || K <= 0 || Nout <= 0) return GNNRAG_E_BADARG;
+                             int32_t math, gnnrag_stream_t stream) {
+  if (!A || !W || !C || M < 0 || K <= 0 || Nout <= 0 || !math_ok(math)) return GNNRAG_E_BADARG;
   if (M >= ((int64_t)1 << 31)) return GNNRAG_E_UNSUPPORTED;
   GemmArgs g;
   memset(&g, 0, sizeof(g));
@@ -594,7 +603,7 @@ extern "C" int gnnrag_linear(const float* A, int64_t M, int32_t K, const float* 
   g.relu = relu;
   for (int n0 = 0; n0 < Nout; n0 += 208) {
     g.n0 = n0;
-    const int rc = launch_gemm<EPI_LINEAR, AMODE_PLAIN>(g, (hipStream_t)stream);
+    const int rc = launch_gemm<EPI_LINEAR, AMODE_PLAIN>(g, (hipStream_t)stream, math);
     if (rc == (1 << 30)) break;
     if (rc) return rc;
   }
@@ -602,16 +611,16 @@ extern "C" int gnnrag_linear(const float* A, int64_t M, int32_t K, const float* 
 }
 
 // shared by the two update entry points: h' = relu(A.W^T + b (+ add)), score = score_func(h') + mask term
-static int update_common(GemmArgs g, int64_t BN, int32_t D, hipStream_t stream) {
+static int update_common(GemmArgs g, int64_t BN, int32_t D, hipStream_t stream, int math) {
   if (D <= 208) {
     g.n0 = 0;
-    return launch_gemm<EPI_UPDATE, AMODE_PLAIN>(g, stream);
+    return launch_gemm<EPI_UPDATE, AMODE_PLAIN>(g, stream, math);
   }
   // wide hidden sizes: column blocks of 208 with bias(+add)+ReLU epilogue, then a row-dot for the score
   g.relu = 1;
   for (int n0 = 0; n0 < D; n0 += 208) {
     g.n0 = n0;
-    const int rc = launch_gemm<EPI_LINEAR, AMODE_PLAIN>(g, stream);
+    const int rc = launch_gemm<EPI_LINEAR, AMODE_PLAIN>(g, stream, math);
     if (rc == (1 << 30)) break;
     if (rc) return rc;
   }
@@ -623,27 +632,29 @@ static int update_common(GemmArgs g, int64_t BN, int32_t D, hipStream_t stream) 
 
 extern "C" int gnnrag_linear_pair(const float* A0, const float* A1, int64_t M, int32_t K, const float* W,
                                   const float* bias, const float* add0, const float* add1, int64_t add_rows,
-                                  float* C0, float* C1, int32_t Nout, gnnrag_stream_t stream) {
-  if (!A0 || !A1 || !W || !C0 || !C1 || M < 0 || K <= 0 || Nout <= 0) return GNNRAG_E_BADARG;
+                                  float* C0, float* C1, int32_t Nout, int32_t math, gnnrag_stream_t stream) {
+  if (!A0 || !A1 || !W || !C0 || !C1 || M < 0 || K <= 0 || Nout <= 0 || !math_ok(math)) return GNNRAG_E_BADARG;
   if ((add0 == nullptr) != (add1 == nullptr)) return GNNRAG_E_BADARG;
   if (M > kSkinnyMaxM) {     // large problems: two ordinary launches
-    int rc = gnnrag_linear(A0, M, K, W, bias, add0, add_rows, 0, C0, Nout, stream);
+    int rc = gnnrag_linear(A0, M, K, W, bias, add0, add_rows, 0, C0, Nout, math, stream);
     if (rc) return rc;
-    return gnnrag_linear(A1, M, K, W, bias, add1, add_rows, 0, C1, Nout, stream);
+    return gnnrag_linear(A1, M, K, W, bias, add1, add_rows, 0, C1, Nout, math, stream);
   }
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.A0 = A0; g.A0b = A1; g.W = W; g.bias = bias; g.add = add0; g.add_b = add1; g.C = C0; g.C_b = C1;
   g.M = (int32_t)M; g.K = K; g.K0 = K; g.Nout = Nout; g.ldw = K;
   g.add_rows = add0 ? (int32_t)(add_rows < M ? add_rows : M) : 0;
-  const int rc = launch_gemm<EPI_LINEAR, AMODE_PLAIN>(g, (hipStream_t)stream);
+  const int rc = launch_gemm<EPI_LINEAR, AMODE_PLAIN>(g, (hipStream_t)stream, math);
   return rc == (1 << 30) ? 0 : rc;
 }
 
 extern "C" int gnnrag_update_score(const float* h, const float* agg, const float* W, const float* b,
                                    const float* w_s, const float* b_s, const float* mask, float* h_out,
-                                   float* score, int64_t BN, int32_t D, int32_t I, gnnrag_stream_t stream) {
-  if (!h || !agg || !W || !b || !w_s || !b_s || !mask || !h_out || !score || BN < 0 || D <= 0 || I <= 0)
+                                   float* score, int64_t BN, int32_t D, int32_t I, int32_t math,
+                                   gnnrag_stream_t stream) {
+  if (!h || !agg || !W || !b || !w_s || !b_s || !mask || !h_out || !score || BN < 0 || D <= 0 || I <= 0 ||
+      !math_ok(math))
     return GNNRAG_E_BADARG;
   if (BN >= ((int64_t)1 << 31)) return GNNRAG_E_UNSUPPORTED;
   GemmArgs g;
@@ -652,14 +663,15 @@ extern "C" int gnnrag_update_score(const float* h, const float* agg, const float
   g.w_s = w_s; g.b_s = b_s; g.mask = mask; g.score = score;
   g.M = (int32_t)BN; g.K = (2 * I + 1) * D; g.K0 = D; g.Nout = D; g.ldw = g.K;
   g.relu = 1;
-  return update_common(g, BN, D, (hipStream_t)stream);
+  return update_common(g, BN, D, (hipStream_t)stream, math);
 }
 
 extern "C" int gnnrag_update_score_fused(const float* h, const float* nbr, const float* W, const float* b,
                                          const float* w_s, const float* b_s, const float* mask, float* h_out,
-                                         float* score, int64_t BN, int32_t D, int32_t I,
+                                         float* score, int64_t BN, int32_t D, int32_t I, int32_t math,
                                          gnnrag_stream_t stream) {
-  if (!h || !nbr || !W || !b || !w_s || !b_s || !mask || !h_out || !score || BN < 0 || D <= 0 || I <= 0)
+  if (!h || !nbr || !W || !b || !w_s || !b_s || !mask || !h_out || !score || BN < 0 || D <= 0 || I <= 0 ||
+      !math_ok(math))
     return GNNRAG_E_BADARG;
   if (BN >= ((int64_t)1 << 31)) return GNNRAG_E_UNSUPPORTED;
   GemmArgs g;
@@ -670,13 +682,14 @@ extern "C" int gnnrag_update_score_fused(const float* h, const float* nbr, const
   g.w_s = w_s; g.b_s = b_s; g.mask = mask; g.score = score;
   g.M = (int32_t)BN; g.K = D; g.K0 = D; g.Nout = D; g.ldw = (2 * I + 1) * D; g.wc0 = 0;
   g.relu = 1;
-  return update_common(g, BN, D, (hipStream_t)stream);
+  return update_common(g, BN, D, (hipStream_t)stream, math);
 }
 
 extern "C" int gnnrag_relation_tables(const gnnrag_csr* csr, const float* T_fwd, const float* T_inv,
                                       const float* ins, const float* W, float* P, int32_t D, int32_t I,
-                                      gnnrag_stream_t stream) {
-  if (!csr || !T_fwd || !T_inv || !ins || !W || !P || D <= 0 || I <= 0 || csr->rel_total < 0) return GNNRAG_E_BADARG;
+                                      int32_t math, gnnrag_stream_t stream) {
+  if (!csr || !T_fwd || !T_inv || !ins || !W || !P || D <= 0 || I <= 0 || csr->rel_total < 0 || !math_ok(math))
+    return GNNRAG_E_BADARG;
   if (csr->rel_total == 0) return 0;      // no facts, no tables
   GemmArgs g;
   memset(&g, 0, sizeof(g));
@@ -689,7 +702,7 @@ extern "C" int gnnrag_relation_tables(const gnnrag_csr* csr, const float* T_fwd,
   g.gen_rows = (const int2*)csr->rel_rows; g.gen_D = D; g.gen_I = I;
   for (int n0 = 0; n0 < D; n0 += 208) {
     g.n0 = n0;
-    const int rc = launch_gemm<EPI_LINEAR, AMODE_GEN>(g, (hipStream_t)stream);
+    const int rc = launch_gemm<EPI_LINEAR, AMODE_GEN>(g, (hipStream_t)stream, math);
     if (rc) return rc;
   }
   return 0;

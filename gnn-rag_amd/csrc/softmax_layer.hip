@@ -147,7 +147,7 @@ extern "C" int gnnrag_reason_layer(const gnnrag_csr* csr, const float* h, const 
                                    int32_t pos_rows, const float* W_e2e, const float* b_e2e,
                                    const float* w_score, const float* b_score, const float* mask,
                                    float* h_out, float* score_out, float* dist_out, void* workspace,
-                                   size_t workspace_bytes, int32_t D, int32_t I, int32_t path,
+                                   size_t workspace_bytes, int32_t D, int32_t I, int32_t path, int32_t math,
                                    gnnrag_stream_t stream) {
   if (!csr || !h || !dist || !ins || !relfeat_fwd || !relfeat_inv || !W_rel || !b_rel || !W_e2e || !b_e2e ||
       !w_score || !b_score || !mask || !h_out || !score_out || !dist_out || !workspace || D <= 0 || I <= 0)
@@ -162,25 +162,26 @@ extern "C" int gnnrag_reason_layer(const gnnrag_csr* csr, const float* h, const 
   int rc;
   // T_d = rel_linear(rel_features_d) (+ pos_emb_d): once per relation row, not once per fact
   rc = gnnrag_linear_pair(relfeat_fwd, relfeat_inv, csr->R1, D, W_rel, b_rel, pos_fwd, pos_inv,
-                          pos_fwd ? pos_rows : 0, T_fwd, T_inv, D, stream);
+                          pos_fwd ? pos_rows : 0, T_fwd, T_inv, D, math, stream);
   if (rc) return rc;
   if (path == GNNRAG_PATH_AUTO)
     path = fused_is_cheaper(csr->B, csr->N, csr->rel_total, D, I) ? GNNRAG_PATH_FUSED : GNNRAG_PATH_UNFUSED;
   if (path == GNNRAG_PATH_FUSED) {
     float* P = (float*)(base + w.P);
     float* nbr = (float*)(base + w.nbr);
-    rc = gnnrag_relation_tables(csr, T_fwd, T_inv, ins, W_e2e, P, D, I, stream);
+    rc = gnnrag_relation_tables(csr, T_fwd, T_inv, ins, W_e2e, P, D, I, math, stream);
     if (rc) return rc;
     rc = gnnrag_aggregate_fused(csr, dist, P, nbr, D, base + w.partial, w.partial_bytes, stream);
     if (rc) return rc;
     rc = gnnrag_update_score_fused(h, nbr, W_e2e, b_e2e, w_score, b_score, mask, h_out, score_out, BN, D, I,
-                                   stream);
+                                   math, stream);
     if (rc) return rc;
   } else {
     float* agg = (float*)(base + w.agg);
     rc = gnnrag_aggregate(csr, dist, ins, T_fwd, T_inv, agg, D, I, base + w.partial, w.partial_bytes, stream);
     if (rc) return rc;
-    rc = gnnrag_update_score(h, agg, W_e2e, b_e2e, w_score, b_score, mask, h_out, score_out, BN, D, I, stream);
+    rc = gnnrag_update_score(h, agg, W_e2e, b_e2e, w_score, b_score, mask, h_out, score_out, BN, D, I, math,
+                             stream);
     if (rc) return rc;
   }
   return gnnrag_masked_softmax(score_out, dist_out, csr->B, csr->N, stream);

@@ -80,9 +80,10 @@ class FactCache:
     copy); the two weight "lists" are float64 arrays - every consumer in the reference
     (``torch.FloatTensor(weight_list)``, ``base_gnn.py:38-40``, ``layer_init.py:39-40``) takes either."""
 
-    def __init__(self, loader):
+    def __init__(self, loader, max_questions: int = 200000):
         self.loader = loader
         self._q = {}
+        self.max_questions = max_questions      # questions kept; beyond that they are rebuilt per batch
 
     def _question(self, sample_id):
         q = self._q.get(sample_id)
@@ -105,7 +106,9 @@ class FactCache:
                 wr = 1.0 / cnt[inv]                                           # :513-517
             else:
                 w = wr = np.zeros(0)
-            q = self._q[sample_id] = (np.stack([h, r, t]), w, wr)
+            q = (np.stack([h, r, t]), w, wr)
+            if len(self._q) < self.max_questions:
+                self._q[sample_id] = q
         return q
 
     def batch(self, sample_ids):
@@ -122,13 +125,22 @@ class FactCache:
         return hrt[0], hrt[1], hrt[2], batch_ids, np.arange(F, dtype=np.int64), cat(1), cat(2)
 
 
-def patch_loader(loader, cache: bool = False):
+def patch_loader(loader, cache: bool = False, keep_rng_stream: bool = False):
     """Rebinds ``loader._build_fact_mat`` to the vectorised builder (the reference file is untouched).
-    ``cache=True`` additionally serves ``fact_dropout == 0`` batches from a :class:`FactCache`."""
+    ``cache=True`` additionally serves ``fact_dropout == 0`` batches from a :class:`FactCache`.  The cached
+    path does not draw the per-question ``np.random.permutation`` the reference draws even without dropout
+    (``dataset_load.py:489-490``), so a run that interleaves cached evaluation batches with training batches
+    (``train_model.py`` evaluates on ``valid`` every epoch) consumes a different numpy RNG stream than the
+    reference; ``keep_rng_stream=True`` draws and discards those permutations (same stream as the reference,
+    at the cost of most of the caching gain).  Use the plain cache for evaluation-only runs."""
     fc = FactCache(loader) if cache else None
 
     def build(self, sample_ids, fact_dropout):
         if fc is not None and fact_dropout == 0:
+            if keep_rng_stream:
+                for sample_id in sample_ids:
+                    n = len(self.create_kb_adj_mats(sample_id)[0]) if self.data_eff else len(self.kb_adj_mats[sample_id][0])
+                    np.random.permutation(n)                                   # dataset_load.py:489
             return fc.batch(sample_ids)
         return build_fact_mat(self, sample_ids, fact_dropout)
 

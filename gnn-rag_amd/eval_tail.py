@@ -25,12 +25,37 @@ import torch
 from . import ops
 
 
+TOPP_MAX_N = 16384      # slots per question the selection kernel sorts in one CU's LDS (eval_tail.hip)
+
+
+def _host_candidates(pred_dist: torch.Tensor, eligible: np.ndarray, local_entity: np.ndarray, ignore_prob: float,
+                     eps: float):
+    """The reference's own host-side selection (evaluate.py:188-207 then :34-51) for subgraphs with more node
+    slots than the kernel sorts in LDS (N > TOPP_MAX_N; the reference handles every size this way)."""
+    probs = pred_dist.detach().float().cpu().numpy()
+    out = []
+    for b in range(probs.shape[0]):
+        p = probs[b].astype(np.float64)
+        keep = np.flatnonzero(eligible[b] & ~(p < ignore_prob))
+        order = keep[np.argsort(-p[keep], kind="stable")]            # sorted(..., reverse=True) is stable too
+        tp, k = 0.0, 0
+        for j in order:                                              # sequential fp64 adds, as the Python loop
+            tp += float(p[j])
+            k += 1
+            if tp > eps:
+                break
+        out.append(([(int(local_entity[b, j]), float(probs[b, j])) for j in order[:k]], int(len(order))))
+    return out
+
+
 def retrieved_candidates(pred_dist: torch.Tensor, local_entity: np.ndarray, query_entities: np.ndarray,
                          pad_ent_id: int, ignore_prob: float, eps: float):
     """Per question the list ``[(entity id, prob), ...]`` that ``f1_and_hits`` would retrieve, best first,
     and the number of candidates that passed the filter.  ``pred_dist`` stays on the GPU."""
     # evaluate.py:177,198-205: the seed flags are compared after a cast to int64
     eligible = (np.asarray(query_entities).astype(np.int64) != 1) & (np.asarray(local_entity) != pad_ent_id)
+    if pred_dist.shape[1] > TOPP_MAX_N:
+        return _host_candidates(pred_dist, eligible, np.asarray(local_entity), ignore_prob, eps)
     el = torch.from_numpy(eligible.astype(np.uint8)).to(pred_dist.device)
     pred_dist = pred_dist.detach().float().contiguous()
     slots, cnt = ops.topp_candidates(pred_dist, el, ignore_prob, eps)

@@ -29,12 +29,14 @@ def plan_for(edge_list, B: int, N: int, R1: int, device) -> "ops.CsrPlan":
     return plan
 
 
-def _device_from_args(args) -> torch.device:
+def _device_from_args(args, like: torch.Tensor = None) -> torch.device:
     if not args.get("use_cuda", False):
         raise GnnragError("gnnrag_amd runs on the GPU only (args['use_cuda'] is False); "
                           "use the reference modules for a CPU run")
     if not torch.cuda.is_available():
         raise GnnragError("no ROCm device visible to torch; gnnrag_amd has no CPU fallback")
+    if like is not None and like.is_cuda:
+        return like.device          # the device the model's tensors live on, not whatever is current
     return torch.device("cuda", torch.cuda.current_device())
 
 
@@ -59,7 +61,7 @@ class BaseGNNLayer(torch.nn.Module):
         """Same inputs as the reference method (``self.edge_list``, ``self.batch_size``,
         ``self.max_local_entity``, ``self.num_relation`` = rows of the relation tables,
         set by ``init_reason``); result is ``self.plan``."""
-        device = _device_from_args(self._args)
+        device = _device_from_args(self._args, getattr(self, "rel_features", None))
         edge_list = self.edge_list
         self.num_fact = len(edge_list[4])
         self.plan = plan_for(edge_list, self.batch_size, self.max_local_entity, self.num_relation, device)

@@ -40,10 +40,10 @@ class QueryReform(nn.Module):
         self.q_ent_attn = nn.Linear(h_dim, h_dim)      # unused by the returned value; state_dict parity
 
     def forward(self, q_node, ent_emb, seed_info, ent_mask):
-        if torch.is_grad_enabled() or not ent_emb.is_cuda:
-            seed_retrieve = torch.bmm(seed_info.unsqueeze(1), ent_emb).squeeze(1)       # :40
+        if torch.is_grad_enabled():
+            seed_retrieve = torch.bmm(seed_info.unsqueeze(1), ent_emb).squeeze(1)       # :40 (autograd form)
         else:
-            seed_retrieve = ops.seed_retrieve(seed_info.float(), ent_emb.float())
+            seed_retrieve = ops.seed_retrieve(seed_info.float(), ent_emb.float())       # raises on CPU tensors
         return self.fusion(q_node, seed_retrieve)                                       # :44
 
 

@@ -3,12 +3,37 @@ PyTorch-ROCm (plumbing), every computation is a call into libgnnrag_hip.so."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import numpy as np
 import torch
 
 from . import _lib
+
+
+MATH_FP32, MATH_BF16X3 = 0, 1
+# Math mode the wrappers below pass to the library (the library itself keeps no mode: it is an argument of
+# every dense entry point).  GNNRAG_MATH=fp32|bf16x3 sets the binding's default for A/B runs.
+_default_math = {"fp32": MATH_FP32, "bf16x3": MATH_BF16X3}[os.environ.get("GNNRAG_MATH", "fp32")]
+
+
+def set_dense_math(mode: int) -> int:
+    """Default math mode of this binding's dense calls: MATH_FP32 (exact fp32 MFMA) or MATH_BF16X3 (exact
+    3-way bf16 split, six plane products, fp32 accumulate).  Returns the old mode."""
+    global _default_math
+    if mode not in (MATH_FP32, MATH_BF16X3):
+        raise ValueError("unknown math mode %r" % (mode,))
+    old, _default_math = _default_math, int(mode)
+    return old
+
+
+def get_dense_math() -> int:
+    return _default_math
+
+
+def _math(math: Optional[int]) -> int:
+    return _default_math if math is None else int(math)
 
 
 def _stream() -> int:
@@ -29,6 +54,12 @@ def _chk(t: torch.Tensor, name: str, dtype=torch.float32, shape=None) -> torch.T
     if shape is not None and tuple(t.shape) != tuple(shape):
         raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
     return t
+
+
+def _on_plan_device(plan: "CsrPlan", t: torch.Tensor, name: str) -> None:
+    """The structure's raw device pointers are only valid on the GPU it was built on."""
+    if t.device != plan.device and not (t.is_cuda and plan.device.index is None):
+        raise _lib.GnnragError("%s lives on %s but the structure was built on %s" % (name, t.device, plan.device))
 
 
 class CsrPlan:
@@ -56,11 +87,21 @@ class CsrPlan:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.GnnragError("CsrPlan needs a GPU device, got %s" % self.device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         base = heads.base
-        if (F and base is not None and heads.dtype == np.int32 and base is rels.base and base is tails.base
-                and base.shape == (3, F) and base.flags.c_contiguous and heads.ctypes.data == base.ctypes.data):
+        if (F and isinstance(base, np.ndarray) and heads.dtype == np.int32 and base is rels.base
+                and base is tails.base and base.dtype == np.int32 and base.shape == (3, F) and base.flags.c_contiguous
+                and heads.ctypes.data == base[0].ctypes.data and rels.ctypes.data == base[1].ctypes.data
+                and tails.ctypes.data == base[2].ctypes.data and heads.shape == rels.shape == tails.shape == (F,)
+                and heads.strides == rels.strides == tails.strides == (4,)):
             hrt = base                  # the batch builder's own [3,F] int32 block (data/fact_mat.py): no copy
         else:
+            for name, a in (("heads", heads), ("rels", rels), ("tails", tails)):
+                # ids that do not fit int32 would wrap when narrowed and could then pass the device-side range
+                # check: one unsigned max per array (negative ids show up as huge values)
+                if F and a.dtype.itemsize > 4 and int(a.view(np.uint64 if a.dtype.itemsize == 8 else a.dtype).max()) >= 2 ** 31:
+                    raise ValueError("edge tuple out of range: %s holds ids outside [0, 2^31)" % name)
             hrt = np.empty((3, max(F, 1)), dtype=np.int32)
             hrt[0, :F], hrt[1, :F], hrt[2, :F] = heads, rels, tails
         with torch.cuda.device(self.device):
@@ -195,7 +236,7 @@ class CsrPlan:
 
 
 def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
-           add: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+           add: Optional[torch.Tensor] = None, relu: bool = False, math: Optional[int] = None) -> torch.Tensor:
     """act(A W^T + bias (+ add on the first add.shape[0] rows)) on fp32 MFMA."""
     lib = _lib.load()
     A = _chk(A, "A")
@@ -214,7 +255,7 @@ def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None
     out = torch.empty((M, Nout), dtype=torch.float32, device=A.device)
     with torch.cuda.device(A.device):
         _lib.check(lib.gnnrag_linear(A.data_ptr(), M, K, W.data_ptr(), _ptr(bias), _ptr(add), add_rows,
-                                     int(relu), out.data_ptr(), Nout, _stream()), "gnnrag_linear")
+                                     int(relu), out.data_ptr(), Nout, _math(math), _stream()), "gnnrag_linear")
     return out
 
 
@@ -225,6 +266,7 @@ def aggregate(plan: CsrPlan, dist: torch.Tensor, ins: torch.Tensor, T_fwd: torch
     ins = _chk(ins, "ins")
     _, I, D = ins.shape
     dist = _chk(dist, "dist").reshape(-1)
+    _on_plan_device(plan, dist, "dist")
     if dist.numel() != B * N or ins.shape[0] != B:
         raise ValueError("dist/ins do not match the plan (B=%d, N=%d)" % (B, N))
     T_fwd = _chk(T_fwd, "T_fwd", shape=(plan.R1, D))
@@ -239,7 +281,7 @@ def aggregate(plan: CsrPlan, dist: torch.Tensor, ins: torch.Tensor, T_fwd: torch
 
 
 def relation_tables(plan: CsrPlan, T_fwd: torch.Tensor, T_inv: torch.Tensor, ins: torch.Tensor,
-                    W_e2e: torch.Tensor) -> torch.Tensor:
+                    W_e2e: torch.Tensor, math: Optional[int] = None) -> torch.Tensor:
     """P[d,row(b,r),:] = sum_i W_e2e[:, block(i,d)] relu(T_d[r,:] * ins[b,i,:])  ->  [2,rel_total,D],
     one row per (question, relation the question uses) - ``plan.rel_rows()`` lists them."""
     lib = _lib.load()
@@ -253,9 +295,23 @@ def relation_tables(plan: CsrPlan, T_fwd: torch.Tensor, T_inv: torch.Tensor, ins
     P = torch.empty((2, plan.rel_total, D), dtype=torch.float32, device=ins.device)
     with torch.cuda.device(ins.device):
         _lib.check(lib.gnnrag_relation_tables(C.byref(plan.c), T_fwd.data_ptr(), T_inv.data_ptr(), ins.data_ptr(),
-                                              W_e2e.data_ptr(), P.data_ptr(), D, I, _stream()),
+                                              W_e2e.data_ptr(), P.data_ptr(), D, I, _math(math), _stream()),
                    "gnnrag_relation_tables")
     return P
+
+
+WALK_L2_GATHER, WALK_LDS_16, WALK_LDS_32 = 0, 1, 2
+WALK_KERNEL_NAMES = {WALK_L2_GATHER: "k_walk_light<FUSED> (table rows gathered from L2)",
+                     WALK_LDS_16: "k_fact_prior + k_walk_slice<FUSED,1> (16-column table slices in LDS)",
+                     WALK_LDS_32: "k_fact_prior + k_walk_slice<FUSED,2> (32-column table slices in LDS)"}
+
+
+def aggregate_fused_variant(plan: CsrPlan, D: int) -> int:
+    """Which kernel ``aggregate_fused`` runs for this structure and hidden size (WALK_*)."""
+    v = _lib.load().gnnrag_aggregate_fused_variant(C.byref(plan.c), int(D))
+    if v < 0:
+        _lib.check(v, "gnnrag_aggregate_fused_variant")
+    return v
 
 
 def aggregate_fused(plan: CsrPlan, dist: torch.Tensor, P: torch.Tensor) -> torch.Tensor:
@@ -266,6 +322,7 @@ def aggregate_fused(plan: CsrPlan, dist: torch.Tensor, P: torch.Tensor) -> torch
     if tuple(P.shape) != (2, plan.rel_total, D):
         raise ValueError("P must be [2, plan.rel_total, D]")
     dist = _chk(dist, "dist").reshape(-1)
+    _on_plan_device(plan, dist, "dist")
     out = torch.empty((B * N, D), dtype=torch.float32, device=dist.device)
     ws = plan.walk_workspace(D, 1)
     with torch.cuda.device(dist.device):
@@ -274,7 +331,7 @@ def aggregate_fused(plan: CsrPlan, dist: torch.Tensor, P: torch.Tensor) -> torch
     return out
 
 
-def update_score_fused(h, nbr, W, b, w_s, b_s, mask, I: int):
+def update_score_fused(h, nbr, W, b, w_s, b_s, mask, I: int, math: Optional[int] = None):
     lib = _lib.load()
     h = _chk(h, "h")
     BN, D = h.shape
@@ -289,11 +346,12 @@ def update_score_fused(h, nbr, W, b, w_s, b_s, mask, I: int):
     with torch.cuda.device(h.device):
         _lib.check(lib.gnnrag_update_score_fused(h.data_ptr(), nbr.data_ptr(), W.data_ptr(), b.data_ptr(),
                                                  w_s.data_ptr(), b_s.data_ptr(), mask.data_ptr(), h_out.data_ptr(),
-                                                 score.data_ptr(), BN, D, I, _stream()), "gnnrag_update_score_fused")
+                                                 score.data_ptr(), BN, D, I, _math(math), _stream()),
+                   "gnnrag_update_score_fused")
     return h_out, score
 
 
-def update_score(h, agg, W, b, w_s, b_s, mask, I: int):
+def update_score(h, agg, W, b, w_s, b_s, mask, I: int, math: Optional[int] = None):
     lib = _lib.load()
     h = _chk(h, "h")
     BN, D = h.shape
@@ -310,7 +368,7 @@ def update_score(h, agg, W, b, w_s, b_s, mask, I: int):
     with torch.cuda.device(h.device):
         _lib.check(lib.gnnrag_update_score(h.data_ptr(), agg.data_ptr(), W.data_ptr(), b.data_ptr(),
                                            w_s.data_ptr(), b_s.data_ptr(), mask.data_ptr(), h_out.data_ptr(),
-                                           score.data_ptr(), BN, D, I, _stream()), "gnnrag_update_score")
+                                           score.data_ptr(), BN, D, I, _math(math), _stream()), "gnnrag_update_score")
     return h_out, score
 
 
@@ -329,6 +387,7 @@ def masked_softmax(score: torch.Tensor, B: int, N: int) -> torch.Tensor:
 def typelayer(plan: CsrPlan, T: torch.Tensor, use_w_rel: bool) -> torch.Tensor:
     lib = _lib.load()
     T = _chk(T, "T")
+    _on_plan_device(plan, T, "T")
     D = T.shape[1]
     if T.shape[0] != plan.R1:
         raise ValueError("T has %d rows, plan has R1=%d" % (T.shape[0], plan.R1))
@@ -406,7 +465,7 @@ class LayerWorkspace:
 
 def reason_layer(plan: CsrPlan, h, dist, ins, relfeat, relfeat_inv, W_rel, b_rel, W_e2e, b_e2e, w_score,
                  b_score, mask, pos=None, pos_inv=None, ws: Optional[LayerWorkspace] = None,
-                 path: int = _lib.PATH_AUTO):
+                 path: int = _lib.PATH_AUTO, math: Optional[int] = None):
     """One ReasonGNNLayer.forward (reasongnn.py:134-174) = ONE call into the library.
     Returns (h_out [B,N,D], score [B,N], dist_out [B,N])."""
     lib = _lib.load()
@@ -414,6 +473,7 @@ def reason_layer(plan: CsrPlan, h, dist, ins, relfeat, relfeat_inv, W_rel, b_rel
     ins = _chk(ins, "ins")
     _, I, D = ins.shape
     h = _chk(h, "h").reshape(B * N, D)
+    _on_plan_device(plan, h, "local_entity_emb")
     dist = _chk(dist, "dist").reshape(-1)
     mask = _chk(mask, "mask").reshape(-1)
     relfeat = _chk(relfeat, "rel_features", shape=(R1, D))
@@ -444,7 +504,7 @@ def reason_layer(plan: CsrPlan, h, dist, ins, relfeat, relfeat_inv, W_rel, b_rel
             relfeat_inv.data_ptr(), W_rel.data_ptr(), b_rel.data_ptr(), _ptr(pos), _ptr(pos_inv), pos_rows,
             W_e2e.data_ptr(), b_e2e.data_ptr(), w_score.data_ptr(), b_score.data_ptr(), mask.data_ptr(),
             h_out.data_ptr(), score.data_ptr(), dist_out.data_ptr(), wbuf.data_ptr(), wbuf.numel(), D, I,
-            int(path), _stream()), "gnnrag_reason_layer")
+            int(path), _math(math), _stream()), "gnnrag_reason_layer")
     return h_out, score, dist_out
 
 
@@ -478,22 +538,6 @@ def topp_candidates(pred_dist: torch.Tensor, eligible: torch.Tensor, ignore_prob
                                               float(eps), slots.data_ptr(), cnt.data_ptr(), _stream()),
                    "gnnrag_topp_candidates")
     return slots, cnt
-
-
-MATH_FP32, MATH_BF16X3 = 0, 1
-
-
-def set_dense_math(mode: int) -> int:
-    """Math mode of the dense projections (process wide): MATH_FP32 (exact fp32 MFMA) or
-    MATH_BF16X3 (exact 3-way bf16 split, six plane products, fp32 accumulate).  Returns the old mode."""
-    lib = _lib.load()
-    old = lib.gnnrag_get_dense_math()
-    _lib.check(lib.gnnrag_set_dense_math(int(mode)), "gnnrag_set_dense_math")
-    return old
-
-
-def get_dense_math() -> int:
-    return _lib.load().gnnrag_get_dense_math()
 
 
 def stream_copy(src: torch.Tensor, dst: torch.Tensor):

@@ -13,7 +13,10 @@
  *    owned by the caller; the library never allocates, frees or retains them.
  *  - all work is enqueued on the given hipStream_t (passed as void*); no internal
  *    synchronisation (one exception: gnnrag_csr_build waits for the stream once, to hand the
- *    relation counts back to the host), no global state, re-entrant per stream.
+ *    relation counts back to the host), re-entrant per stream.  No state that affects results:
+ *    the only process-wide data are idempotent per-device caches of launch attributes (raised
+ *    dynamic-LDS caps, CU counts), keyed by the device current at the call, so one process may
+ *    drive several GPUs.
  *  - fp32 values, int32 indices, row-major contiguous.
  *  - return value: 0 = success; > 0 = hipError_t of a failed runtime call / launch;
  *    < 0 = GNNRAG_E_* argument error.  gnnrag_error_string() renders either.
@@ -31,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GNNRAG_ABI_VERSION 4
+#define GNNRAG_ABI_VERSION 5
 
 #define GNNRAG_E_BADARG      (-1)  /* null pointer / negative size / inconsistent sizes   */
 #define GNNRAG_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set (see DESIGN)  */
@@ -103,16 +106,14 @@ int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const int32_t* t
 int gnnrag_csr_permute_weight(const gnnrag_csr* csr, const float* w_per_fact, int square,
                               float* out_fwd, float* out_inv, gnnrag_stream_t stream);
 
-/* Math mode of the dense projections (gnnrag_linear on large M, gnnrag_update_score*,
- * gnnrag_relation_tables), process wide like a BLAS math mode:
- *   GNNRAG_MATH_FP32   v_mfma_f32_16x16x4_f32: bit-exact fp32 fmaf chains (default);
+/* Math mode of the dense projections, an argument of every entry point that multiplies matrices
+ * (gnnrag_linear*, gnnrag_update_score*, gnnrag_relation_tables, gnnrag_reason_layer):
+ *   GNNRAG_MATH_FP32   v_mfma_f32_16x16x4_f32: bit-exact fp32 fmaf chains;
  *   GNNRAG_MATH_BF16X3 each fp32 operand split EXACTLY into three bf16 planes, six plane products
  *                      on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: per-product relative
  *                      error <= 3*2^-24 (fp32 class), about 2.5x the fp32 MFMA rate. */
 #define GNNRAG_MATH_FP32   0
 #define GNNRAG_MATH_BF16X3 1
-int gnnrag_set_dense_math(int mode);
-int gnnrag_get_dense_math(void);
 
 /* C[M,Nout] = act( A[M,K] . W[Nout,K]^T + bias[Nout] + add[row < add_rows, :] ), fp32 MFMA.
  * Used for  T_d = rel_linear_step(rel_features_d) (+ pos_emb_d(rel)), computed once per
@@ -121,13 +122,13 @@ int gnnrag_get_dense_math(void);
  * bias/add may be NULL.  relu != 0 applies max(.,0). */
 int gnnrag_linear(const float* A, int64_t M, int32_t K, const float* W, const float* bias,
                   const float* add, int64_t add_rows, int relu,
-                  float* C, int32_t Nout, gnnrag_stream_t stream);
+                  float* C, int32_t Nout, int32_t math, gnnrag_stream_t stream);
 
 /* Two gnnrag_linear problems that share W, bias and shapes (the forward and inverse relation
  * transforms of one layer call) in ONE launch. */
 int gnnrag_linear_pair(const float* A0, const float* A1, int64_t M, int32_t K, const float* W,
                        const float* bias, const float* add0, const float* add1, int64_t add_rows,
-                       float* C0, float* C1, int32_t Nout, gnnrag_stream_t stream);
+                       float* C0, float* C1, int32_t Nout, int32_t math, gnnrag_stream_t stream);
 
 /* agg[n, 2i+d, :] = sum_{f: dst_d(f)=n} w_f * dist[src_d(f)] * relu(T_d[rel_f,:] * ins[n/N, i, :])
  * = reason_layer (reasongnn.py:61-89, d=0) and reason_layer_inv (reasongnn.py:91-116, d=1)
@@ -149,12 +150,19 @@ int gnnrag_aggregate_fused(const gnnrag_csr* csr, const float* dist, const float
                            int32_t D, void* workspace, size_t workspace_bytes,
                            gnnrag_stream_t stream);
 
+/* Which kernel gnnrag_aggregate_fused dispatches for this structure and hidden size (decided on the
+ * host from rel_max and D, nothing is launched): lets tests and bench.py name the kernel they ran. */
+#define GNNRAG_WALK_L2_GATHER 0  /* k_walk_light<FUSED>: table rows gathered from L2 (tables exceed a CU's LDS) */
+#define GNNRAG_WALK_LDS_16    1  /* k_walk_slice<FUSED,1>: 16-column table slices in LDS                      */
+#define GNNRAG_WALK_LDS_32    2  /* k_walk_slice<FUSED,2>: 32-column slices (small per-question tables)       */
+int gnnrag_aggregate_fused_variant(const gnnrag_csr* csr, int32_t D);
+
 /* h_out = relu(e2e_linear(cat(h, agg)))            (reasongnn.py:161-163)
  * score = score_func(h_out) + (1 - mask) * -1e11   (reasongnn.py:165-168), mask add in fp32.
  * h [BN,D], agg [BN,2I*D], W [D,(2I+1)D], b [D], w_s [D], b_s [1] (device), mask [BN]. */
 int gnnrag_update_score(const float* h, const float* agg, const float* W, const float* b,
                         const float* w_s, const float* b_s, const float* mask,
-                        float* h_out, float* score, int64_t BN, int32_t D, int32_t I,
+                        float* h_out, float* score, int64_t BN, int32_t D, int32_t I, int32_t math,
                         gnnrag_stream_t stream);
 
 /* dist[g,:] = softmax(score[g,:]) over the N slots of each question (reasongnn.py:169). */
@@ -224,13 +232,14 @@ int gnnrag_typelayer_backward(const gnnrag_csr* csr, const gnnrag_relorder* relo
  * (the e2e_linear column blocks in the concat order of reasongnn.py:150-161).  The operand
  * relu(T_d * ins) is generated inside the GEMM's tile loader and never stored. */
 int gnnrag_relation_tables(const gnnrag_csr* csr, const float* T_fwd, const float* T_inv, const float* ins,
-                           const float* W_e2e, float* P, int32_t D, int32_t I, gnnrag_stream_t stream);
+                           const float* W_e2e, float* P, int32_t D, int32_t I, int32_t math,
+                           gnnrag_stream_t stream);
 
 /* h_out = relu(h . W_e2e[:, 0:D]^T + b + nbr), nbr [BN,D] from gnnrag_aggregate_fused; score as in
  * gnnrag_update_score.  Together: reasongnn.py:161-168. */
 int gnnrag_update_score_fused(const float* h, const float* nbr, const float* W_e2e, const float* b,
                               const float* w_s, const float* b_s, const float* mask,
-                              float* h_out, float* score, int64_t BN, int32_t D, int32_t I,
+                              float* h_out, float* score, int64_t BN, int32_t D, int32_t I, int32_t math,
                               gnnrag_stream_t stream);
 
 /* One whole ReasonGNNLayer.forward (reasongnn.py:134-174) enqueued with a single call:
@@ -254,7 +263,7 @@ int gnnrag_reason_layer(const gnnrag_csr* csr,
                         const float* w_score, const float* b_score, const float* mask,
                         float* h_out, float* score_out, float* dist_out,
                         void* workspace, size_t workspace_bytes,
-                        int32_t D, int32_t I, int32_t path, gnnrag_stream_t stream);
+                        int32_t D, int32_t I, int32_t path, int32_t math, gnnrag_stream_t stream);
 
 /* Candidate selection of Evaluator.evaluate (evaluate.py:188-207) + the sort and top-p cut of
  * f1_and_hits (evaluate.py:34-51), one workgroup per question:

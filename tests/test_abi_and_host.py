@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, n), "missing export: " + n
         assert n in _lib.SIGNATURES, "binding lacks a signature for " + n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.gnnrag_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.gnnrag_abi_version() == _lib.ABI_VERSION == 5
     assert b"bad argument" in lib.gnnrag_error_string(-1)
 
 
@@ -60,9 +60,20 @@ def test_size_queries_and_struct_layout(lib):
 
 def test_argument_errors_without_gpu(lib):
     assert lib.gnnrag_masked_softmax(None, None, 1, 1, None) == -1
-    assert lib.gnnrag_linear(None, 1, 1, None, None, None, 0, 0, None, 1, None) == -1
+    assert lib.gnnrag_linear(None, 1, 1, None, None, None, 0, 0, None, 1, 0, None) == -1
     assert lib.gnnrag_aggregate(None, None, None, None, None, None, 200, 2, None, 0, None) == -1
-    assert lib.gnnrag_relation_tables(None, None, None, None, None, None, 8, 2, None) == -1
+    assert lib.gnnrag_relation_tables(None, None, None, None, None, None, 8, 2, 0, None) == -1
+    # the math mode is an argument (no library-wide mode): unknown values are rejected before anything is launched
+    one = ctypes.c_void_p(256)
+    assert lib.gnnrag_linear(one, 1, 1, one, None, None, 0, 0, one, 1, 7, None) == -1
+    c = _lib.CsrStruct()
+    c.rel_total, c.rel_max = 10, 5
+    assert lib.gnnrag_aggregate_fused_variant(ctypes.byref(c), 200) == 2         # small tables: 32-column LDS slices
+    c.rel_max = 602
+    assert lib.gnnrag_aggregate_fused_variant(ctypes.byref(c), 200) == 1
+    c.rel_max = 6001
+    assert lib.gnnrag_aggregate_fused_variant(ctypes.byref(c), 200) == 0         # tables exceed a CU's LDS
+    assert lib.gnnrag_aggregate_fused_variant(None, 200) == -1
 
 
 def test_module_surface_matches_reference_state_dict():

@@ -47,7 +47,7 @@ def _patch_backend(monkeypatch):
     from gnnrag_amd.modules.kg_reasoning import base_gnn
 
     def reason_layer(plan, h, dist, ins, relfeat, relfeat_inv, W_rel, b_rel, W_e2e, b_e2e, w_score, b_score,
-                     mask, pos=None, pos_inv=None, ws=None, path=0):
+                     mask, pos=None, pos_inv=None, ws=None, path=0, math=None):
         st = otorch.Structure(plan.tuple7(), plan.B, plan.N, plan.w_gnn is not None)
         p = {"rel_linear0.weight": W_rel, "rel_linear0.bias": b_rel, "e2e_linear0.weight": W_e2e,
              "e2e_linear0.bias": b_e2e, "score_func.weight": w_score.reshape(1, -1), "score_func.bias": b_score}
@@ -58,7 +58,7 @@ def _patch_backend(monkeypatch):
                                              p, 0, relfeat, relfeat_inv, pos is not None)
         return hn, score, nd
 
-    def linear(A, W, bias=None, add=None, relu=False):
+    def linear(A, W, bias=None, add=None, relu=False, math=None):
         out = torch.nn.functional.linear(A, W, bias)
         if add is not None:
             out[: add.shape[0]] += add
@@ -100,7 +100,9 @@ def _patch_backend(monkeypatch):
     monkeypatch.setattr(ops, "reason_layer", reason_layer)
     monkeypatch.setattr(ops, "linear", linear)
     monkeypatch.setattr(ops, "typelayer", typelayer)
-    monkeypatch.setattr(base_gnn, "_device_from_args", lambda args: torch.device("cpu"))
+    monkeypatch.setattr(base_gnn, "_device_from_args", lambda args, like=None: torch.device("cpu"))
+    monkeypatch.setattr(ops, "seed_retrieve",
+                        lambda seed_info, ent_emb: torch.bmm(seed_info.unsqueeze(1), ent_emb).squeeze(1))
     monkeypatch.setattr(base_gnn, "_check_gpu_tensor", lambda t, what: None)
     base_gnn._last_plan.update(key=None, plan=None, tuple=None)
 

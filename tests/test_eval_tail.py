@@ -90,3 +90,22 @@ def test_patched_evaluator_matches_reference(monkeypatch, tmp_path):
     assert filecmp.cmp(os.path.join(str(tmp_path), "ref_test.info"), os.path.join(str(tmp_path), "fast_test.info"),
                        shallow=False)
     assert os.path.getsize(os.path.join(str(tmp_path), "fast_test.info")) > 100
+
+
+@pytest.mark.parametrize("quantise", [False, True])
+def test_large_subgraph_selection_on_the_host(quantise):
+    """More node slots than the kernel sorts in LDS (N > 16384): the selection follows the reference's own
+    host loop; same result as the plain-Python restatement (ties, empty questions)."""
+    import gnnrag_amd  # noqa: F401
+    import oracle.eval_tail as oe
+    from gnnrag_amd import eval_tail
+    N = eval_tail.TOPP_MAX_N + 3
+    rng = np.random.default_rng(11 + int(quantise))
+    p, cands, seeds, pad = _random_case(rng, 4, N, quantise)
+    for eps in (0.95, 0.5):
+        ignore = (1 - eps) / N
+        picked = eval_tail.retrieved_candidates(torch.from_numpy(p), cands, seeds, pad, ignore, eps)
+        for b in range(4):
+            kept, cut = oe.select(p[b].tolist(), cands[b].tolist(), seeds[b].tolist(), pad, ignore, eps)
+            want = [(int(cands[b, j]), float(p[b, j])) for j in kept[:cut]]
+            assert picked[b] == (want, len(kept))

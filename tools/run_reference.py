@@ -35,11 +35,19 @@ def main():
     install.install()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    is_eval = "--is_eval" in sys.argv
     if world > 1:                                        # one process per GPU (torchrun), RCCL over xGMI
+        if not is_eval:
+            # only evaluation is question-sharded: a training run under torchrun would train one full replica per
+            # rank without gradient sync, and every rank would write the same checkpoint / .info file
+            raise SystemExit("tools/run_reference.py: with WORLD_SIZE > 1 only evaluation runs (--is_eval) are "
+                             "supported; launch training as a single process")
+        import atexit
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group("nccl")
+        atexit.register(lambda: dist.is_initialized() and dist.destroy_process_group())
 
     import parsing
     if not hasattr(parsing, "create_parser_nutrea"):
@@ -63,7 +71,9 @@ def main():
             dataset = orig_load(*a, **kw)
             for split in ("train", "valid", "test"):
                 if dataset.get(split) is not None:
-                    patch_loader(dataset[split], cache=(split != "train"))     # training permutes / drops facts
+                    # the per-question cache skips numpy RNG draws the reference makes (fact_mat.patch_loader):
+                    # evaluation-only runs use it as it is, training runs keep the reference's RNG stream
+                    patch_loader(dataset[split], cache=(split != "train"), keep_rng_stream=not is_eval)
             return dataset
 
         dataset_load.load_data = load_data

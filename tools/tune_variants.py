@@ -22,6 +22,14 @@ VARIANTS = {
     "no_split_tail": {"GNNRAG_SLICE_SPLIT_TAIL": 0},
     "no_halfstep": {"GNNRAG_SLICE_HALFSTEP": 0},
     "wide_always": {"GNNRAG_SLICE_WIDE_LDS_KB": 159},
+    # timing-only ablations of k_gemm_f32 (results are wrong on purpose): see GNNRAG_GEMM_ABL in gemm_f32.hip
+    "abl_nomfma": {"GNNRAG_GEMM_ABL": 1},
+    "abl_noepi": {"GNNRAG_GEMM_ABL": 2},
+    "abl_noload": {"GNNRAG_GEMM_ABL": 4},
+    "abl_nolds": {"GNNRAG_GEMM_ABL": 8},
+    "abl_mfma_epi": {"GNNRAG_GEMM_ABL": 12},
+    "abl_mfma_only": {"GNNRAG_GEMM_ABL": 14},
+    "abl_mem_only": {"GNNRAG_GEMM_ABL": 1 + 8},
 }
 
 CHILD = r'''
