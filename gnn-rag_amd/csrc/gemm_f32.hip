@@ -29,12 +29,23 @@
 // (register blow-up), direct stores from the MFMA layout instead of the LDS-staged epilogue (-25 % on the
 // self-block update).
 #define GNNRAG_GEMM_MT1_NW 8     // the one-row-tile-per-wave variant may use 8-wave (128-row) workgroups
+#ifndef GNNRAG_GEMM_WRES
+#define GNNRAG_GEMM_WRES 1       // short-K problems in exact fp32 run the W-resident kernel (k_gemm_wres)
+#endif
 #ifndef GNNRAG_GEMM_ABL
 #define GNNRAG_GEMM_ABL 0        // timing-only ablation builds (tools/tune_variants.py): 1 no MFMA, 2 no epilogue
                                  // traffic, 4 no global loads in the k loop, 8 no LDS restaging in the k loop
 #endif
 
+#ifndef GNNRAG_GEMM_TIMING
+#define GNNRAG_GEMM_TIMING 0     // profiling builds only: per-workgroup phase stamps (s_memtime) into a debug buffer
+#endif
+
 namespace gnnrag {
+
+#if GNNRAG_GEMM_TIMING
+__device__ long long* g_tbuf = nullptr;     // [waves][32] stamps; set by gnnrag_debug_set_timing_buffer (timing builds only)
+#endif
 
 constexpr int kBK = 32;    // k per LDS tile
 constexpr int kSkinnyMaxM = 16384;   // up to here a problem runs on k_gemm_skinny (one wave per 16 x 64 tile, no LDS)
@@ -456,6 +467,328 @@ void k_gemm_f32(GemmArgs g) {
   }
 }
 
+// ---- cross-lane helpers of the epilogue: VALU only (DPP row operations), no LDS crossbar round trips (the first
+// version reduced every row's score with six dependent ds_bpermute shuffles: 96 LDS round trips per wave and tile)
+template <int CTRL, int BANK>
+__device__ __forceinline__ float dpp_f(float old, float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), CTRL, 0xf, BANK, false));
+}
+__device__ __forceinline__ float lane_xor1(float x) { return dpp_f<0xB1, 0xf>(x, x); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float lane_xor2(float x) { return dpp_f<0x4E, 0xf>(x, x); }   // quad_perm [2,3,0,1]
+__device__ __forceinline__ float lane_xor4(float x) {
+  const float t = dpp_f<0x104, 0x5>(x, x);      // row_shl:4 into lanes 0-3, 8-11 of a 16-lane row (they read lane + 4)
+  return dpp_f<0x114, 0xA>(t, x);               // row_shr:4 into lanes 4-7, 12-15 (they read lane - 4)
+}
+__device__ __forceinline__ float lane_xor8(float x) { return dpp_f<0x128, 0xf>(x, x); }  // row_ror:8
+
+// Sums 4 values per lane over the 16 lanes of a DPP row with 6 DPP moves (instead of 4 x 4 shuffles): two
+// reduce-scatter steps over lane bits 0 and 1 halve the values a lane carries, two all-reduce steps over bits 2
+// and 3 finish.  Returns the total of value index 2*(lane&1) + ((lane>>1)&1); one fixed summation order.
+__device__ __forceinline__ float row16_sum4(const float (&v)[4], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2;
+  float w2[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) w2[j] = (b0 ? v[j + 2] : v[j]) + lane_xor1(b0 ? v[j] : v[j + 2]);
+  float w = (b1 ? w2[1] : w2[0]) + lane_xor2(b1 ? w2[0] : w2[1]);
+  w += lane_xor4(w);
+  w += lane_xor8(w);
+  return w;
+}
+__device__ __forceinline__ int row16_sum4_index(int lane) { return 2 * (lane & 1) + ((lane >> 1) & 1); }
+
+// Output-column permutation.  The MFMA C layout gives lane (fr = lane & 15, fg = lane >> 4) the entries
+// (row 4*fg + q, column slot fr) of every 16x16 tile nt.  WHICH output column a slot stands for is free: it is
+// the W row staged at LDS row nt*16 + fr.  Column tiles are taken in groups of four (64 columns) and slot
+// (4a + b, fr) is given column 64a + 4*fr + b, so a lane holds FOUR CONSECUTIVE columns of its rows in the
+// registers acc[4a..4a+3][q]: the epilogue loads `add` and stores C straight from the MFMA layout in 16-byte
+// pieces, 256 contiguous bytes per 16 lanes - no transposition through LDS.  A trailing tile (NT % 4 == 1)
+// keeps the plain order (one column per lane).
+template <int NT> struct ColMap {
+  static_assert(NT % 4 <= 1, "column tiles come in groups of four plus at most one");
+  static constexpr int NFULL = NT / 4;
+  static constexpr int NGRP = (NT + 3) / 4;
+  // LDS row of W row j (0 <= j < NT*16)
+  static __device__ __forceinline__ int lds_row(int j) {
+    if (j < NFULL * 64) {
+      const int a = j >> 6, w = j & 63;
+      return ((a << 2) + (w & 3)) * 16 + (w >> 2);
+    }
+    return j;
+  }
+};
+
+// Opaque copy of a lane-dependent value: address arithmetic derived from it is redone where it is used instead of
+// being hoisted out of the row-tile loop and kept in (spilled) registers across the k loop.
+__device__ __forceinline__ int opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+// ---- W-resident kernel: the whole weight block lives in LDS, A fragments come straight from global memory ------
+// For C[M, Nout] = A[M, K] . W^T with a SHORT K and a huge M (the self-block update: M = B*N = 128 000,
+// K = Nout = D = 200) the k-tiled kernel above restages the same 160 KB of W for every 128 rows (as much L2 -> LDS
+// traffic as A itself), synchronises its waves twice per 32 k, and its loads run one k tile (a few us) ahead of
+// their use while the loaded HBM latency is of that order: its k loop is latency bound, not MFMA bound (phase
+// timeline).  Here
+//  * one 8-wave workgroup per CU copies W [Nout, K] fp32 into LDS ONCE (160 000 B at D = 200: row stride K
+//    floats = 50 float4 chunks, which is bank-conflict free for the ds_read_b128 fragment reads as it is; rows in
+//    ColMap order) - afterwards there is no barrier and no LDS write in the kernel;
+//  * every wave owns a contiguous run of 16-row tiles of A (M/16 tiles over 2048 waves: 3.9 each at C2) and
+//    reads a tile's A fragments in the MFMA layout directly from global memory (lane (fr, fg) loads the float4
+//    A[row fr][16c + 4fg ..]: 64-byte pieces, consecutive c complete the 128-byte lines), a WHOLE TILE AHEAD:
+//    the fragment registers of k group c are refilled with the next tile's data as soon as group c has been
+//    multiplied, i.e. ~10 us before their next use.  The epilogue's `add` rows are requested at the start of the
+//    tile.  256 VGPRs per lane (2 waves per SIMD) hold accumulators (52), fragments (52) and add rows (52);
+//  * the two waves of a SIMD are independent, so one's epilogue overlaps the other's MFMAs by itself.
+// Exact fp32 (v_mfma_f32_16x16x4_f32), alternating accumulators.
+template <int NT, int NC, int EPI, bool HAS_ADD>
+__global__ __launch_bounds__(512, 2) void k_gemm_wres(GemmArgs g, int S) {
+  typedef ColMap<NT> CM;
+  extern __shared__ __attribute__((aligned(16))) float Wl[];     // [Nout rows in ColMap order][S float4 chunks]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int K = g.K, KC = K >> 2, Nout = g.Nout;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#if GNNRAG_GEMM_TIMING
+  const long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
+
+  // W -> LDS (float4 copies; row j lands at LDS row ColMap::lds_row(j)).  Twenty requests per thread are in flight
+  // before the first one is written (a one-at-a-time copy of 160 KB cost ~25 us of exposed L2 latency per launch).
+  {
+    const int total = Nout * KC;
+    constexpr int UN = 20;
+    for (int base = 0; base < total; base += 512 * UN) {
+      f32x4 v[UN];
+      int dst[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int idx = base + u * 512 + tid;
+        const int idc = idx < total ? idx : total - 1;
+        const int j = idc / KC, kc = idc - j * KC;
+        v[u] = *reinterpret_cast<const f32x4*>(g.W + (size_t)j * g.ldw + g.wc0 + 4 * kc);
+        dst[u] = idx < total ? (CM::lds_row(j) * S + kc) * 4 : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+        if (dst[u] >= 0) *reinterpret_cast<f32x4*>(Wl + dst[u]) = v[u];
+    }
+  }
+  // bias and score weights behind W (read with ds_read in the epilogue: global loads there would have to wait for
+  // the fragment refills issued just before them)
+  float* Bl = Wl + (size_t)Nout * S * 4;
+  float* Sl = Bl + Nout;
+  for (int j = tid; j < Nout; j += 512) {
+    Bl[j] = g.bias ? g.bias[j] : 0.f;
+    Sl[j] = (EPI == EPI_UPDATE) ? g.w_s[j] : 0.f;
+  }
+
+  // this wave's 16-row tiles: a contiguous run (a workgroup-local ticket that hands tiles to whichever wave is free
+  // was measured and is slower: 126 vs 116 us, the last tiles then start late and run alone)
+  const long long U = ((long long)g.M + 15) >> 4;
+  const long long GW = (long long)gridDim.x * 8, gw = (long long)blockIdx.x * 8 + wave;
+  int t = (int)(U * gw / GW);
+  const int tend = (int)(U * (gw + 1) / GW);
+  // per k group c: this lane's float4 offset inside a row of A / of W (zero beyond K: the A value is zeroed, the W
+  // address is clamped to a valid chunk so that 0 * finite = 0)
+  // (raw load: the k >= K zeroing happens where the fragment is USED, so that a refill does not wait for its data)
+  // Only the last k group can reach beyond K (K > 16 * (NC - 1)).
+  auto a_frag = [&](int tile, int c) -> f32x4 {
+    const int row = min(tile * 16 + fr, g.M - 1);                 // rows beyond M: valid memory, results discarded
+    const float* rowp = g.A0 + (size_t)row * g.K0 + 4 * fg;
+    if (c < NC - 1) return *reinterpret_cast<const f32x4*>(rowp + 16 * c);
+    return *reinterpret_cast<const f32x4*>(rowp + (min(16 * c + 4 * fg, K - 4) - 4 * fg));
+  };
+  f32x4 ra[NC];
+  if (t < tend) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) ra[c] = a_frag(t, c);
+  }
+  // LDS fragment addresses: row (nt*16 + fr) * S + chunk; rows beyond Nout are clamped (their columns are never stored)
+  int wrow[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int a = nt >> 2, b = nt & 3;
+    const int col = a < CM::NFULL ? 64 * a + 4 * fr + b : 64 * CM::NFULL + (nt - 4 * CM::NFULL) * 16 + fr;
+    wrow[nt] = (col < Nout ? nt * 16 + fr : 0) * S;
+  }
+  auto col_of = [&](int a) { return a < CM::NFULL ? 64 * a + 4 * fr : 64 * CM::NFULL + fr; };
+  const float bs = (EPI == EPI_UPDATE) ? g.b_s[0] : 0.f;
+  int tnext_c = 0;
+#if GNNRAG_GEMM_TIMING
+  long long* tb = g_tbuf ? g_tbuf + ((size_t)blockIdx.x * 8 + wave) * 32 : nullptr;
+  int stamp = 0;
+  if (tb && lane == 0) tb[stamp] = __builtin_amdgcn_s_memtime();
+  ++stamp;
+#endif
+  __syncthreads();
+#if GNNRAG_GEMM_TIMING
+  if (tb && lane == 0) { tb[stamp] = __builtin_amdgcn_s_memtime(); tb[30] = __builtin_amdgcn_s_getreg((31 << 11) | 4); tb[31] = t_entry; }
+  ++stamp;
+#endif
+
+  for (; t < tend; t = tnext_c) {
+#if GNNRAG_GEMM_TIMING
+    if (tb && lane == 0 && stamp < 28) tb[stamp] = __builtin_amdgcn_s_memtime();
+    ++stamp;
+#endif
+    const int rbase = t * 16 + 4 * fg;                             // C layout: this lane's rows rbase + q
+    // the epilogue's addend rows, in the MFMA / ColMap layout
+    f32x4 addv[CM::NGRP][4];
+#pragma unroll
+    for (int a = 0; a < CM::NGRP; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) addv[a][q] = zero4;
+    if constexpr (HAS_ADD) {       // compile time: a branch here would make the compiler's vmcnt waits conservative
+#pragma unroll
+      for (int a = 0; a < CM::NGRP; ++a) {
+        const int col = col_of(a);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = min(rbase + q, g.M - 1);
+          const float* arow = g.add + (size_t)row * Nout;
+          if (a < CM::NFULL) addv[a][q] = *reinterpret_cast<const f32x4*>(arow + min(col, Nout - 4));
+          else addv[a][q][0] = arow[min(col, Nout - 1)];
+        }
+      }
+    }
+    float mrow = 0.f;                          // mask of the row whose score this lane will write
+    if constexpr (EPI == EPI_UPDATE) mrow = g.mask[min(rbase + row16_sum4_index(fr), g.M - 1)];
+    __builtin_amdgcn_sched_barrier(0);        // keep the requests up here: the scheduler would sink them to their use
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = zero4;
+    const int tnext = t + 1;
+    tnext_c = tnext;
+    const int tload = tnext < tend ? tnext : t;      // (no next tile: the current one is simply requested again -
+                                                     // no branch, so that the compiler's vmcnt bookkeeping stays exact)
+    // W never changes after the first barrier, so the compiler would hoist all NT*NC fragment reads out of the
+    // tile loop (676 registers): the lane's chunk offset is made opaque once per tile
+    const int fg_t = opaque(fg);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      f32x4 a = ra[c];
+      int kc = 4 * c + fg_t;
+      if (c == NC - 1) {
+        if (16 * c + 4 * fg_t >= K) a = zero4;
+        kc = min(kc, KC - 1);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; nt += 2) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(Wl + (size_t)(wrow[nt] + kc) * 4);
+        f32x4 b1 = zero4;
+        if (nt + 1 < NT) b1 = *reinterpret_cast<const f32x4*>(Wl + (size_t)(wrow[nt + 1 < NT ? nt + 1 : nt] + kc) * 4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b0[s], acc[nt], 0, 0, 0);
+          if (nt + 1 < NT) acc[nt + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[s], acc[nt + 1], 0, 0, 0);
+        }
+      }
+      ra[c] = a_frag(tload, c);                                    // refill: the next tile's k group c
+    }
+#if GNNRAG_GEMM_TIMING
+    if (tb && lane == 0 && stamp < 28) tb[stamp] = __builtin_amdgcn_s_memtime();
+    ++stamp;
+#endif
+    // epilogue from the registers: 4 consecutive columns per lane and column group
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ws4[CM::NGRP], bias4[CM::NGRP];        // this lane's columns of bias / score weights (from LDS)
+#pragma unroll
+    for (int a = 0; a < CM::NGRP; ++a) {
+      const int col = col_of(a);
+      ws4[a] = zero4;
+      bias4[a] = zero4;
+      if (a < CM::NFULL) {
+        if (col < Nout) {                           // Nout % 4 == 0: the four columns are valid together
+          ws4[a] = *reinterpret_cast<const f32x4*>(Sl + col);
+          bias4[a] = *reinterpret_cast<const f32x4*>(Bl + col);
+        }
+      } else if (col < Nout) {
+        ws4[a][0] = Sl[col];
+        bias4[a][0] = Bl[col];
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < CM::NGRP; ++a) {
+      const int col = col_of(a);
+      const int nb = a < CM::NFULL ? 4 : 1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = rbase + q;
+        f32x4 v = zero4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * a + e < NT) v[e] = acc[4 * a + e][q];
+        v = (v + bias4[a]) + addv[a][q];
+        if (EPI == EPI_UPDATE || g.relu) v = __builtin_elementwise_max(v, zero4);
+        if (row < g.M) {
+          float* crow = g.C + (size_t)row * Nout + col;
+          if (nb == 4) {
+            if (col < Nout) *reinterpret_cast<f32x4*>(crow) = v;
+          } else if (col < Nout) {
+            crow[0] = v[0];
+          }
+        }
+        if (EPI == EPI_UPDATE)
+          part[q] += v[0] * ws4[a][0] + v[1] * ws4[a][1] + v[2] * ws4[a][2] + v[3] * ws4[a][3];
+      }
+    }
+    if constexpr (EPI == EPI_UPDATE) {
+      const float tot = row16_sum4(part, lane);
+      const int srow = rbase + row16_sum4_index(fr);
+      // fp32 on purpose: score - 1e11 rounds to exactly -1e11, as in the reference
+      if (fr < 4 && srow < g.M) g.score[srow] = (tot + bs) + (1.0f - mrow) * kVeryNeg;
+    }
+  }
+#if GNNRAG_GEMM_TIMING
+  if (tb && lane == 0 && stamp < 30) tb[stamp] = __builtin_amdgcn_s_memtime();
+#endif
+}
+
+// applicability of k_gemm_wres and its LDS row stride (float4 chunks): S >= K/4 with S % 4 == 2 keeps the
+// ds_read_b128 fragment reads bank-conflict free; the whole block must fit one CU's LDS
+static int wres_stride(const GemmArgs& g) {
+  if (g.K % 4 || g.Nout % 4 || g.K0 != g.K || g.A1 || g.n0 || g.K < 16) return 0;
+  int S = g.K / 4;
+  while (S % 4 != 2) ++S;
+  if ((size_t)g.Nout * S * 16 + (size_t)g.Nout * 8 > 160 * 1024) return 0;
+  return S;
+}
+
+template <int EPI>
+static int launch_wres(const GemmArgs& g, int S, hipStream_t stream) {
+  int cus = 0;
+  {
+    const int rc = device_cu_count(&cus);
+    if (rc) return rc;
+  }
+  const int tiles = (g.M + 15) / 16;
+  int grid = cus > 0 ? cus : 1;
+  if (grid * 8 > tiles) grid = (tiles + 7) / 8;
+  const size_t lds = (size_t)g.Nout * S * 16 + (size_t)g.Nout * 8 ;      // W, bias, score weights
+  const int nc = (g.K + 15) / 16, nt = (g.Nout + 15) / 16;
+#define GNNRAG_WRES1(NTT, NCC, HA)                                                                              \
+  do {                                                                                                          \
+    static DeviceMask cap;                                                                                      \
+    const int rc_ = raise_lds_cap(k_gemm_wres<NTT, NCC, EPI, HA>, cap);                                         \
+    if (rc_) return rc_;                                                                                        \
+    hipLaunchKernelGGL((k_gemm_wres<NTT, NCC, EPI, HA>), dim3(grid), dim3(512), lds, stream, g, S);             \
+  } while (0)
+#define GNNRAG_WRES(NTT, NCC)                                                                                   \
+  do {                                                                                                          \
+    if (g.add) GNNRAG_WRES1(NTT, NCC, true);                                                                    \
+    else GNNRAG_WRES1(NTT, NCC, false);                                                                         \
+  } while (0)
+  if (nt <= 4 && nc <= 4) GNNRAG_WRES(4, 4);
+  else if (nt <= 8 && nc <= 8) GNNRAG_WRES(8, 8);
+  else if (nt <= 13 && nc <= 13) GNNRAG_WRES(13, 13);
+  else return GNNRAG_E_UNSUPPORTED;
+#undef GNNRAG_WRES
+#undef GNNRAG_WRES1
+  GNNRAG_LAUNCH_CHECK();
+  return 0;
+}
+
 // score for Nout > 208 (column blocks): one wave per row, dot(h', w_s)
 __global__ __launch_bounds__(256) void k_score_rows(const float* __restrict__ h, const float* __restrict__ w_s,
                                                     const float* __restrict__ b_s,
@@ -590,6 +923,13 @@ static int launch_gemm(GemmArgs g, hipStream_t stream, int math) {
 
 using namespace gnnrag;
 
+#if GNNRAG_GEMM_TIMING
+extern "C" int gnnrag_debug_set_timing_buffer(long long* buf) {
+  GNNRAG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tbuf), &buf, sizeof(buf)));
+  return 0;
+}
+#endif
+
 extern "C" int gnnrag_linear(const float* A, int64_t M, int32_t K, const float* W, const float* bias,
                              const float* add, int64_t add_rows, int relu, float* C, int32_t Nout,
                              int32_t math, gnnrag_stream_t stream) {
@@ -614,6 +954,11 @@ extern "C" int gnnrag_linear(const float* A, int64_t M, int32_t K, const float* 
 static int update_common(GemmArgs g, int64_t BN, int32_t D, hipStream_t stream, int math) {
   if (D <= 208) {
     g.n0 = 0;
+    // short K, exact fp32, aligned operands: the W-resident kernel (whole weight block in LDS)
+    const bool al = aligned16(g.A0) && aligned16(g.W) && aligned16(g.C) && (!g.add || aligned16(g.add)) &&
+                    g.ldw % 4 == 0 && g.wc0 % 4 == 0 && (!g.add || g.add_rows >= g.M);
+    const int S = (GNNRAG_GEMM_WRES && math == GNNRAG_MATH_FP32 && al && g.M >= 4096) ? wres_stride(g) : 0;
+    if (S) return launch_wres<EPI_UPDATE>(g, S, stream);
     return launch_gemm<EPI_UPDATE, AMODE_PLAIN>(g, stream, math);
   }
   // wide hidden sizes: column blocks of 208 with bias(+add)+ReLU epilogue, then a row-dot for the score

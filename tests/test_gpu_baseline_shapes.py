@@ -147,7 +147,8 @@ def test_c1_shape_single_question(dev):
         want = otorch.run_stack(batch, feats, params, use_type_layer=True)
         for path in (0, 1, 2):
             got = stack.run_stack(batch, feats, params, dev, use_type_layer=True, path=path)
-            assert np.abs(got["h0"] - want64["h0"]).max() <= TOL_INTERNAL
+            # TypeLayer sums hundreds of facts at the hubs (|h0| up to ~1e2): fp32 rounding scales with the magnitude
+            assert np.abs(got["h0"] - want64["h0"]).max() <= TOL_INTERNAL * max(1.0, np.abs(want64["h0"]).max())
             _check_stack(got, want64, cfg.T * cfg.L, tol=TOL_INTERNAL, what="C1 np64 path %d" % path)
             _check_stack(got, want, cfg.T * cfg.L, what="C1 torch path %d" % path)
 

@@ -30,6 +30,8 @@ VARIANTS = {
     "abl_mfma_epi": {"GNNRAG_GEMM_ABL": 12},
     "abl_mfma_only": {"GNNRAG_GEMM_ABL": 14},
     "abl_mem_only": {"GNNRAG_GEMM_ABL": 1 + 8},
+    "timing": {"GNNRAG_GEMM_TIMING": 1},        # per-wave phase stamps of k_gemm_wres (tools/gemm_timeline_wres.py)
+    "no_wres": {"GNNRAG_GEMM_WRES": 0},         # the k-tiled kernel for the self-block update
 }
 
 CHILD = r'''
