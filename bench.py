@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-b", type=int, default=8)
-    ap.add_argument("--math", choices=["default", "fp32", "bf16x3"], default="default",
+    ap.add_argument("--math", choices=["default", "fp32", "bf16x3", "mixed"], default="default",
                     help="math mode of the dense projections (default = the library's default)")
     args = ap.parse_args()
 
@@ -88,8 +88,8 @@ def main():
     from gnnrag_amd import _lib, ops, shard, stack, synth
     _lib.load()
     if args.math != "default":
-        ops.set_dense_math(ops.MATH_BF16X3 if args.math == "bf16x3" else ops.MATH_FP32)
-    math_name = ["fp32 (v_mfma_f32_16x16x4_f32)", "bf16x3 (exact 3-way bf16 split, 6 plane products, fp32 accumulate)"][ops.get_dense_math()]
+        ops.set_dense_math({"fp32": ops.MATH_FP32, "bf16x3": ops.MATH_BF16X3, "mixed": ops.MATH_MIXED}[args.math])
+    math_name = ops.MATH_NAMES[ops.get_dense_math()]
 
     cfg = synth.CONFIGS[args.workload]
     # every rank owns its own questions (weak scaling): same shapes, different seed

@@ -29,6 +29,9 @@
 // (register blow-up), direct stores from the MFMA layout instead of the LDS-staged epilogue (-25 % on the
 // self-block update).
 #define GNNRAG_GEMM_MT1_NW 8     // the one-row-tile-per-wave variant may use 8-wave (128-row) workgroups
+#ifndef GNNRAG_TABLES_WRES
+#define GNNRAG_TABLES_WRES 1     // bf16x3 relation tables on the W-resident kernel of tables_b3.hip
+#endif
 #ifndef GNNRAG_GEMM_WRES
 #define GNNRAG_GEMM_WRES 1       // short-K problems in exact fp32 run the W-resident kernel (k_gemm_wres)
 #endif
@@ -146,28 +149,7 @@ __device__ __forceinline__ f32x4 load_w4(const GemmArgs& g, int j, int k) {
   return v;
 }
 
-// bf16 planes of 4 consecutive fp32 values (truncation split: x = hi + mid + lo EXACTLY - hi keeps the
-// top 8 significand bits, the remainder x - hi is exact in fp32 and has <= 16 bits, and so on)
-struct Split3 { uint2 hi, mid, lo; };
-__device__ __forceinline__ Split3 split3(f32x4 x) {
-  unsigned h[4], m[4], l[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const unsigned u = __float_as_uint(x[e]);
-    h[e] = u & 0xffff0000u;
-    const float r = x[e] - __uint_as_float(h[e]);
-    m[e] = __float_as_uint(r) & 0xffff0000u;
-    const float r2 = r - __uint_as_float(m[e]);
-    l[e] = __float_as_uint(r2);            // <= 8 significant bits: its low 16 encoding bits are zero
-  }
-  Split3 s;
-  s.hi = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
-  s.mid = make_uint2((m[0] >> 16) | m[1], (m[2] >> 16) | m[3]);
-  s.lo = make_uint2((l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u));
-  return s;
-}
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // MATH = 0: v_mfma_f32_16x16x4_f32 (bit-exact fmaf chains).
 // MATH = 1: every fp32 operand is split exactly into three bf16 planes (hi, mid, lo) when its tile is
@@ -860,7 +842,7 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs g) {
   }
 }
 
-static bool math_ok(int math) { return math == GNNRAG_MATH_FP32 || math == GNNRAG_MATH_BF16X3; }
+static bool math_ok(int math) { return math == GNNRAG_MATH_FP32 || math == GNNRAG_MATH_BF16X3 || math == GNNRAG_MATH_MIXED; }
 
 template <int EPI, int AMODE>
 static int launch_gemm(GemmArgs g, hipStream_t stream, int math) {
@@ -890,7 +872,7 @@ static int launch_gemm(GemmArgs g, hipStream_t stream, int math) {
   const int bm = small_tiles ? (nw8 ? 128 : 64) : 128;
   const dim3 grid((g.M + bm - 1) / bm, ny);
   const int ncol = g.Nout - g.n0;
-  const bool b3 = math == GNNRAG_MATH_BF16X3;
+  const bool b3 = math != GNNRAG_MATH_FP32;       // MIXED: the k-tiled kernel runs its bf16x3 form
   g.v4out = (g.Nout % 4 == 0) && (g.n0 % 4 == 0) && aligned16(g.C) && (g.add == nullptr || aligned16(g.add));
 #define GNNRAG_GEMM_LAUNCH(NT, MT, V, MATH, NW) \
   hipLaunchKernelGGL((k_gemm_f32<NT, MT, V, EPI, AMODE, MATH, NW>), grid, dim3(64 * NW), 0, stream, g)
@@ -957,7 +939,7 @@ static int update_common(GemmArgs g, int64_t BN, int32_t D, hipStream_t stream, 
     // short K, exact fp32, aligned operands: the W-resident kernel (whole weight block in LDS)
     const bool al = aligned16(g.A0) && aligned16(g.W) && aligned16(g.C) && (!g.add || aligned16(g.add)) &&
                     g.ldw % 4 == 0 && g.wc0 % 4 == 0 && (!g.add || g.add_rows >= g.M);
-    const int S = (GNNRAG_GEMM_WRES && math == GNNRAG_MATH_FP32 && al && g.M >= 4096) ? wres_stride(g) : 0;
+    const int S = (GNNRAG_GEMM_WRES && math != GNNRAG_MATH_BF16X3 && al && g.M >= 4096) ? wres_stride(g) : 0;
     if (S) return launch_wres<EPI_UPDATE>(g, S, stream);
     return launch_gemm<EPI_UPDATE, AMODE_PLAIN>(g, stream, math);
   }
@@ -1036,6 +1018,11 @@ extern "C" int gnnrag_relation_tables(const gnnrag_csr* csr, const float* T_fwd,
   if (!csr || !T_fwd || !T_inv || !ins || !W || !P || D <= 0 || I <= 0 || csr->rel_total < 0 || !math_ok(math))
     return GNNRAG_E_BADARG;
   if (csr->rel_total == 0) return 0;      // no facts, no tables
+  if (math == GNNRAG_MATH_MIXED) math = GNNRAG_MATH_BF16X3;
+  if (math == GNNRAG_MATH_BF16X3 && GNNRAG_TABLES_WRES) {     // W-resident kernel (tables_b3.hip) where its shapes allow
+    const int rc = tables_b3_launch(csr, T_fwd, T_inv, ins, W, P, D, I, (hipStream_t)stream);
+    if (rc != GNNRAG_E_UNSUPPORTED) return rc;
+  }
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.A0 = T_fwd;

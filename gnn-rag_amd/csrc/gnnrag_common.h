@@ -61,4 +61,34 @@ static inline int device_cu_count(int* cus) {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#if defined(__HIPCC__)
+// bf16 planes of 4 consecutive fp32 values (truncation split: x = hi + mid + lo EXACTLY - hi keeps the
+// top 8 significand bits, the remainder x - hi is exact in fp32 and has <= 16 bits, and so on)
+struct Split3 { uint2 hi, mid, lo; };
+__device__ __forceinline__ Split3 split3(f32x4 x) {
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned u = __float_as_uint(x[e]);
+    h[e] = u & 0xffff0000u;
+    const float r = x[e] - __uint_as_float(h[e]);
+    m[e] = __float_as_uint(r) & 0xffff0000u;
+    const float r2 = r - __uint_as_float(m[e]);
+    l[e] = __float_as_uint(r2);            // <= 8 significant bits: its low 16 encoding bits are zero
+  }
+  Split3 s;
+  s.hi = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
+  s.mid = make_uint2((m[0] >> 16) | m[1], (m[2] >> 16) | m[3]);
+  s.lo = make_uint2((l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u));
+  return s;
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#endif
+
+// relation tables in the bf16x3 math mode on a W-resident kernel (tables_b3.hip); returns GNNRAG_E_UNSUPPORTED when
+// the shape is outside that kernel's set (the caller then takes the k-tiled kernel)
+int tables_b3_launch(const gnnrag_csr* csr, const float* T_fwd, const float* T_inv, const float* ins, const float* W,
+                     float* P, int32_t D, int32_t I, hipStream_t stream);
+
 }  // namespace gnnrag

@@ -1,0 +1,302 @@
+// Per-question relation tables of the fused path in the bf16x3 math mode, on a W-resident kernel.
+//
+//   P[d, m, :] = sum_i  W_e2e[:, (1+2i+d)D : (2+2i+d)D] . relu( T_d[r_m, :] * ins[b_m, i, :] )      m = compact row (b_m, r_m)
+//
+// (reference: the e2e_linear column blocks applied to the per-fact messages of reasongnn.py:71-79 / :98-105, once
+// per (question, relation in use) instead of once per fact - see gemm_f32.hip / DESIGN.md section 3.3).
+//
+// Why a second kernel: on the k-tiled kernel (gemm_f32.hip) this product ran at ~30 % of the bf16 matrix rate at C2
+// (127 us): 150 rows per workgroup leave a 22-row remainder tile that costs a full tile, and every 32 k the
+// workgroup restages operands and synchronises twice.  The operand here is GENERATED from two small L2-resident
+// tables, so nothing has to stream from HBM and the weights can stay put:
+//   * workgroup = (direction d, column part h, row chunk): 8 waves, one per CU;
+//   * per instruction i the workgroup splits its weight block W_{i,d}[columns of h, :] into three bf16 planes ONCE
+//     (exact 3-way split, gnnrag_common.h) and keeps them in LDS (3 x 112 x 416 B = 140 KB at D = 200; row stride
+//     26 x 16 B keeps the ds_read_b128 fragment reads bank-conflict free);
+//   * every wave owns up to 5 of the chunk's 16-row tiles and keeps ALL their accumulators in registers across the
+//     instructions (5 x 7 column tiles x 4 = 140 VGPRs), so P is written once and nothing is re-read;
+//   * the A fragment of (tile, i, 32 k) - relu(T * ins), split into planes in registers - is built by the lane
+//     that feeds it to the MFMA, from loads issued one k block ahead; six v_mfma_f32_16x16x32_bf16 per (column
+//     tile, k block): hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid, smallest terms first, fp32 accumulation.
+// Two barriers per instruction and workgroup instead of two per 32 k.
+#include "gnnrag_common.h"
+
+namespace gnnrag {
+
+constexpr int kTabTPW = 3;        // row tiles per wave and pass (accumulators in registers; 5 spill: 140 + 40 + 36 VGPRs)
+constexpr int kTabNTH = 7;        // column tiles per column part (two parts cover up to 13 tiles = 208 columns)
+constexpr int kTabNKB = 7;        // k blocks of 32: 192 < D <= 208 (the hidden size of the BASELINE configs is 200)
+constexpr int kTabSlots = 26;     // LDS row stride of a weight plane in 16-byte slots (26 % 4 == 2: conflict free)
+constexpr int kTabQBytes = 160 * 1024 - 3 * kTabNTH * 16 * kTabSlots * 16 - 64;   // LDS left for instruction rows (24 000 B)
+
+struct TabArgs {
+  const float* T[2];       // [R1, D] relation tables of the two directions
+  const float* ins;        // [B, I, D]
+  const float* W;          // e2e_linear.weight [D, (2I+1) D]
+  float* P;                // [2, M, D]
+  const int2* rows;        // [M] (question, relation id) of every compact row
+  int32_t M, D, I, ldw;
+  int32_t ct0;             // column tiles of part 0 (part 1 takes the rest)
+  int32_t npass;           // passes of kTabTPW tiles per wave
+};
+
+// LDS row of column slot: the first four column tiles of a part are interleaved so that a lane holds four
+// consecutive columns (float4 stores in the epilogue), the others keep the plain order
+__device__ __forceinline__ int tab_lds_row(int j) {
+  if (j < 64) return ((j & 3) << 4) + (j >> 2);
+  return j;
+}
+
+// One column part with CTN column tiles (compile time: the MFMA loop has no branches).  QLDS: the instruction rows
+// of the chunk's questions are in LDS (the usual case) - also compile time: a run-time branch around the global-memory
+// variant's loads would make every vmcnt wait of the loop conservative, i.e. wait for the prefetch just issued.
+template <int CTN, bool QLDS>
+__device__ __forceinline__ void tables_b3_part(const TabArgs& a, unsigned char* lds, int col0, int bmin, int nq) {
+  constexpr int RB = kTabSlots * 16;                        // bytes per weight row of one plane
+  constexpr int PL = kTabNTH * 16 * RB;                     // bytes per plane
+  constexpr int ctn = CTN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int d = blockIdx.y;
+  const int D = a.D, I = a.I;
+  const int ncol = min(ctn * 16, D - col0);                 // valid columns of this part
+  const float* T = a.T[d];
+  float* P = a.P + (size_t)d * a.M * D;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  constexpr int NKB = kTabNKB;                              // 32-wide k blocks
+  const int KC = D >> 2;                                    // float4 chunks of a weight row
+
+  // this wave's 16-row tiles: the chunk's tiles are dealt out contiguously to the 8 waves
+  const long long U = ((long long)a.M + 15) >> 4;
+  const int c0 = (int)(U * blockIdx.x / gridDim.x), c1 = (int)(U * (blockIdx.x + 1) / gridDim.x);
+  const int nchunk = c1 - c0;
+  const int w0 = c0 + (int)((long long)nchunk * wave / 8), w1 = c0 + (int)((long long)nchunk * (wave + 1) / 8);
+
+  if (tid < 16) reinterpret_cast<unsigned*>(lds + 3 * PL)[tid] = 0u;   // slack behind the last plane: finite (k >= D reads)
+  // the instruction rows ins[b, :, :] of the questions this chunk's rows belong to (rows are sorted by question):
+  // LDS behind the planes when they fit, else they are read from global memory (cache resident)
+  float* qarea = reinterpret_cast<float*>(lds + 3 * PL + 64);
+  constexpr bool q_in_lds = QLDS;
+  if (q_in_lds) {
+    const float* src = a.ins + (size_t)bmin * I * D;
+    for (int x = tid * 4; x < nq * I * D; x += 512 * 4)
+      *reinterpret_cast<f32x4*>(qarea + x) = *reinterpret_cast<const f32x4*>(src + x);
+  }
+
+  for (int pass = 0; pass < a.npass; ++pass) {
+    const int tbase = w0 + pass * kTabTPW;
+    const int ntile = max(0, min(kTabTPW, w1 - tbase));     // wave-uniform
+    f32x4 acc[kTabTPW][CTN];
+#pragma unroll
+    for (int j = 0; j < kTabTPW; ++j)
+#pragma unroll
+      for (int nt = 0; nt < CTN; ++nt) acc[j][nt] = zero4;
+
+    for (int i = 0; i < I; ++i) {
+      __syncthreads();                                      // the previous block's fragment reads are done
+      // ---- this instruction's weight block -> three bf16 planes in LDS ----
+      {
+        const int wcol = (1 + 2 * i + d) * D;               // first k column of the block inside e2e_linear.weight
+        const int total = ctn * 16 * kTabSlots * 2;         // 8-byte pieces (4 k) per plane: rows x 52
+        constexpr int UN = 6;                               // requests in flight per thread before the first split
+        for (int base = 0; base < total; base += 512 * UN) {
+          f32x4 v[UN];
+          int off[UN];
+#pragma unroll
+          for (int u = 0; u < UN; ++u) {
+            const int idx = base + u * 512 + tid;
+            const int j = idx / (kTabSlots * 2), kc = idx - j * (kTabSlots * 2);
+            v[u] = zero4;
+            off[u] = idx < total ? tab_lds_row(j) * RB + kc * 8 : -1;
+            if (idx < total && j < ncol && kc < KC)
+              v[u] = *reinterpret_cast<const f32x4*>(a.W + (size_t)(col0 + j) * a.ldw + wcol + 4 * kc);
+          }
+#pragma unroll
+          for (int u = 0; u < UN; ++u) {
+            if (off[u] >= 0) {
+              const Split3 sp = split3(v[u]);
+              unsigned char* dst = lds + off[u];
+              *reinterpret_cast<uint2*>(dst) = sp.hi;
+              *reinterpret_cast<uint2*>(dst + PL) = sp.mid;
+              *reinterpret_cast<uint2*>(dst + 2 * PL) = sp.lo;
+            }
+          }
+        }
+      }
+      __syncthreads();
+
+      // ---- MFMA phase: k blocks outermost, the wave's tiles inside: a tile's T row piece for k block kb + 1 is
+      // requested right after the piece for kb has been consumed, i.e. a whole round of tiles (kTabTPW x 42 MFMAs)
+      // before its use; the instruction rows come from LDS ----
+      int toff[kTabTPW], qoff[kTabTPW];                     // per tile: this lane's row offsets (floats) into T / the q area
+#pragma unroll
+      for (int j = 0; j < kTabTPW; ++j) {
+        const int m = min((tbase + (j < ntile ? j : 0)) * 16 + fr, a.M - 1);
+        const int2 br = a.rows[m];
+        toff[j] = br.y * D + 8 * fg;
+        qoff[j] = ((br.x - bmin) * I + i) * D + 8 * fg;
+      }
+      const int kmax = D - 8;                               // last valid 8-element start of a row
+      f32x4 traw[kTabTPW][2];
+#pragma unroll
+      for (int j = 0; j < kTabTPW; ++j) {
+        const float* tp = T + toff[j] + (min(8 * fg, kmax) - 8 * fg);
+        traw[j][0] = *reinterpret_cast<const f32x4*>(tp);
+        traw[j][1] = *reinterpret_cast<const f32x4*>(tp + 4);
+      }
+      for (int kb = 0; kb < NKB; ++kb) {      // (not unrolled: the unrolled loop spills 200 registers)
+        const bool kok = 32 * kb + 8 * fg <= kmax;
+        const int kbn = min(kb + 1, NKB - 1);               // (the last block requests itself again: no branch)
+        const int kon = min(32 * kbn + 8 * fg, kmax) - 8 * fg;
+        const int koq = min(32 * kb + 8 * fg, kmax) - 8 * fg;
+        const unsigned char* wb = lds + fr * RB + kb * 64 + fg * 16;
+#pragma unroll
+        for (int j = 0; j < kTabTPW; ++j) {
+          if (j < ntile) {                                  // wave-uniform
+            const f32x4 t0 = traw[j][0], t1 = traw[j][1];
+            {
+              const float* tp = T + toff[j] + kon;
+              traw[j][0] = *reinterpret_cast<const f32x4*>(tp);
+              traw[j][1] = *reinterpret_cast<const f32x4*>(tp + 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);              // the requests stay ABOVE the MFMAs
+            f32x4 q0, q1;
+            if constexpr (QLDS) {
+              const float* qp = qarea + qoff[j] + koq;
+              q0 = *reinterpret_cast<const f32x4*>(qp);
+              q1 = *reinterpret_cast<const f32x4*>(qp + 4);
+            } else {
+              const float* qp = a.ins + (size_t)bmin * I * D + qoff[j] + koq;
+              q0 = *reinterpret_cast<const f32x4*>(qp);
+              q1 = *reinterpret_cast<const f32x4*>(qp + 4);
+            }
+            // A planes of this k block: relu(T * ins), exact 3-way bf16 split
+            const Split3 s0 = split3(kok ? __builtin_elementwise_max(t0 * q0, zero4) : zero4);
+            const Split3 s1 = split3(kok ? __builtin_elementwise_max(t1 * q1, zero4) : zero4);
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            bf16x8 ap[3];
+            ap[0] = __builtin_bit_cast(bf16x8, (u32x4){s0.hi.x, s0.hi.y, s1.hi.x, s1.hi.y});
+            ap[1] = __builtin_bit_cast(bf16x8, (u32x4){s0.mid.x, s0.mid.y, s1.mid.x, s1.mid.y});
+            ap[2] = __builtin_bit_cast(bf16x8, (u32x4){s0.lo.x, s0.lo.y, s1.lo.x, s1.lo.y});
+            // (A plane, B plane) pairs, smallest terms first: mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi
+            constexpr int PA[6] = {1, 2, 0, 1, 0, 0};
+            constexpr int PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+            for (int nt = 0; nt < CTN; nt += 2) {
+              bf16x8 b0[3], b1[3];
+#pragma unroll
+              for (int pl = 0; pl < 3; ++pl) {
+                b0[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + nt * 16 * RB));
+                b1[pl] = b0[pl];
+                if (nt + 1 < CTN)
+                  b1[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + (nt + 1) * 16 * RB));
+              }
+#pragma unroll
+              for (int p = 0; p < 6; ++p) {
+                acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[PA[p]], b0[PB[p]], acc[j][nt], 0, 0, 0);
+                if (nt + 1 < CTN)
+                  acc[j][nt + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[PA[p]], b1[PB[p]], acc[j][nt + 1], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+
+    // ---- epilogue: the pass's tiles leave the registers (C layout: rows 4 fg + q, column slot fr) ----
+#pragma unroll
+    for (int j = 0; j < kTabTPW; ++j) {
+      if (j < ntile) {
+        const int rbase = (tbase + j) * 16 + 4 * fg;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = rbase + q;
+          if (row < a.M) {
+            float* prow = P + (size_t)row * D + col0;
+            // interleaved group (column tiles 0..3): columns 4 fr .. 4 fr + 3
+            static_assert(CTN >= 4, "a column part holds at least the interleaved group");
+            {
+              const f32x4 v = {acc[j][0][q], acc[j][1][q], acc[j][2][q], acc[j][3][q]};
+              const int c = 4 * fr;
+              if (c + 4 <= ncol) *reinterpret_cast<f32x4*>(prow + c) = v;
+              else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (c + e < ncol) prow[c + e] = v[e];
+              }
+            }
+#pragma unroll
+            for (int nt = 4; nt < CTN; ++nt) {
+              const int c = nt * 16 + fr;
+              if (c < ncol) prow[c] = acc[j][nt][q];
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void k_tables_b3(TabArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int NT = (a.D + 15) >> 4;
+  const int h = blockIdx.z;
+  const int ctn = h == 0 ? a.ct0 : NT - a.ct0;              // column tiles of this part
+  const int col0 = h == 0 ? 0 : a.ct0 * 16;                 // first column of this part
+  // questions this chunk's rows belong to (rows are sorted by question)
+  const long long U = ((long long)a.M + 15) >> 4;
+  const int c0 = (int)(U * blockIdx.x / gridDim.x), c1 = (int)(U * (blockIdx.x + 1) / gridDim.x);
+  const int rlo = min(c0 * 16, a.M - 1), rhi = min(c1 * 16, a.M) - 1;
+  const int bmin = a.rows[rlo].x, bmax = a.rows[max(rhi, rlo)].x;
+  const int nq = bmax - bmin + 1;
+  const bool q_in_lds = (size_t)nq * a.I * a.D * sizeof(float) <= kTabQBytes;
+#define GNNRAG_TAB_CASE(N)                                                  \
+  case N:                                                                   \
+    if (q_in_lds) tables_b3_part<N, true>(a, lds, col0, bmin, nq);          \
+    else tables_b3_part<N, false>(a, lds, col0, bmin, nq);                  \
+    break;
+  switch (ctn) {
+    GNNRAG_TAB_CASE(6) GNNRAG_TAB_CASE(7)
+    default: break;
+  }
+#undef GNNRAG_TAB_CASE
+}
+
+int tables_b3_launch(const gnnrag_csr* csr, const float* T_fwd, const float* T_inv, const float* ins, const float* W,
+                     float* P, int32_t D, int32_t I, hipStream_t stream) {
+  // shapes of the kernel: D a multiple of 8 (a lane's 8 consecutive k), at most 2 x 7 column tiles, 4-byte offsets
+  // that keep float4 accesses aligned, enough rows to fill the chip
+  if (D % 8 || (D + 31) / 32 != kTabNKB || (D + 15) / 16 != 13 || csr->rel_total < 1024) return GNNRAG_E_UNSUPPORTED;
+  if ((((uintptr_t)T_fwd | (uintptr_t)T_inv | (uintptr_t)ins | (uintptr_t)W | (uintptr_t)P) & 15) != 0)
+    return GNNRAG_E_UNSUPPORTED;
+  TabArgs a;
+  memset(&a, 0, sizeof(a));
+  a.T[0] = T_fwd; a.T[1] = T_inv; a.ins = ins; a.W = W; a.P = P;
+  a.rows = (const int2*)csr->rel_rows;
+  a.M = csr->rel_total; a.D = D; a.I = I; a.ldw = (2 * I + 1) * D;
+  const int NT = (D + 15) / 16;
+  a.ct0 = NT <= kTabNTH ? NT : (NT + 1) / 2;
+  const int parts = NT <= kTabNTH ? 1 : 2;
+  int cus = 0;
+  {
+    const int rc = device_cu_count(&cus);
+    if (rc) return rc;
+  }
+  const long long U = ((long long)a.M + 15) / 16;
+  int chunks = cus / (2 * parts);
+  if (chunks < 1) chunks = 1;
+  if ((long long)chunks * 8 > U) chunks = (int)((U + 7) / 8);
+  const int tiles_per_wave = (int)((((U + chunks - 1) / chunks) + 7) / 8);         // largest w1 - w0 of the floor split
+  a.npass = (tiles_per_wave + kTabTPW - 1) / kTabTPW;
+  const size_t lds = 160 * 1024;          // three weight planes, 64 B of slack, instruction rows
+  static DeviceMask cap;
+  {
+    const int rc = raise_lds_cap(k_tables_b3, cap);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_tables_b3, dim3(chunks, 2, parts), dim3(512), lds, stream, a);
+  GNNRAG_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace gnnrag

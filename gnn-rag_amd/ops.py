@@ -12,17 +12,22 @@ import torch
 from . import _lib
 
 
-MATH_FP32, MATH_BF16X3 = 0, 1
+MATH_FP32, MATH_BF16X3, MATH_MIXED = 0, 1, 2
+MATH_NAMES = {MATH_FP32: "fp32 (v_mfma_f32_16x16x4_f32, bit-exact fmaf chains)",
+              MATH_BF16X3: "bf16x3 (exact 3-way bf16 split, 6 plane products on v_mfma_f32_16x16x32_bf16, fp32 accumulate)",
+              MATH_MIXED: "mixed (exact fp32 MFMA for the self-block update and small products, bf16x3 for the relation "
+                          "tables: per product the faster fp32-class form)"}
 # Math mode the wrappers below pass to the library (the library itself keeps no mode: it is an argument of
-# every dense entry point).  GNNRAG_MATH=fp32|bf16x3 sets the binding's default for A/B runs.
-_default_math = {"fp32": MATH_FP32, "bf16x3": MATH_BF16X3}[os.environ.get("GNNRAG_MATH", "fp32")]
+# every dense entry point).  GNNRAG_MATH=fp32|bf16x3|mixed sets the binding's default.
+_default_math = {"fp32": MATH_FP32, "bf16x3": MATH_BF16X3, "mixed": MATH_MIXED}[os.environ.get("GNNRAG_MATH", "mixed")]
 
 
 def set_dense_math(mode: int) -> int:
-    """Default math mode of this binding's dense calls: MATH_FP32 (exact fp32 MFMA) or MATH_BF16X3 (exact
-    3-way bf16 split, six plane products, fp32 accumulate).  Returns the old mode."""
+    """Default math mode of this binding's dense calls: MATH_FP32 (exact fp32 MFMA), MATH_BF16X3 (exact 3-way bf16
+    split, six plane products, fp32 accumulate) or MATH_MIXED (per kernel the faster of the two; the default).
+    Returns the old mode."""
     global _default_math
-    if mode not in (MATH_FP32, MATH_BF16X3):
+    if mode not in (MATH_FP32, MATH_BF16X3, MATH_MIXED):
         raise ValueError("unknown math mode %r" % (mode,))
     old, _default_math = _default_math, int(mode)
     return old

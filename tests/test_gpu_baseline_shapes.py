@@ -34,7 +34,9 @@ def _plan_of(batch, dev):
 
 def _check_stack(got, want, ncalls, tol=TOL_STATED, what=""):
     for c in range(ncalls):
-        eh = np.abs(got["h"][c] - want["h"][c]).max()
+        # node embeddings: fp32 rounding scales with their magnitude (a TypeLayer start sums hundreds of facts at the
+        # hubs); distributions are <= 1
+        eh = np.abs(got["h"][c] - want["h"][c]).max() / max(1.0, np.abs(want["h"][c]).max())
         ed = np.abs(got["dist"][c] - want["dist"][c]).max()
         assert eh <= tol and ed <= tol, (what, c, eh, ed)
         assert (got["dist"][c].argmax(1) == want["dist"][c].argmax(1)).all(), (what, c)

@@ -436,11 +436,14 @@ def test_shape_sweep_both_paths_vs_np64(dev, B, N, E, R, D, I):
                                        err_msg="dist call %d path %d" % (c, path))
 
 
-@pytest.fixture
-def bf16x3(dev):
+# The binding's default math mode is MATH_MIXED (per kernel the faster fp32-class form), so every test above runs
+# that mode; the tests below repeat the reference-fixture and oracle gates with the mode pinned to bf16x3 (param
+# "bf16x3") and to exact fp32 ("fp32") everywhere.
+@pytest.fixture(params=["bf16x3", "fp32"])
+def bf16x3(dev, request):
     from gnnrag_amd import ops
-    old = ops.set_dense_math(ops.MATH_BF16X3)
-    yield
+    old = ops.set_dense_math(ops.MATH_BF16X3 if request.param == "bf16x3" else ops.MATH_FP32)
+    yield request.param
     ops.set_dense_math(old)
 
 
@@ -455,10 +458,8 @@ def test_bf16x3_linear_is_fp32_class(dev, bf16x3, M, K, Nout):
     b = rng.standard_normal(Nout).astype(np.float32)
     want = A.astype(np.float64) @ W.astype(np.float64).T + b
     Ad, Wd, bd = _to_dev(dev, A, W, b)
-    got3 = ops.linear(Ad, Wd, bd).cpu().numpy()
-    ops.set_dense_math(ops.MATH_FP32)
-    got32 = ops.linear(Ad, Wd, bd).cpu().numpy()
-    ops.set_dense_math(ops.MATH_BF16X3)
+    got3 = ops.linear(Ad, Wd, bd, math=ops.MATH_BF16X3).cpu().numpy()
+    got32 = ops.linear(Ad, Wd, bd, math=ops.MATH_FP32).cpu().numpy()
     scale = np.abs(A).astype(np.float64) @ np.abs(W).astype(np.float64).T + np.abs(b)      # sum |a||w|
     e3 = (np.abs(got3 - want) / scale).max()
     e32 = (np.abs(got32 - want) / scale).max()
@@ -586,3 +587,35 @@ def test_query_reform_equals_reference_op_sequence_at_c2(dev, capsys):
             times.append(a.elapsed_time(b) / 10)
     with capsys.disabled():
         print("\nQueryReform at C2: reference op sequence %.3f ms, drop-in %.3f ms" % tuple(times))
+
+
+@pytest.mark.parametrize("B,R,used,I,N", [(4, 600, None, 2, 1200), (9, 1500, 260, 3, 1500), (3, 40, None, 1, 300)])
+def test_relation_tables_bf16x3_w_resident_kernel(dev, B, R, used, I, N):
+    """The bf16x3 relation tables on the W-resident kernel (tables_b3.hip; D = 200, >= 1024 compact rows): against
+    the exact-fp32 kernel and the float64 definition, incl. questions of very different relation counts (row chunks
+    that span several questions), 1-3 instructions and a row count that is not a multiple of 16."""
+    from gnnrag_amd import ops, synth
+    D = 200
+    cfg = synth.GraphConfig(name="tab", B=B, N=N, E=6 * N, R=R, D=D, I=I, L=1, T=1, seed=B + R, rel_per_question=used,
+                            n_real_min=N // 3)
+    batch = synth.make_batch(cfg)
+    et = batch.edge_tuple
+    plan = ops.CsrPlan(et[0], et[1], et[2], cfg.B, cfg.N, cfg.R1, dev)
+    assert plan.rel_total >= 1024 or (B, R) == (3, 40)          # the last case stays on the k-tiled kernel
+    rng = np.random.default_rng(5)
+    Tf = (0.3 * rng.standard_normal((cfg.R1, D))).astype(np.float32)
+    Ti = (0.3 * rng.standard_normal((cfg.R1, D))).astype(np.float32)
+    ins = (0.3 * rng.standard_normal((B, I, D))).astype(np.float32)
+    W = rng.uniform(-0.05, 0.05, size=(D, (2 * I + 1) * D)).astype(np.float32)
+    dTf, dTi, dins, dW = (torch.from_numpy(x).to(dev) for x in (Tf, Ti, ins, W))
+    P32 = ops.relation_tables(plan, dTf, dTi, dins, dW, math=ops.MATH_FP32).cpu().numpy()
+    Pb3 = ops.relation_tables(plan, dTf, dTi, dins, dW, math=ops.MATH_BF16X3).cpu().numpy()
+    rows = plan.rel_rows()
+    want = np.zeros((2, plan.rel_total, D))
+    for d, Tt in enumerate((Tf, Ti)):
+        for i in range(I):
+            A = np.maximum(Tt[rows[:, 1]].astype(np.float64) * ins[rows[:, 0], i].astype(np.float64), 0.0)
+            want[d] += A @ W[:, (1 + 2 * i + d) * D:(2 + 2 * i + d) * D].astype(np.float64).T
+    scale = max(1.0, np.abs(want).max())
+    assert np.abs(P32 - want).max() <= TOL_INTERNAL * scale
+    assert np.abs(Pb3 - want).max() <= TOL_INTERNAL * scale
