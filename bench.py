@@ -6,7 +6,8 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" = one pass of the hot path over one batch of synthetic question subgraphs:
-L consecutive ReasonGNNLayer.forward calls (relation transform + typed-edge aggregation +
+T x L consecutive ReasonGNNLayer.forward calls (T = 1 for the C2 / C4 / C5 workloads, 3 for the WebQSP-shaped C1 / C3:
+the released checkpoint's num_iter), i.e. per iteration L calls (relation transform + typed-edge aggregation +
 gated update + score + masked softmax each) starting from the seed distribution, exactly as
 one iteration of ReaRev.forward drives the layer (reference rearev.py:206-211).  Inputs
 (CSR structure, features, parameters) are resident in HBM when the timed region starts; the
@@ -61,6 +62,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch", choices=["eager", "graph"], default="eager",
+                    help="eager: one gnnrag_reason_stack call per step; graph: the step captured once as a hipGraph "
+                         "(gnnrag_reason_stack_capture) and replayed")
     ap.add_argument("--cpu-sample-b", type=int, default=8)
     ap.add_argument("--math", choices=["default", "fp32", "bf16x3", "mixed"], default="default",
                     help="math mode of the dense projections (default = the library's default)")
@@ -112,9 +116,27 @@ def main():
     torch.cuda.synchronize()
     csr_build_ms = (time.perf_counter() - t0) * 1e3 / 3
 
+    graph = None
+    if args.launch == "graph":
+        with torch.no_grad():
+            layer.local_entity_emb = devin.h0
+            stack.run_layers(layer, cfg, devin)                   # builds layer._stack, raises launch attributes
+            graph = layer._stack
+            graph.capture(devin.h0, devin.seed_dist, devin.ins[0].clone())
+        h0_slot = graph.h[cfg.L - 1]
+
     def step():
-        layer.local_entity_emb = devin.h0
-        d, _ = stack.run_layers(layer, cfg, devin)
+        if graph is not None:
+            # a step starts from h0 (like the eager step): the captured sequence reads its node state from h[L-1];
+            # T iterations = T replays, the instructions of iteration t written into the captured buffer first
+            h0_slot.copy_(devin.h0, non_blocking=True)
+            for t in range(cfg.T):
+                if cfg.T > 1:
+                    graph._graph_in[1].copy_(devin.ins[t], non_blocking=True)
+                d = graph.replay()[2][cfg.L - 1]
+        else:
+            layer.local_entity_emb = devin.h0
+            d, _ = stack.run_layers(layer, cfg, devin)
         if distributed:
             d = shard.gather_rows(d, cfg.B * world)
         return d
@@ -160,6 +182,8 @@ def main():
         # amortised over ONE step (a ReaRev forward runs num_iter steps on the same structure); never `value`
         "value_incl_upload_and_build": world * cfg.B * cfg.E * cfg.L / (elapsed / args.steps + csr_build_ms * 1e-3),
         "dense_math": math_name,
+        "launch": ("hipGraph replay of the captured L-layer sequence (+ one D2D copy of h0 per step)"
+                   if graph is not None else "eager: one gnnrag_reason_stack call per step"),
     }
 
     if rank == 0:

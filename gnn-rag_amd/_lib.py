@@ -40,6 +40,12 @@ class RelorderStruct(C.Structure):
                 ("chunk_ptr", C.c_void_p)]
 
 
+class LayerParams(C.Structure):
+    """Mirror of ``struct gnnrag_layer_params`` (include/gnnrag.h)."""
+    _fields_ = [("W_rel", C.c_void_p), ("b_rel", C.c_void_p), ("pos_fwd", C.c_void_p), ("pos_inv", C.c_void_p),
+                ("W_e2e", C.c_void_p), ("b_e2e", C.c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/gnnrag.h declares
 _VP = C.c_void_p
 SIGNATURES = {
@@ -80,12 +86,19 @@ SIGNATURES = {
     "gnnrag_layer_workspace_bytes": (C.c_size_t, [C.POINTER(CsrStruct), C.c_int32, C.c_int32]),
     "gnnrag_reason_layer": (C.c_int, [C.POINTER(CsrStruct)] + [_VP] * 9 + [C.c_int32] + [_VP] * 8 +
                             [_VP, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP]),
+    "gnnrag_reason_stack": (C.c_int, [C.POINTER(CsrStruct), C.c_int32, C.POINTER(LayerParams)] + [_VP] * 5 +
+                            [C.c_int32] + [_VP] * 6 + [_VP, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP]),
+    "gnnrag_reason_stack_capture": (C.c_int, [C.POINTER(CsrStruct), C.c_int32, C.POINTER(LayerParams)] + [_VP] * 5 +
+                                    [C.c_int32] + [_VP] * 6 + [_VP, C.c_size_t, C.c_int32, C.c_int32, C.c_int32,
+                                                               C.c_int32, _VP, C.POINTER(C.c_void_p)]),
+    "gnnrag_graph_launch": (C.c_int, [_VP, _VP]),
+    "gnnrag_graph_destroy": (C.c_int, [_VP]),
     "gnnrag_stream_copy": (C.c_int, [_VP, _VP, C.c_int64, _VP]),
     "gnnrag_abi_version": (C.c_int, []),
     "gnnrag_error_string": (C.c_char_p, [C.c_int]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 PATH_AUTO, PATH_UNFUSED, PATH_FUSED = 0, 1, 2
 E_TUPLE = -4
 _lib = None

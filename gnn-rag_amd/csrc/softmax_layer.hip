@@ -187,6 +187,82 @@ extern "C" int gnnrag_reason_layer(const gnnrag_csr* csr, const float* h, const 
   return gnnrag_masked_softmax(score_out, dist_out, csr->B, csr->N, stream);
 }
 
+extern "C" int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnrag_layer_params* layers,
+                                   const float* h0, const float* dist0, const float* ins,
+                                   const float* relfeat_fwd, const float* relfeat_inv, int32_t pos_rows,
+                                   const float* w_score, const float* b_score, const float* mask, float* h_out,
+                                   float* score_out, float* dist_out, void* workspace, size_t workspace_bytes,
+                                   int32_t D, int32_t I, int32_t path, int32_t math, gnnrag_stream_t stream) {
+  if (!csr || L <= 0 || !layers || !h0 || !dist0 || !h_out || !score_out || !dist_out) return GNNRAG_E_BADARG;
+  const size_t BN = (size_t)csr->B * csr->N;
+  const float* h = h0;
+  const float* dist = dist0;
+  for (int j = 0; j < L; ++j) {
+    const gnnrag_layer_params& p = layers[j];
+    float* hj = h_out + (size_t)j * BN * D;
+    float* sj = score_out + (size_t)j * BN;
+    float* dj = dist_out + (size_t)j * BN;
+    const int rc = gnnrag_reason_layer(csr, h, dist, ins, relfeat_fwd, relfeat_inv, p.W_rel, p.b_rel, p.pos_fwd,
+                                       p.pos_inv, pos_rows, p.W_e2e, p.b_e2e, w_score, b_score, mask, hj, sj, dj,
+                                       workspace, workspace_bytes, D, I, path, math, stream);
+    if (rc) return rc;
+    h = hj;
+    dist = dj;
+  }
+  return 0;
+}
+
+struct gnnrag_graph {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
+
+extern "C" int gnnrag_reason_stack_capture(const gnnrag_csr* csr, int32_t L, const gnnrag_layer_params* layers,
+                                           const float* h0, const float* dist0, const float* ins,
+                                           const float* relfeat_fwd, const float* relfeat_inv, int32_t pos_rows,
+                                           const float* w_score, const float* b_score, const float* mask,
+                                           float* h_out, float* score_out, float* dist_out, void* workspace,
+                                           size_t workspace_bytes, int32_t D, int32_t I, int32_t path, int32_t math,
+                                           gnnrag_stream_t stream_, gnnrag_graph** out) {
+  if (!out) return GNNRAG_E_BADARG;
+  *out = nullptr;
+  hipStream_t stream = (hipStream_t)stream_;
+  GNNRAG_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+  const int rc = gnnrag_reason_stack(csr, L, layers, h0, dist0, ins, relfeat_fwd, relfeat_inv, pos_rows, w_score,
+                                     b_score, mask, h_out, score_out, dist_out, workspace, workspace_bytes, D, I, path,
+                                     math, stream);
+  hipGraph_t graph = nullptr;
+  const hipError_t e = hipStreamEndCapture(stream, &graph);      // always end the capture, also after an error
+  if (rc) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
+  }
+  if (e != hipSuccess) return (int)e;
+  hipGraphExec_t exec = nullptr;
+  const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (e2 != hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    return (int)e2;
+  }
+  gnnrag_graph* g = new gnnrag_graph{graph, exec};
+  *out = g;
+  return 0;
+}
+
+extern "C" int gnnrag_graph_launch(gnnrag_graph* graph, gnnrag_stream_t stream) {
+  if (!graph) return GNNRAG_E_BADARG;
+  GNNRAG_HIP(hipGraphLaunch(graph->exec, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int gnnrag_graph_destroy(gnnrag_graph* graph) {
+  if (!graph) return 0;
+  (void)hipGraphExecDestroy(graph->exec);
+  (void)hipGraphDestroy(graph->graph);
+  delete graph;
+  return 0;
+}
+
 extern "C" int gnnrag_abi_version(void) { return GNNRAG_ABI_VERSION; }
 
 extern "C" const char* gnnrag_error_string(int code) {

@@ -43,6 +43,12 @@ class ReasonGNNLayer(BaseGNNLayer):
         self._ws = ops.LayerWorkspace()
         # kernel path of the library (0 auto / 1 unfused / 2 fused); GNNRAG_PATH overrides for A/B runs
         self.path = int(os.environ.get("GNNRAG_PATH", "0"))
+        # One library call per ReaRev iteration instead of one per layer (ops.LayerStack): the step-0 call runs all
+        # num_gnn layers, the calls for steps 1.. hand out what it computed - provided the caller passes back the
+        # distribution it was given and the same instructions, as ReaRev.forward does (rearev.py:208-210).
+        self.use_stack = os.environ.get("GNNRAG_STACK", "1") != "0"
+        self._stack = None
+        self._ahead = None
 
     def init_layers(self, args):
         D = self.entity_dim
@@ -77,11 +83,20 @@ class ReasonGNNLayer(BaseGNNLayer):
         self.possible_cand = []
         self.build_matrix()
         self.query_entities = query_entities
+        self._stack = None             # bound to this batch's structure and relation features on first use
+        self._ahead = None
 
     def forward(self, current_dist, relational_ins, step=0, return_score=False):
         """Next distribution and node representations (reference: reasongnn.py:134-174)."""
         if torch.is_grad_enabled() or (self.training and self.linear_dropout > 0):
             return self._forward_autograd(current_dist, relational_ins, step, return_score)
+        if self.use_stack and self.num_gnn > 1:
+            got = self._forward_stack(current_dist, relational_ins, step)
+            if got is not None:
+                h_out, score_tp, new_dist = got
+                self.local_entity_emb = h_out
+                self.possible_cand.append(self.local_entity_mask)
+                return (score_tp, new_dist) if return_score else (new_dist, h_out)
         rel_linear = getattr(self, "rel_linear" + str(step))
         e2e_linear = getattr(self, "e2e_linear" + str(step))
         pos = pos_inv = None
@@ -100,6 +115,32 @@ class ReasonGNNLayer(BaseGNNLayer):
         if return_score:
             return score_tp, new_dist
         return new_dist, self.local_entity_emb
+
+    def _forward_stack(self, current_dist, relational_ins, step):
+        """(h, score, dist) of layer `step` from a whole-iteration run, or None when the call does not continue the
+        sequence the step-0 call ran ahead (then the single-layer path computes it)."""
+        if step == 0:
+            if self._stack is None:
+                layers = []
+                for j in range(self.num_gnn):
+                    rl, e2e = getattr(self, "rel_linear" + str(j)), getattr(self, "e2e_linear" + str(j))
+                    pos = getattr(self, "pos_emb" + str(j)).weight if self.use_posemb else None
+                    pos_inv = getattr(self, "pos_emb_inv" + str(j)).weight if self.use_posemb else None
+                    layers.append((rl.weight, rl.bias, e2e.weight, e2e.bias, pos, pos_inv))
+                self._stack = ops.LayerStack(self.plan, self.rel_features.detach().float(),
+                                             self.rel_features_inv.detach().float(), layers, self.score_func.weight,
+                                             self.score_func.bias, self.local_entity_mask, self.num_ins, path=self.path)
+            h, score, dist = self._stack.run(self.local_entity_emb.detach().float(), current_dist.detach().float(),
+                                             relational_ins.detach().float())
+            self._ahead = dict(ins=relational_ins, h=h, score=score, dist=dist, given=[dist[j] for j in range(self.num_gnn)],
+                               emb=[h[j] for j in range(self.num_gnn)])
+            return self._ahead["emb"][0], score[0], self._ahead["given"][0]
+        a = self._ahead
+        if (a is None or step >= self.num_gnn or relational_ins is not a["ins"] or current_dist is not a["given"][step - 1]
+                or self.local_entity_emb is not a["emb"][step - 1]):
+            self._ahead = None
+            return None
+        return a["emb"][step], a["score"][step], a["given"][step]
 
     def _forward_autograd(self, current_dist, relational_ins, step, return_score):
         """Differentiable form of the same layer (reasongnn.py:134-174 op for op; the per-fact

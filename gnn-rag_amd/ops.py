@@ -513,6 +513,128 @@ def reason_layer(plan: CsrPlan, h, dist, ins, relfeat, relfeat_inv, W_rel, b_rel
     return h_out, score, dist_out
 
 
+class LayerStack:
+    """The L ``ReasonGNNLayer.forward`` calls of one ReaRev iteration (rearev.py:208-210) as ONE library call
+    (``gnnrag_reason_stack``), optionally captured as a hipGraph and replayed (``gnnrag_reason_stack_capture``).
+
+    Everything that does not change between the iterations of a batch is validated and turned into raw pointers once,
+    here: the structure, the relation features, the layers' parameters, the mask and the output buffers
+    (``h [L,B,N,D]``, ``score`` / ``dist [L,B,N]``: every layer's outputs are kept, the reference returns each of
+    them to its caller).  ``run(h0, dist0, ins)`` then costs one ctypes call."""
+
+    def __init__(self, plan: CsrPlan, relfeat, relfeat_inv, layers, w_score, b_score, mask, I: int,
+                 path: int = _lib.PATH_AUTO, math: Optional[int] = None):
+        """layers: list of (W_rel, b_rel, W_e2e, b_e2e, pos, pos_inv) tensors per layer (pos / pos_inv may be None)."""
+        lib = _lib.load()
+        B, N, R1 = plan.B, plan.N, plan.R1
+        relfeat = _chk(relfeat, "rel_features")
+        D = relfeat.shape[1]
+        _on_plan_device(plan, relfeat, "rel_features")
+        self.plan, self.B, self.N, self.D, self.I, self.L = plan, B, N, D, int(I), len(layers)
+        self.path, self.math = int(path), _math(math)
+        keep = [relfeat, _chk(relfeat_inv, "rel_features_inv", shape=(R1, D)),
+                _chk(w_score, "score_func.weight").reshape(-1), _chk(b_score, "score_func.bias").reshape(-1),
+                _chk(mask, "mask").reshape(-1)]
+        if tuple(relfeat.shape) != (R1, D) or keep[2].numel() != D or keep[4].numel() != B * N:
+            raise ValueError("layer stack inputs do not match the plan (B=%d, N=%d, R1=%d, D=%d)" % (B, N, R1, D))
+        self._relfeat, self._relfeat_inv, self._ws, self._bs, self._mask = keep
+        self._params = (_lib.LayerParams * self.L)()
+        self.pos_rows = 0
+        for j, (W_rel, b_rel, W_e2e, b_e2e, pos, pos_inv) in enumerate(layers):
+            t = [_chk(W_rel, "rel_linear.weight", shape=(D, D)), _chk(b_rel, "rel_linear.bias", shape=(D,)),
+                 _chk(W_e2e, "e2e_linear.weight", shape=(D, (2 * self.I + 1) * D)),
+                 _chk(b_e2e, "e2e_linear.bias", shape=(D,))]
+            if pos is not None:
+                pos = _chk(pos, "pos_emb.weight")
+                pos_inv = _chk(pos_inv, "pos_emb_inv.weight", shape=tuple(pos.shape))
+                if pos.shape[1] != D or pos.shape[0] > R1 or (self.pos_rows and pos.shape[0] != self.pos_rows):
+                    raise ValueError("pos_emb must be [<=R1, D], the same size in every layer")
+                self.pos_rows = pos.shape[0]
+                t += [pos, pos_inv]
+            keep += t
+            pr = self._params[j]
+            pr.W_rel, pr.b_rel, pr.W_e2e, pr.b_e2e = (x.data_ptr() for x in t[:4])
+            pr.pos_fwd, pr.pos_inv = (t[4].data_ptr(), t[5].data_ptr()) if pos is not None else (None, None)
+        self._keep = keep                                        # the tensors behind the raw pointers stay alive
+        self.device = relfeat.device
+        nbytes = max(lib.gnnrag_layer_workspace_bytes(C.byref(plan.c), D, self.I), 256)
+        self._ws_buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self._graph = None
+        self.h = self.score = self.dist = None                   # graph mode: the fixed buffers of the captured sequence
+
+    def _new_outputs(self):
+        f32, dev, L, B, N, D = torch.float32, self.device, self.L, self.B, self.N, self.D
+        return (torch.empty((L, B, N, D), dtype=f32, device=dev), torch.empty((L, B, N), dtype=f32, device=dev),
+                torch.empty((L, B, N), dtype=f32, device=dev))
+
+    def _args(self, h0, dist0, ins, out):
+        h, score, dist = out
+        return (C.byref(self.plan.c), self.L, self._params, h0.data_ptr(), dist0.data_ptr(), ins.data_ptr(),
+                self._relfeat.data_ptr(), self._relfeat_inv.data_ptr(), self.pos_rows, self._ws.data_ptr(),
+                self._bs.data_ptr(), self._mask.data_ptr(), h.data_ptr(), score.data_ptr(),
+                dist.data_ptr(), self._ws_buf.data_ptr(), self._ws_buf.numel(), self.D, self.I, self.path, self.math)
+
+    def _inputs(self, h0, dist0, ins):
+        h0 = _chk(h0, "local_entity_emb").reshape(self.B * self.N, self.D)
+        dist0 = _chk(dist0, "dist").reshape(-1)
+        ins = _chk(ins, "relational_ins", shape=(self.B, self.I, self.D))
+        if dist0.numel() != self.B * self.N:
+            raise ValueError("dist does not match the plan")
+        _on_plan_device(self.plan, h0, "local_entity_emb")
+        return h0, dist0, ins
+
+    def run(self, h0, dist0, ins):
+        """Runs the L layers; returns freshly allocated (h [L,B,N,D], score [L,B,N], dist [L,B,N])."""
+        h0, dist0, ins = self._inputs(h0, dist0, ins)
+        out = self._new_outputs()
+        with torch.cuda.device(h0.device):
+            _lib.check(_lib.load().gnnrag_reason_stack(*self._args(h0, dist0, ins, out), _stream()),
+                       "gnnrag_reason_stack")
+        return out
+
+    def capture(self, h0, dist0, ins):
+        """Captures the sequence as a hipGraph over FIXED buffers (``self.h / score / dist``, allocated here): the
+        node state is read from ``self.h[L-1]`` (the previous iteration's last layer; ``h0`` is copied there now),
+        the prior from ``dist0`` and the instructions from ``ins`` - both are kept and read again by every replay, so
+        rewrite them in place between replays (rearev.py:208,217-221).  An eager ``run`` must have happened before
+        (launch attributes are raised on first use)."""
+        if self.L < 2:
+            raise ValueError("graph replay needs num_gnn >= 2 (layer 0 reads the buffer the last layer writes)")
+        self.release_graph()
+        self.h, self.score, self.dist = self._new_outputs()
+        self.h[self.L - 1].copy_(h0.reshape(self.B, self.N, self.D))
+        h0g, dist0, ins = self._inputs(self.h[self.L - 1], dist0, ins)
+        g = C.c_void_p()
+        with torch.cuda.device(h0g.device):
+            # stream capture is not allowed on the legacy default stream (torch's default): capture on a side stream
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                _lib.check(_lib.load().gnnrag_reason_stack_capture(
+                    *self._args(h0g, dist0, ins, (self.h, self.score, self.dist)), _stream(), C.byref(g)),
+                    "gnnrag_reason_stack_capture")
+            torch.cuda.current_stream().wait_stream(side)
+        self._graph, self._graph_in = g, (dist0, ins)
+
+    def replay(self):
+        if self._graph is None:
+            raise RuntimeError("capture() first")
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().gnnrag_graph_launch(self._graph, _stream()), "gnnrag_graph_launch")
+        return self.h, self.score, self.dist
+
+    def release_graph(self):
+        if self._graph is not None:
+            _lib.load().gnnrag_graph_destroy(self._graph)
+            self._graph = None
+
+    def __del__(self):
+        try:
+            self.release_graph()
+        except Exception:
+            pass
+
+
 def seed_retrieve(seed_info: torch.Tensor, ent_emb: torch.Tensor) -> torch.Tensor:
     """sum_n seed_info[b,n] * ent_emb[b,n,:]  ->  [B,D] (query_update.py:40), reading only flagged rows."""
     lib = _lib.load()

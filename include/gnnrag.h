@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GNNRAG_ABI_VERSION 5
+#define GNNRAG_ABI_VERSION 6
 
 #define GNNRAG_E_BADARG      (-1)  /* null pointer / negative size / inconsistent sizes   */
 #define GNNRAG_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set (see DESIGN)  */
@@ -268,6 +268,47 @@ int gnnrag_reason_layer(const gnnrag_csr* csr,
                         float* h_out, float* score_out, float* dist_out,
                         void* workspace, size_t workspace_bytes,
                         int32_t D, int32_t I, int32_t path, int32_t math, gnnrag_stream_t stream);
+
+/* L consecutive ReasonGNNLayer.forward calls on one batch - what one iteration of ReaRev.forward does
+ * (rearev.py:208-210: `for j in range(num_gnn): curr_dist, global_rep = reasoning(curr_dist, relation_ins, step=j)`)
+ * enqueued with ONE call: layer j reads h[j-1] / dist[j-1] (h0 / dist0 for j = 0) and writes h_out[j], score_out[j],
+ * dist_out[j] ([L, B*N, D] / [L, B*N] / [L, B*N], every layer's outputs are kept: the reference returns each of them
+ * to its caller).  `layers` is a HOST array of L parameter sets.  Same arithmetic, kernels and workspace as L calls
+ * of gnnrag_reason_layer (bit-identical results); what it removes is the per-call host work in front of ~8 short
+ * kernels per layer, which bounds small batches (one question per batch: SURVEY.md section 8 f-3). */
+typedef struct gnnrag_layer_params {
+  const float* W_rel;    /* rel_linear{j}.weight [D, D]                      */
+  const float* b_rel;    /* rel_linear{j}.bias   [D]                         */
+  const float* pos_fwd;  /* pos_emb{j}.weight [pos_rows, D] or NULL          */
+  const float* pos_inv;  /* pos_emb_inv{j}.weight [pos_rows, D] or NULL      */
+  const float* W_e2e;    /* e2e_linear{j}.weight [D, (2I+1) D]               */
+  const float* b_e2e;    /* e2e_linear{j}.bias [D]                           */
+} gnnrag_layer_params;
+int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnrag_layer_params* layers,
+                        const float* h0, const float* dist0, const float* ins,
+                        const float* relfeat_fwd, const float* relfeat_inv, int32_t pos_rows,
+                        const float* w_score, const float* b_score, const float* mask,
+                        float* h_out, float* score_out, float* dist_out,
+                        void* workspace, size_t workspace_bytes,
+                        int32_t D, int32_t I, int32_t path, int32_t math, gnnrag_stream_t stream);
+
+/* The same L-layer sequence captured as a hipGraph (stream capture on `stream`, which must not be capturing): every
+ * pointer and size is baked in, so a replay repeats the sequence on whatever the buffers hold then.  One batch's
+ * T iterations replay one graph when the caller keeps the buffers in place: h0 = h_out + (L-1)*B*N*D (the previous
+ * iteration's last layer; rearev.py:208-211 carries the node state over), dist0 = the seed distribution, `ins`
+ * rewritten in place between replays (rearev.py:217-221).  Results are bit-identical to the eager sequence.
+ * Run the eager call once before capturing (launch attributes are raised on first use). */
+typedef struct gnnrag_graph gnnrag_graph;
+int gnnrag_reason_stack_capture(const gnnrag_csr* csr, int32_t L, const gnnrag_layer_params* layers,
+                                const float* h0, const float* dist0, const float* ins,
+                                const float* relfeat_fwd, const float* relfeat_inv, int32_t pos_rows,
+                                const float* w_score, const float* b_score, const float* mask,
+                                float* h_out, float* score_out, float* dist_out,
+                                void* workspace, size_t workspace_bytes,
+                                int32_t D, int32_t I, int32_t path, int32_t math, gnnrag_stream_t stream,
+                                gnnrag_graph** out);
+int gnnrag_graph_launch(gnnrag_graph* graph, gnnrag_stream_t stream);
+int gnnrag_graph_destroy(gnnrag_graph* graph);
 
 /* Candidate selection of Evaluator.evaluate (evaluate.py:188-207) + the sort and top-p cut of
  * f1_and_hits (evaluate.py:34-51), one workgroup per question:

@@ -93,6 +93,27 @@ def _patch_backend(monkeypatch):
         return torch.from_numpy(og.typelayer_grad(plan.tuple7(), plan.B, plan.N, T0, g_pre.numpy(),
                                                   plan.w_rel if use_w_rel else None).astype(np.float32))
 
+    class FakeStack:
+        """ops.LayerStack on the oracle: the module's run-ahead protocol (step 0 computes every layer of the
+        iteration, steps 1.. are handed out) is exercised against the live reference's own ReaRev.forward loop."""
+        calls = 0
+
+        def __init__(self, plan, relfeat, relfeat_inv, layers, w_score, b_score, mask, I, path=0, math=None):
+            self.plan, self.relfeat, self.relfeat_inv, self.layers = plan, relfeat, relfeat_inv, layers
+            self.w_score, self.b_score, self.mask = w_score, b_score, mask
+
+        def run(self, h0, dist0, ins):
+            FakeStack.calls += 1
+            hs, ss, ds = [], [], []
+            h, d = h0, dist0
+            B, N = self.plan.B, self.plan.N
+            for (W_rel, b_rel, W_e2e, b_e2e, pos, pos_inv) in self.layers:
+                h, sc, d = reason_layer(self.plan, h, d, ins, self.relfeat, self.relfeat_inv, W_rel, b_rel, W_e2e, b_e2e,
+                                        self.w_score, self.b_score, self.mask, pos=pos, pos_inv=pos_inv)
+                hs.append(h.reshape(B, N, -1)); ss.append(sc.reshape(B, N)); ds.append(d.reshape(B, N))
+            return torch.stack(hs), torch.stack(ss), torch.stack(ds)
+
+    monkeypatch.setattr(ops, "LayerStack", FakeStack)
     monkeypatch.setattr(ops, "CsrPlan", FakePlan)
     monkeypatch.setattr(ops, "aggregate", aggregate)
     monkeypatch.setattr(ops, "aggregate_backward", aggregate_backward)
@@ -173,6 +194,17 @@ def test_swapped_model_reproduces_reference_forward(reference_setup, monkeypatch
     # side effects the model / callers read back
     assert mine.reasoning.local_entity_emb.shape == model.reasoning.local_entity_emb.shape
     assert len(mine.reasoning.possible_cand) == args["num_iter"] * args["num_gnn"]
+    # the reference's loop (rearev.py:208-210) was served by ONE whole-iteration run per iteration: the run-ahead
+    # sequence of the last iteration was consumed to its end without falling back to per-layer calls
+    from gnnrag_amd import ops
+    assert ops.LayerStack.calls == args["num_iter"]
+    assert mine.reasoning._ahead is not None and mine.reasoning.local_entity_emb is mine.reasoning._ahead["emb"][-1]
+    # and with the run-ahead switched off the per-layer path gives the same result
+    plain = install.swap(copy.deepcopy(model), args)
+    plain.reasoning.use_stack = False
+    with torch.no_grad():
+        _, pred2, dist2, _ = plain(batch[:-1])
+    assert torch.equal(pred2, pred) and torch.equal(dist2, dist) and ops.LayerStack.calls == args["num_iter"]
 
 
 def test_unmodified_evaluator_reports_identical_metrics(reference_setup, monkeypatch):

@@ -619,3 +619,56 @@ def test_relation_tables_bf16x3_w_resident_kernel(dev, B, R, used, I, N):
     scale = max(1.0, np.abs(want).max())
     assert np.abs(P32 - want).max() <= TOL_INTERNAL * scale
     assert np.abs(Pb3 - want).max() <= TOL_INTERNAL * scale
+
+
+@pytest.mark.parametrize("cfgname", ["tiny50", "mid"])
+def test_whole_iteration_call_and_graph_replay_are_bit_identical(dev, cfgname):
+    """f-3: the L layer calls of a ReaRev iteration as ONE library call (gnnrag_reason_stack, run ahead by the module's
+    step-0 call) and as a replayed hipGraph (gnnrag_reason_stack_capture) reproduce the per-layer calls bit for bit -
+    every layer's h / score / dist, over T iterations with carried node state and changing instructions."""
+    from gnnrag_amd import ops, stack, synth
+    if cfgname == "mid":
+        cfg = synth.GraphConfig(name="mid", B=4, N=2000, E=10000, R=600, D=200, I=2, L=3, T=3, seed=21)
+    else:
+        cfg = synth.GraphConfig(**{**synth.CONFIGS["tiny50"].__dict__, "T": 3})
+    batch = synth.make_batch(cfg)
+    feats = synth.make_features(cfg)
+    params = synth.make_layer_params(cfg)
+    devin = stack.DeviceInputs(batch, feats, dev)
+    outs = {}
+    for mode in ("per_layer", "stack"):
+        layer = stack.build_layer(cfg, batch, params, dev)
+        layer.use_stack = mode == "stack"
+        stack.init_reason(layer, batch, devin, devin.h0)
+        _, rec = stack.run_layers(layer, cfg, devin, record=True)
+        outs[mode] = rec
+        if mode == "stack":
+            assert layer._stack is not None and layer._ahead is not None          # the run-ahead path really ran
+    for k in ("h", "score", "dist"):
+        for a, b in zip(outs["per_layer"][k], outs["stack"][k]):
+            assert np.array_equal(a, b), k
+    # graph replay over fixed buffers: node state carried in h[L-1], instructions rewritten in place
+    layer = stack.build_layer(cfg, batch, params, dev)
+    stack.init_reason(layer, batch, devin, devin.h0)
+    layers = []
+    for j in range(cfg.L):
+        rl, e2e = getattr(layer, "rel_linear%d" % j), getattr(layer, "e2e_linear%d" % j)
+        pos = getattr(layer, "pos_emb%d" % j).weight if cfg.pos_emb else None
+        pos_inv = getattr(layer, "pos_emb_inv%d" % j).weight if cfg.pos_emb else None
+        layers.append((rl.weight, rl.bias, e2e.weight, e2e.bias, pos, pos_inv))
+    with torch.no_grad():
+        st = ops.LayerStack(layer.plan, devin.rel_features, devin.rel_features_inv, layers, layer.score_func.weight,
+                            layer.score_func.bias, layer.local_entity_mask, cfg.I)
+        st.run(devin.h0, devin.seed_dist, devin.ins[0])                           # eager once (launch attributes)
+        ins_buf = devin.ins[0].clone()
+        st.capture(devin.h0, devin.seed_dist, ins_buf)
+        c = 0
+        for t in range(cfg.T):
+            ins_buf.copy_(devin.ins[t])
+            h, score, dist = st.replay()
+            for j in range(cfg.L):
+                assert np.array_equal(h[j].cpu().numpy(), outs["per_layer"]["h"][c])
+                assert np.array_equal(dist[j].cpu().numpy(), outs["per_layer"]["dist"][c])
+                assert np.array_equal(score[j].cpu().numpy(), outs["per_layer"]["score"][c])
+                c += 1
+        st.release_graph()
