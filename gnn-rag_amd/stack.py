@@ -91,3 +91,26 @@ def run_stack(batch, feats: dict, params: dict, device, *, use_type_layer=False,
     _, rec = run_layers(layer, cfg, dev, record=True)
     out.update(rec)
     return out
+
+
+@torch.no_grad()
+def run_rearev_loop(type_layer, reasoning, reforms, *, local_entity, query_entities, edge_tuple, seed_dist,
+                    rel_features, rel_features_inv, instructions, num_iter: int):
+    """The reasoning part of ``ReaRev.forward`` (rearev.py:163-243) on built modules, with the tensors the encoders
+    hand over (relation features, the initial instructions [B, I, D]) as inputs: TypeLayer start (``get_ent_init``,
+    :79-88), ``init_reason`` (:147-153), ``num_iter`` x (``num_gnn`` layer calls, then one QueryReform per
+    instruction: :206-221).  Nothing is fed back from outside between the calls.  Returns (pred, pred_dist)."""
+    h0 = type_layer(local_entity=local_entity, edge_list=edge_tuple, rel_features=rel_features)
+    reasoning.init_reason(local_entity=local_entity, kb_adj_mat=edge_tuple, local_entity_emb=h0,
+                          rel_features=rel_features, rel_features_inv=rel_features_inv, query_entities=query_entities)
+    ins = [instructions[:, j].unsqueeze(1) for j in range(instructions.shape[1])]      # rearev.py:194-196
+    dist = seed_dist
+    for _ in range(num_iter):
+        relation_ins = torch.cat(ins, dim=1)                                          # :207
+        dist = seed_dist                                                              # :208
+        for j in range(reasoning.num_gnn):
+            dist, global_rep = reasoning(dist, relation_ins, step=j)                  # :209-210
+        for j, reform in enumerate(reforms):                                          # :217-221
+            q = reform(ins[j].squeeze(1), global_rep, query_entities, local_entity)
+            ins[j] = q.unsqueeze(1)
+    return torch.max(dist, dim=1)[1], dist                                            # :236-237

@@ -127,3 +127,72 @@ def test_typelayer_grad_oracle_matches_reference_autograd():
                           ("kb_self_linear.bias", g_T.sum(0))):
             want = zg[tag + name]
             np.testing.assert_allclose(got, want, rtol=0, atol=2e-4 * max(np.abs(want).max(), 1e-3), err_msg=name)
+
+
+def test_eval_tail_restatement_reproduces_the_reference_info_file():
+    """oracle/eval_tail.py (candidate filter, stable sort, top-p cut, f1_and_hits, the .info record) fed with the
+    pred_dist the LIVE reference computed reproduces every line the reference's Evaluator wrote, byte for byte
+    (tests/golden/rearev_closed_loop.npz, made by make_golden_e2e.py)."""
+    import json
+    import oracle.eval_tail as oe
+    z = np.load(os.path.join(GOLDEN, "rearev_closed_loop.npz"))
+    eps, N, T = float(z["eps"]), int(z["max_local_entity"]), int(z["T"])
+    ignore_prob = (1 - eps) / N
+    id2entity = {i: str(s) for i, s in enumerate(z["id2entity"])}
+    pad = len(id2entity)
+    lines = [str(l) for l in z["info"]]
+    qi = 0
+    for k in range(int(z["n_batches"])):
+        g = lambda name: z["b%d.%s" % (k, name)]
+        answers = json.loads(str(g("answers")))
+        probs, cands, seeds = g("pred_dist"), g("local_entity"), g("query_entities")
+        for b in range(probs.shape[0]):
+            kept, cut = oe.select(probs[b].tolist(), cands[b].tolist(), seeds[b].tolist(), pad, ignore_prob, eps)
+            # the reference hands f1_and_hits EVERY kept candidate; it cuts the list itself
+            cand2prob = [(int(cands[b, j]), float(probs[b, j])) for j in kept]
+            question = json.loads(lines[qi])["question"]
+            rec = oe.info_record(question, T, answers[b], cand2prob, id2entity, None, eps)
+            assert json.dumps(rec) == lines[qi]
+            assert len(rec["cand"]) == cut
+            qi += 1
+    assert qi == len(lines)
+
+
+def test_oracle_closed_loop_reproduces_the_reference_forward():
+    """The restatements chained the way ReaRev.forward chains the real modules (TypeLayer -> T x (L layers +
+    QueryReform), rearev.py:163-243), started from the encoder outputs the live reference recorded, reproduce its
+    pred_dist and pred on every batch of the closed-loop fixture - the chain the GPU closed-loop test relies on is
+    pinned end to end on the CPU as well."""
+    import torch
+    import oracle.query_update_torch as oq
+    z = np.load(os.path.join(GOLDEN, "rearev_closed_loop.npz"))
+    D, I, L, T = (int(z[k]) for k in ("D", "I", "L", "T"))
+    p = {k[len("param.reasoning."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param.reasoning.")}
+    tw, tb = (torch.from_numpy(z["param.type_layer.kb_self_linear." + s]) for s in ("weight", "bias"))
+    rf = [{s: torch.from_numpy(z["param.reform%d.%s" % (j, s)]) for s in
+           ("q_ent_attn.weight", "q_ent_attn.bias", "fusion.r.weight", "fusion.g.weight")} for j in range(I)]
+    num_entity = int(z["num_entity"])
+    for k in range(int(z["n_batches"])):
+        g = lambda name: z["b%d.%s" % (k, name)]
+        F = len(g("heads"))
+        et = (g("heads"), g("rels"), g("tails"), g("batch_ids"), np.arange(F), g("weight_list").tolist(),
+              g("weight_rel_list").tolist())
+        local_entity = torch.from_numpy(g("local_entity"))
+        B, N = local_entity.shape
+        relfeat, relfeat_inv = torch.from_numpy(g("rel_features")), torch.from_numpy(g("rel_features_inv"))
+        qe = torch.from_numpy(g("query_entities")).float()
+        seed = torch.from_numpy(g("seed_dist")).float()
+        mask = (local_entity != num_entity).float()
+        h = otorch.type_layer(et, B, N, relfeat, tw, tb, bool(int(z["norm_rel"])))
+        st = otorch.Structure(et, B, N, bool(int(z["normalized_gnn"])))
+        ins = [torch.from_numpy(g("ins0"))[:, j] for j in range(I)]
+        for _ in range(T):
+            rel_ins = torch.stack(ins, dim=1)
+            dist = seed
+            for j in range(L):
+                _, dist, h = otorch.layer_forward(st, h, mask, dist, rel_ins, p, j, relfeat, relfeat_inv,
+                                                  bool(int(z["pos_emb"])))
+            ins = [oq.query_reform(ins[j], h, qe, local_entity, rf[j]["q_ent_attn.weight"], rf[j]["q_ent_attn.bias"],
+                                   rf[j]["fusion.r.weight"], rf[j]["fusion.g.weight"]) for j in range(I)]
+        assert np.abs(dist.numpy() - g("pred_dist")).max() <= 1e-6
+        assert np.array_equal(dist.argmax(1).numpy(), g("pred"))
