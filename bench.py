@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spread-steps", type=int, default=200,
+                    help="extra steps timed one by one after the timed region (step-time spread); 0 = off")
     ap.add_argument("--launch", choices=["eager", "graph"], default="eager",
                     help="eager: one gnnrag_reason_stack call per step; graph: the step captured once as a hipGraph "
                          "(gnnrag_reason_stack_capture) and replayed")
@@ -161,6 +163,21 @@ def main():
         elapsed = float(tmax.item())
     assert torch.isfinite(last).all()
 
+    # step-time spread: `spread_steps` further steps, each bracketed by its own HIP event pair (rank 0's device time)
+    spread = None
+    if args.spread_steps > 0:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+               for _ in range(args.spread_steps)]
+        for a, b in evs:
+            a.record()
+            step()
+            b.record()
+        torch.cuda.synchronize()
+        ts = np.array([a.elapsed_time(b) for a, b in evs])
+        spread = {"n": int(len(ts)), "p05": float(np.percentile(ts, 5)), "p50": float(np.percentile(ts, 50)),
+                  "p95": float(np.percentile(ts, 95)), "max": float(ts.max()), "mean": float(ts.mean()),
+                  "unit": "ms per step, device time between HIP events (rank 0)"}
+
     ms_per_step = elapsed * 1e3 / args.steps
     typed_edges = cfg.B * cfg.E * cfg.L * world
     facts = F * cfg.L * world
@@ -182,6 +199,7 @@ def main():
         # amortised over ONE step (a ReaRev forward runs num_iter steps on the same structure); never `value`
         "value_incl_upload_and_build": world * cfg.B * cfg.E * cfg.L / (elapsed / args.steps + csr_build_ms * 1e-3),
         "dense_math": math_name,
+        "step_ms_spread": spread,
         "launch": ("hipGraph replay of the captured L-layer sequence (+ one D2D copy of h0 per step)"
                    if graph is not None else "eager: one gnnrag_reason_stack call per step"),
     }
@@ -199,6 +217,16 @@ def main():
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
         print(json.dumps(out))
+
+
+def kernel_sources_digest():
+    """sha256 over the HIP sources of the aggregation path (what profiles/pmc_traffic.json is valid for)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("aggregate.hip", "csr_plan.hip", "gnnrag_common.h"):
+        with open(os.path.join(REPO, "gnn-rag_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def _events_ms(fn, reps):
@@ -273,6 +301,7 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
     ba = bytes_agg(cfg, F_g)
 
     def hbm(kernel, dense_ms, seed_ms, extra=None):
+        # a step's T iterations each run 1 layer call on the (sparse) seed prior and L - 1 on dense priors
         avg = (seed_ms + (L - 1) * dense_ms) / L
         ach = ba / (avg * 1e-3) / 1e9
         o = {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -284,16 +313,34 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
              "measured_copy_ceiling_GBps": copy_gbps}
         if extra:
             o.update(extra)
+        o["traffic_source"] = pmc_note
+        if o.get("traffic"):
+            # what the memory system really moved per launch (the fused walk never writes agg): the honest HBM rate
+            o["real_traffic_GBps"] = o["traffic"] / (avg * 1e-3) / 1e9
+            o["real_traffic_frac"] = o["real_traffic_GBps"] / HBM_PEAK_GBPS
+            o["real_traffic_frac_of_copy_ceiling"] = o["real_traffic_GBps"] / copy_gbps
         return o
 
-    pmc = {}
+    # HBM traffic of the aggregation kernels comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read
+    # from inside the process); tools/refresh_profiles.sh stores them in profiles/pmc_traffic.json together with the
+    # digest of the kernel sources they were measured on.  A figure measured on OTHER sources is not reported.
+    pmc, pmc_note = {}, "profiles/pmc_traffic.json absent"
     ppath = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(ppath):
         try:
             pmc = json.load(open(ppath))
-        except Exception:
-            pmc = {}
-    r_fused = hbm("gnnrag_aggregate_fused (k_fact_prior + k_walk_slice<FUSED>: LDS walk over per-question relation-table slices)", ms["aggregate_fused_dense"],
+            cur = kernel_sources_digest()
+            if pmc.get("workload", "C2") != cfg.name:
+                pmc, pmc_note = {}, "pmc_traffic.json was measured on workload %s" % pmc.get("workload", "C2")
+            elif pmc.get("kernel_sources_sha256") != cur:
+                pmc_note = ("STALE: measured on kernel sources %s, current %s - not reported"
+                            % (str(pmc.get("kernel_sources_sha256"))[:12], cur[:12]))
+                pmc = {}
+            else:
+                pmc_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (x2 FETCH correction), commit %s, same kernel sources" % pmc.get("commit", "?")
+        except Exception as e:
+            pmc, pmc_note = {}, "unreadable: %r" % (e,)
+    r_fused = hbm("gnnrag_aggregate_fused: " + ops.WALK_KERNEL_NAMES[ops.aggregate_fused_variant(plan, D)], ms["aggregate_fused_dense"],
                   ms["aggregate_fused_seed"],
                   {"note": "fused walk: e2e_linear is pushed into per-question relation tables, so agg [BN,2I*D] is "
                            "never written; `achieved` still uses the pinned unfused byte count (SURVEY 8d), i.e. it "
@@ -379,7 +426,12 @@ def cpu_baseline_leg(cfg, sample_b):
             "sample": "%d questions of the same %s shape (N=%d, E=%d, D=%d, I=%d, L=%d), torch-CPU restatement of "
                       "the reference op sequence, thread count chosen by a probe, 2 timed passes, median %.2f s/pass; "
                       "structure build %.2f s" % (sub.B, cfg.name, sub.N, sub.E, sub.D, sub.I, sub.L, t, build_s),
-            "seconds_per_pass": t}
+            "seconds_per_pass": t,
+            # the LIVE reference on the same C2 shape, full batch (/root/reference is not on
+            # the GPU box, so it cannot be re-timed here): 11.7 s per 3-layer pass on 8 vCPUs
+            "live_reference_survey": {"seconds_per_pass": 11.7, "typed_edge_layers_per_sec": 1.64e5, "cores": 8,
+                                      "source": "BASELINE.md section 3: reference ReasonGNNLayer, torch 2.10 CPU, "
+                                                "C2 shapes (B=64), survey container"}}
 
 
 if __name__ == "__main__":

@@ -67,7 +67,7 @@ def build_variant(name: str, defines: dict, verbose: bool = False) -> str:
     with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(cc, SOURCES))
     out = os.path.join(LIBDIR, "exp_%s.so" % name)
-    r = subprocess.run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs,
+    r = subprocess.run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-pthread", "-o", out] + objs,
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed (%s):\n%s" % (name, r.stderr[-4000:]))
@@ -98,7 +98,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(cc, SOURCES))
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-pthread", "-o", LIB] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-8000:]))

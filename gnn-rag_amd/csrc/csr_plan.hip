@@ -11,6 +11,9 @@
 // The sort itself is rocPRIM's device radix sort (a plain library op); everything around it
 // (record gather, row pointers, heavy-row list) is hand written.  All of it is HBM-bound
 // integer work: coalesced 4/8-byte streams, no atomics except the heavy-row append.
+#include <thread>
+#include <vector>
+
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 
@@ -455,6 +458,43 @@ extern "C" int gnnrag_relorder_build(const gnnrag_csr* csr, const int32_t* heads
   GNNRAG_HIP(hipMemcpyAsync(&n, total, sizeof(n), hipMemcpyDeviceToHost, stream));
   GNNRAG_HIP(hipStreamSynchronize(stream));
   out->n_chunks = n;
+  return 0;
+}
+
+// Host helper of the boundary: the reference's tuple holds int64 ids (dataset_load.py:527), the structure int32.
+// Narrows the three arrays into one [3, F] int32 block with a few threads and checks on the way that every id
+// fits (numpy's astype + three max passes cost 18 ms per C5 batch of 7 M facts - more than the GPU step).
+extern "C" int gnnrag_narrow_tuple(const int64_t* heads, const int64_t* rels, const int64_t* tails, int64_t F,
+                                   int32_t* out, int32_t nthreads) {
+  if (F < 0 || (F > 0 && (!heads || !rels || !tails || !out))) return GNNRAG_E_BADARG;
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 16) nthreads = 16;
+  if (F < (1 << 16)) nthreads = 1;
+  const int64_t* src[3] = {heads, rels, tails};
+  std::vector<int> bad((size_t)nthreads, 0);
+  auto work = [&](int t) {
+    const int64_t lo = F * t / nthreads, hi = F * (t + 1) / nthreads;
+    uint64_t acc = 0;
+    for (int a = 0; a < 3; ++a) {
+      const int64_t* s = src[a];
+      int32_t* d = out + (size_t)a * F;
+      for (int64_t i = lo; i < hi; ++i) {
+        const int64_t v = s[i];
+        acc |= (uint64_t)v;
+        d[i] = (int32_t)v;
+      }
+    }
+    bad[t] = (acc >> 31) != 0;        // negative or >= 2^31 somewhere
+  };
+  if (nthreads == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
+  }
+  for (int t = 0; t < nthreads; ++t)
+    if (bad[t]) return GNNRAG_E_TUPLE;
   return 0;
 }
 

@@ -61,6 +61,18 @@ def _chk(t: torch.Tensor, name: str, dtype=torch.float32, shape=None) -> torch.T
     return t
 
 
+_stage_buf = {"t": None}
+
+
+def _pinned_stage(n: int) -> torch.Tensor:
+    """Pinned int32 staging block of at least n elements (grown geometrically, reused across batches)."""
+    t = _stage_buf["t"]
+    if t is None or t.numel() < n:
+        t = torch.empty(max(n, 1 << 20, 0 if t is None else 2 * t.numel()), dtype=torch.int32, pin_memory=True)
+        _stage_buf["t"] = t
+    return t
+
+
 def _on_plan_device(plan: "CsrPlan", t: torch.Tensor, name: str) -> None:
     """The structure's raw device pointers are only valid on the GPU it was built on."""
     if t.device != plan.device and not (t.is_cuda and plan.device.index is None):
@@ -101,16 +113,29 @@ class CsrPlan:
                 and tails.ctypes.data == base[2].ctypes.data and heads.shape == rels.shape == tails.shape == (F,)
                 and heads.strides == rels.strides == tails.strides == (4,)):
             hrt = base                  # the batch builder's own [3,F] int32 block (data/fact_mat.py): no copy
+        elif (F and heads.dtype == rels.dtype == tails.dtype == np.int64 and heads.flags.c_contiguous
+              and rels.flags.c_contiguous and tails.flags.c_contiguous):
+            # the reference's own tuple (int64 arrays): threaded narrowing into a pinned staging block, with the
+            # check that every id fits int32 (ids that wrapped could pass the device-side range check)
+            stage = _pinned_stage(3 * F)
+            rc = lib.gnnrag_narrow_tuple(heads.ctypes.data, rels.ctypes.data, tails.ctypes.data, F, stage.data_ptr(),
+                                         min(8, os.cpu_count() or 1))
+            if rc == _lib.E_TUPLE:
+                raise ValueError("edge tuple out of range: ids must lie in [0, 2^31)")
+            _lib.check(rc, "gnnrag_narrow_tuple")
+            hrt = stage[: 3 * F].view(3, F)
         else:
             for name, a in (("heads", heads), ("rels", rels), ("tails", tails)):
-                # ids that do not fit int32 would wrap when narrowed and could then pass the device-side range
-                # check: one unsigned max per array (negative ids show up as huge values)
-                if F and a.dtype.itemsize > 4 and int(a.view(np.uint64 if a.dtype.itemsize == 8 else a.dtype).max()) >= 2 ** 31:
+                if F and a.dtype.itemsize > 4 and (int(a.max()) >= 2 ** 31 or int(a.min()) < 0):
                     raise ValueError("edge tuple out of range: %s holds ids outside [0, 2^31)" % name)
             hrt = np.empty((3, max(F, 1)), dtype=np.int32)
             hrt[0, :F], hrt[1, :F], hrt[2, :F] = heads, rels, tails
         with torch.cuda.device(self.device):
-            self._hrt = torch.from_numpy(hrt).to(self.device, non_blocking=False)   # ONE int32 upload
+            if isinstance(hrt, np.ndarray):
+                self._hrt = torch.from_numpy(hrt).to(self.device, non_blocking=False)   # ONE int32 upload
+            else:
+                self._hrt = hrt.to(self.device, non_blocking=True)                      # from the pinned block
+                torch.cuda.current_stream().synchronize()                               # the block is reused next batch
             nbytes = lib.gnnrag_csr_bytes(F, B, N, R1, 0, 0)
             sbytes = lib.gnnrag_csr_scratch_bytes(F, B, N, R1)
             self._mem = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)

@@ -100,6 +100,12 @@ int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const int32_t* t
                      void* csr_mem, size_t csr_bytes, void* scratch, size_t scratch_bytes,
                      gnnrag_csr* out, gnnrag_stream_t stream);
 
+/* HOST helper (no device work): narrows the batch tuple's int64 id arrays (dataset_load.py:527) into one [3, F]
+ * int32 block (heads, rels, tails) with up to `nthreads` threads and checks that every id lies in [0, 2^31):
+ * GNNRAG_E_TUPLE otherwise.  `out` is host memory (pinned memory makes the following upload faster). */
+int gnnrag_narrow_tuple(const int64_t* heads, const int64_t* rels, const int64_t* tails, int64_t F,
+                        int32_t* out, int32_t nthreads);
+
 /* Permutes a per-fact weight array of the caller's tuple into the structure's sorted order for
  * both directions: out_d[i] = w[perm_d[i]] (squared if square != 0).  Lets a binding attach
  * weight_list / weight_rel_list lazily (only when normalized_gnn / norm_rel ask for them). */

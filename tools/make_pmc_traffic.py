@@ -21,7 +21,7 @@ def per_kernel(path, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
-def main(fetch_db, write_db, out):
+def main(fetch_db, write_db, out, workload="C2"):
     fetch, nf = per_kernel(fetch_db, "FETCH_SIZE")
     write, _ = per_kernel(write_db, "WRITE_SIZE")
 
@@ -30,9 +30,22 @@ def main(fetch_db, write_db, out):
         w = sum(v for k, v in write.items() if pred(k)) * 1024.0
         return f, w
 
-    res = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on tools/prof_ops.py (C2, dense and seed priors alternate)",
+    import os
+    import subprocess
+    import sys as _sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _sys.path.insert(0, repo)
+    import bench
+    try:
+        commit = subprocess.run(["git", "-C", repo, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:
+        commit = ""
+    res = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on tools/prof_ops.py (%s, dense and seed priors alternate)" % workload,
+           "workload": workload, "commit": commit or os.environ.get("GNNRAG_COMMIT", "unknown (no .git on the GPU box)"),
+           "kernel_sources_sha256": bench.kernel_sources_digest(),
            "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests at 64 B)"}
-    f, w = group(lambda k: "k_walk_slice" in k or "k_fact_prior" in k)
+    f, w = group(lambda k: "k_walk_slice" in k or "k_fact_prior" in k or ("k_walk_light" in k and "ILi2E" in k)
+                 or ("k_heavy" in k and "ILi2E" in k))
     res.update(aggregate_fused_fetch_bytes_raw=f, aggregate_fused_write_bytes=w,
                aggregate_fused_hbm_bytes_per_launch=2 * f + w)
     f, w = group(lambda k: ("k_walk_light" in k or "k_heavy" in k) and "ILi0E" in k)
@@ -44,4 +57,4 @@ def main(fetch_db, write_db, out):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])

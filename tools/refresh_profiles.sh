@@ -1,21 +1,41 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): bench + rocprofv3 kernel stats + the two PMC passes the
-# roofline's `traffic` figure comes from.  Usage: tools/refresh_profiles.sh <tag>   (e.g. r01i)
-# Outputs under gpurun_out/<tag>/ ; copy what should be judged into profiles/.
+# Runs on the GPU box (via gpurun): the default bench, its rocprofv3 kernel stats, the two PMC passes the roofline's
+# `traffic` figure comes from (C2 and C5), and one bench line per other workload (C1, C3, C4, C5, C2fb; C1 / C3 also
+# as hipGraph replays).  Usage: tools/refresh_profiles.sh <tag>   (e.g. r02a)
+# Outputs under gpurun_out/<tag>/ ; copy what should be judged into profiles/ (tools/collect_profiles.py <tag>).
 set -u
 TAG=${1:-rXX}
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
-python bench.py > $OUT/bench_default.log 2>&1
+export GNNRAG_COMMIT=${GNNRAG_COMMIT:-$(cat $R/.commit_stamp 2>/dev/null || echo unknown)}
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
-for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc -o $C -- python $R/tools/prof_ops.py --workload C2 --reps 4 --ops agg,aggf > $OUT/pmc_$C.log 2>&1
+for W in C2 C5; do
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$W -o $C -- python $R/tools/prof_ops.py --workload $W --reps 4 --ops agg,aggf > $OUT/pmc_${W}_$C.log 2>&1
+  done
+  ( cd $R && python tools/make_pmc_traffic.py $(find $OUT/pmc_$W -name 'FETCH_SIZE_results.db' | head -1) $(find $OUT/pmc_$W -name 'WRITE_SIZE_results.db' | head -1) $OUT/pmc_traffic_$W.json $W > $OUT/make_pmc_$W.log 2>&1 )
 done
+cp $OUT/pmc_traffic_C2.json $R/profiles/pmc_traffic.json        # the default bench below reads it (same sources: not stale)
+cd $R
+python bench.py > $OUT/bench_default.log 2>&1
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python $R/bench.py --no-cpu-baseline --spread-steps 0 > $OUT/bench_under_rocprof.log 2>&1
 cd $R
 python tools/rocpd_stats.py $(find $OUT/trace -name 'bench_results.db' | head -1) > $OUT/kernel_stats_bench.txt 2>&1
-python tools/make_pmc_traffic.py $(find $OUT/pmc -name 'FETCH_SIZE_results.db' | head -1) $(find $OUT/pmc -name 'WRITE_SIZE_results.db' | head -1) $OUT/pmc_traffic.json > $OUT/make_pmc.log 2>&1
-find $OUT -name '*.db' -size +20M -delete
-tail -1 $OUT/bench_default.log | cut -c1-400
+for W in C1 C3 C4 C5 C2fb; do
+  cp $OUT/pmc_traffic_$W.json $R/profiles/pmc_traffic.json 2>/dev/null || cp $OUT/pmc_traffic_C2.json $R/profiles/pmc_traffic.json
+  python bench.py --workload $W --no-cpu-baseline --steps 30 > $OUT/bench_$W.log 2>&1
+done
+cp $OUT/pmc_traffic_C2.json $R/profiles/pmc_traffic.json
+for W in C1 C3; do
+  python bench.py --workload $W --no-cpu-baseline --steps 30 --launch graph > $OUT/bench_${W}_graph.log 2>&1
+done
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_C5 -o bench -- python $R/bench.py --workload C5 --no-cpu-baseline --steps 10 --spread-steps 0 > $OUT/bench_C5_under_rocprof.log 2>&1
+cd $R
+python tools/rocpd_stats.py $(find $OUT/trace_C5 -name 'bench_results.db' | head -1) > $OUT/kernel_stats_bench_C5.txt 2>&1
+find $OUT -name '*.db' -delete
+tail -1 $OUT/bench_default.log | cut -c1-300
 head -12 $OUT/kernel_stats_bench.txt
+for W in C1 C3 C4 C5 C2fb C1_graph C3_graph; do echo -n "$W: "; tail -1 $OUT/bench_$W.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4), d['roofline']['kernel'][:60], round(d['roofline']['frac'],3))" 2>&1 | tail -1; done
