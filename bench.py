@@ -62,6 +62,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: every rank owns its own cfg.B questions; strong: ONE global batch of cfg.B questions is "
+                         "split over the ranks by facts (the WebQSP-dev mode of SURVEY.md section 8e)")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="CI only: the multi-rank skeleton on CPU (gloo, the oracle as the per-rank step, tiny batch)")
     ap.add_argument("--spread-steps", type=int, default=200,
                     help="extra steps timed one by one after the timed region (step-time spread); 0 = off")
     ap.add_argument("--launch", choices=["eager", "graph"], default="eager",
@@ -78,6 +83,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if args.dry_run_cpu:
+        return dry_run_cpu(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -98,12 +105,24 @@ def main():
     math_name = ops.MATH_NAMES[ops.get_dense_math()]
 
     cfg = synth.CONFIGS[args.workload]
-    # every rank owns its own questions (weak scaling): same shapes, different seed
-    batch = synth.make_batch(cfg, seed=cfg.seed + 1000 * rank)
-    feats = synth.make_features(cfg, seed=cfg.seed + 1000 * rank)
+    strong = args.scaling == "strong" and world > 1
+    ranges = None
+    if strong:
+        # ONE global batch (same seed on every rank), split by facts: the rank keeps its contiguous question range
+        gcfg = cfg
+        gbatch = synth.make_batch(gcfg)
+        gfeats = synth.make_features(gcfg)
+        batch, feats, ranges = strong_shard(gbatch, gfeats, rank, world)
+        cfg = batch.cfg
+        global_B = gcfg.B
+    else:
+        # every rank owns its own questions (weak scaling): same shapes, different seed
+        batch = synth.make_batch(cfg, seed=cfg.seed + 1000 * rank)
+        feats = synth.make_features(cfg, seed=cfg.seed + 1000 * rank)
+        global_B = cfg.B * world
     params = synth.make_layer_params(cfg)
     F = batch.F
-    F_g = F // cfg.B
+    F_g = max(F // max(cfg.B, 1), 1)
 
     devin = stack.DeviceInputs(batch, feats, dev)
     layer = stack.build_layer(cfg, batch, params, dev)
@@ -140,7 +159,7 @@ def main():
             layer.local_entity_emb = devin.h0
             d, _ = stack.run_layers(layer, cfg, devin)
         if distributed:
-            d = shard.gather_rows(d, cfg.B * world)
+            d = shard.gather_rows(d, global_B, ranges=ranges)
         return d
 
     for _ in range(args.warmup):
@@ -179,14 +198,14 @@ def main():
                   "unit": "ms per step, device time between HIP events (rank 0)"}
 
     ms_per_step = elapsed * 1e3 / args.steps
-    typed_edges = cfg.B * cfg.E * cfg.L * world
-    facts = F * cfg.L * world
+    typed_edges = global_B * cfg.E * cfg.L * cfg.T
+    facts = (F * world if not strong else sum(int(x) for x in strong_facts(ranges, gbatch))) * cfg.L * cfg.T
     value = typed_edges / (elapsed / args.steps)
 
     out = {
         "metric": "kg_edges_aggregated_per_sec", "value": value, "unit": "typed-edge*layers/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "%s: synthetic Freebase-shaped subgraphs, %d nodes / %d typed edges (+%d self loops) "
                                "per question, batch %d per GPU, %d layers, hidden %d, %d instructions"
@@ -197,7 +216,7 @@ def main():
         "csr_build_ms": csr_build_ms, "csr_first_call_ms": csr_first_ms,
         # host-buffer boundary: int64 tuple -> int32 upload over PCIe + device structure build, once per batch,
         # amortised over ONE step (a ReaRev forward runs num_iter steps on the same structure); never `value`
-        "value_incl_upload_and_build": world * cfg.B * cfg.E * cfg.L / (elapsed / args.steps + csr_build_ms * 1e-3),
+        "value_incl_upload_and_build": typed_edges / (elapsed / args.steps + csr_build_ms * 1e-3),
         "dense_math": math_name,
         "step_ms_spread": spread,
         "launch": ("hipGraph replay of the captured L-layer sequence (+ one D2D copy of h0 per step)"
@@ -216,6 +235,86 @@ def main():
         import ctypes
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
+        print(json.dumps(out))
+
+
+def strong_shard(gbatch, gfeats, rank, world):
+    """This rank's contiguous question range of ONE global batch, balanced by facts (shard.shard_ranges)."""
+    from gnnrag_amd import shard, synth
+    cfg = gbatch.cfg
+    ref = (gbatch.local_entity, gbatch.query_entities, gbatch.edge_tuple, np.zeros((cfg.B, 1)), gbatch.seed_dist, None,
+           np.zeros((cfg.B, cfg.N)))
+    ranges = shard.shard_ranges(ref, world, "facts")
+    lo, hi = ranges[rank]
+    sb = shard.shard_batch(ref, rank, world, "facts")
+    sub = synth.Batch(cfg=synth.GraphConfig(**{**cfg.__dict__, "B": hi - lo}), local_entity=sb[0], query_entities=sb[1],
+                      seed_dist=sb[4], edge_tuple=sb[2], num_entity=gbatch.num_entity, n_real=gbatch.n_real[lo:hi])
+    feats = dict(gfeats)
+    feats["h0"] = gfeats["h0"][lo:hi]
+    feats["ins"] = gfeats["ins"][:, lo:hi]
+    return sub, feats, ranges
+
+
+def strong_facts(ranges, gbatch):
+    from gnnrag_amd import shard
+    f = shard.facts_per_question(gbatch.edge_tuple, gbatch.cfg.B)
+    return [f[lo:hi].sum() for lo, hi in ranges]
+
+
+def dry_run_cpu(args, world, rank):
+    """CI skeleton (tests/test_shard_gloo.py): everything of the multi-rank path that is not a kernel - rendezvous,
+    sharding, the all-gather of the scored nodes, barrier-bracketed timing with the MAX over ranks, one JSON line -
+    on CPU over gloo with a tiny workload and the CPU restatement as the per-rank step."""
+    import torch.distributed as dist
+    import gnnrag_amd  # noqa: F401
+    from gnnrag_amd import shard, synth
+    import oracle.rearev_torch_cpu as otorch
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    gcfg = synth.GraphConfig(name="dry", B=6, N=24, E=60, R=5, D=16, I=2, L=2, T=1, seed=9, n_real_min=3)
+    gbatch, gfeats = synth.make_batch(gcfg), synth.make_features(gcfg)
+    params = synth.make_layer_params(gcfg)
+    strong = args.scaling == "strong" and world > 1
+    if strong:
+        batch, feats, ranges = strong_shard(gbatch, gfeats, rank, world)
+        global_B = gcfg.B
+    else:
+        batch, feats, ranges, global_B = gbatch, gfeats, None, gcfg.B * world
+
+    def step():
+        d = torch.from_numpy(otorch.run_stack(batch, feats, params)["dist"][-1])
+        return shard.gather_rows(d, global_B, ranges=ranges) if world > 1 else d
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ok = None
+    if strong:
+        full = otorch.run_stack(gbatch, gfeats, params)["dist"][-1]
+        ok = bool(np.array_equal(last.numpy(), full))
+    out = {"metric": "kg_edges_aggregated_per_sec", "value": global_B * gcfg.E * gcfg.L / (elapsed / args.steps),
+           "unit": "typed-edge*layers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+           "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "dry run on CPU (gloo): NOT a measurement"}, "gathered_matches_unsharded": ok}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
         print(json.dumps(out))
 
 

@@ -28,6 +28,37 @@ def question_range(B: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, hi
 
 
+def balanced_ranges(weights, world: int):
+    """Contiguous shards [lo, hi) of len(weights) questions whose summed weights are as even as a contiguous split
+    allows ("for load balance on real data, shard by cumulative F_g not by count" - WebQSP
+    subgraphs differ by two orders of magnitude in size, and the slowest rank sets the step).  Greedy sweep against
+    the ideal cumulative targets; every rank gets at least one question while questions remain."""
+    w = np.maximum(np.asarray(weights, dtype=np.float64), 0.0) + 1e-9          # empty questions still cost a slot
+    B = len(w)
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    out, lo = [], 0
+    for r in range(world):
+        left = world - r - 1                                                   # ranks after this one
+        if r == world - 1:
+            hi = B
+        else:
+            target = cum[-1] * (r + 1) / world
+            hi = int(np.searchsorted(cum, target, side="left"))
+            # the boundary question goes to the side that leaves the smaller error
+            if hi > lo + 1 and hi <= B and abs(cum[hi - 1] - target) <= abs(cum[hi] - target if hi < len(cum) else np.inf):
+                hi -= 1
+            hi = max(hi, min(lo + 1, B))                                       # at least one question if any are left
+            hi = min(hi, max(B - left, lo))                                    # leave one for each later rank
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def facts_per_question(edge_tuple, B: int) -> np.ndarray:
+    """F_g: facts (typed edges + self loops) of every question of a batch tuple."""
+    return np.bincount(np.asarray(edge_tuple[3]).astype(np.int64), minlength=B)[:B]
+
+
 def shard_edge_tuple(edge_tuple, N: int, lo: int, hi: int):
     """Facts of questions [lo, hi), re-based so the shard is a self-contained batch.
     Facts of one question are contiguous and ``batch_ids`` is non-decreasing
@@ -43,13 +74,25 @@ def shard_edge_tuple(edge_tuple, N: int, lo: int, hi: int):
             bids[a:b] - lo, np.arange(b - a, dtype=np.int64), list(wl[a:b]), list(wrl[a:b]))
 
 
-def shard_batch(batch: tuple, rank: int, world: int) -> tuple:
+def shard_ranges(batch: tuple, world: int, balance: str = "facts"):
+    """The [lo, hi) question range of every rank for one batch: ``balance="facts"`` evens out the facts per rank
+    (every rank derives the same split from the batch tuple it already holds - no communication), ``"count"`` the
+    number of questions."""
+    B = batch[0].shape[0]
+    if balance == "count":
+        return [question_range(B, r, world) for r in range(world)]
+    if balance != "facts":
+        raise ValueError("balance must be 'facts' or 'count'")
+    return balanced_ranges(facts_per_question(batch[2], B), world)
+
+
+def shard_batch(batch: tuple, rank: int, world: int, balance: str = "count") -> tuple:
     """Shards a reference batch tuple (``get_batch`` output, dataset_load.py:613-629):
     ``(local_entity, query_entities, kb_adj_mat, query_text, seed_dist, true_batch_id,
     answer_dist[, answer_lists])``."""
     local_entity = batch[0]
     B, N = local_entity.shape
-    lo, hi = question_range(B, rank, world)
+    lo, hi = shard_ranges(batch, world, balance)[rank]
     out = [batch[0][lo:hi], batch[1][lo:hi], shard_edge_tuple(batch[2], N, lo, hi), batch[3][lo:hi],
            batch[4][lo:hi], batch[5], batch[6][lo:hi]]
     if len(batch) > 7:
@@ -57,16 +100,32 @@ def shard_batch(batch: tuple, rank: int, world: int) -> tuple:
     return tuple(out)
 
 
-def gather_rows(local: torch.Tensor, B: int, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+def gather_rows(local: torch.Tensor, B: int, group: Optional[dist.ProcessGroup] = None,
+                ranges=None) -> torch.Tensor:
     """All-gathers per-question rows ``[b_local, ...]`` of contiguous shards into ``[B, ...]``.
     One collective (``all_gather_into_tensor``; RCCL on GPUs, gloo in the CPU tests);
-    shards are padded to the largest shard so every rank contributes the same count."""
+    shards are padded to the largest shard so every rank contributes the same count.  ``ranges``: the [lo, hi) of
+    every rank (``shard_ranges``) when the split is not the even one."""
     if not dist.is_available() or not dist.is_initialized():
         if local.shape[0] != B:
             raise ValueError("not distributed, but the local shard is not the whole batch")
         return local
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if ranges is not None:
+        lo, hi = ranges[rank]
+        if local.shape[0] != hi - lo:
+            raise ValueError("rank %d holds %d rows, expected %d" % (rank, local.shape[0], hi - lo))
+        rows = max(h - l for l, h in ranges)
+        send = local.contiguous()
+        if hi - lo != rows:
+            send = local.new_zeros((rows,) + tuple(local.shape[1:]))
+            send[: hi - lo] = local
+        recv = local.new_empty((world * rows,) + tuple(local.shape[1:]))
+        dist.all_gather_into_tensor(recv, send, group=group)
+        if all(h - l == rows for l, h in ranges):
+            return recv
+        return torch.cat([recv[r * rows: r * rows + (h - l)] for r, (l, h) in enumerate(ranges)], dim=0)
     lo, hi = question_range(B, rank, world)
     if local.shape[0] != hi - lo:
         raise ValueError("rank %d holds %d rows, expected %d" % (rank, local.shape[0], hi - lo))
@@ -88,14 +147,15 @@ def gather_rows(local: torch.Tensor, B: int, group: Optional[dist.ProcessGroup] 
     return torch.cat(parts, dim=0)
 
 
-def shard_model(model, group: Optional[dist.ProcessGroup] = None):
+def shard_model(model, group: Optional[dist.ProcessGroup] = None, balance: str = "facts"):
     """Question-sharded evaluation of a reference model (``ReaRev`` / ``NSM``): ``model(batch)`` then runs
     this rank's contiguous question range only and all-gathers the scored nodes, so that every rank hands
     the full ``pred_dist [B, N]`` to the unchanged ``Evaluator`` (BASELINE config "dev set batched across
     8 GPUs, question-sharded, RCCL gather").  Returns the same 4-tuple as ``Model.forward``
     (rearev.py:243): the loss is the batch mean (per-rank means weighted by their question counts,
     all-reduced), ``pred`` the argmax of the gathered distribution.  Training calls, single-process runs and
-    batches with fewer questions than ranks pass through unchanged."""
+    batches with fewer questions than ranks pass through unchanged.  ``balance``: "facts" splits the batch so that
+    every rank gets about the same number of facts (the slowest rank sets the step), "count" by question count."""
     inner = model.forward
 
     def forward(batch, training=False):
@@ -106,9 +166,10 @@ def shard_model(model, group: Optional[dist.ProcessGroup] = None):
         if world == 1 or B < world:
             return inner(batch, training=training)
         rank = dist.get_rank(group)
-        lo, hi = question_range(B, rank, world)
-        loss, _, pred_dist, tp_list = inner(shard_batch(batch, rank, world), training=training)
-        full = gather_rows(pred_dist, B, group)
+        ranges = shard_ranges(batch, world, balance)
+        lo, hi = ranges[rank]
+        loss, _, pred_dist, tp_list = inner(shard_batch(batch, rank, world, balance), training=training)
+        full = gather_rows(pred_dist, B, group, ranges=ranges)
         total = loss.detach().float().reshape(1) * float(hi - lo)       # calc_loss_label divides by the local batch size
         dist.all_reduce(total, group=group)
         return total[0] / B, torch.max(full, dim=1)[1], full, tp_list

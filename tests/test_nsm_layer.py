@@ -8,7 +8,9 @@ import torch
 
 from conftest import GOLDEN
 
-CASES = {"plain": (False, False), "kb_norm": (True, True)}       # tag -> (reason_kb, normalized_gnn)
+# tag -> (reason_kb, normalized_gnn, direction): NSMLayer walks head -> tail, NSMLayer_back tail -> head
+CASES = {"plain": (False, False, 0), "kb_norm": (True, True, 0), "back_plain": (False, False, 1),
+         "back_kb_norm": (True, True, 1)}
 
 
 def _load():
@@ -24,9 +26,10 @@ def _load():
 def test_nsm_oracle_matches_reference(tag):
     import oracle.nsm_layer as on
     z, et, params = _load()
-    reason_kb, normalized = CASES[tag]
-    got = on.run(et, int(z["B"]), int(z["N"]), z["local_entity"], int(z["num_entity"]), z["h0"], z["rel_features"],
-                 z["ins"], z["seed_dist"], params, reason_kb=reason_kb, normalized_gnn=normalized,
+    reason_kb, normalized, direction = CASES[tag]
+    relfeat = z["rel_features_inv"] if direction else z["rel_features"]
+    got = on.run(et, int(z["B"]), int(z["N"]), z["local_entity"], int(z["num_entity"]), z["h0"], relfeat,
+                 z["ins"], z["seed_dist"], params, reason_kb=reason_kb, normalized_gnn=normalized, direction=direction,
                  Gd=z["Gd"], Gh=z["Gh"])
     for c in range(int(z["L"])):
         assert np.abs(got["dist"][c] - z[tag + ".ref.dist"][c]).max() <= 2e-6
@@ -41,20 +44,24 @@ def test_nsm_oracle_matches_reference(tag):
 @pytest.mark.parametrize("tag", list(CASES))
 def test_nsm_module_matches_reference_fixture(tag, grad):
     import gnnrag_amd  # noqa: F401
-    from gnnrag_amd.modules.kg_reasoning.nsm_gnn import NSMLayer
+    from gnnrag_amd.modules.kg_reasoning.nsm_gnn import NSMLayer, NSMLayer_back
     dev = torch.device("cuda", 0)
     z, et, params = _load()
-    reason_kb, normalized = CASES[tag]
+    reason_kb, normalized, direction = CASES[tag]
     B, N, D, L = int(z["B"]), int(z["N"]), int(z["D"]), int(z["L"])
     args = dict(use_cuda=True, normalized_gnn=normalized, num_step=L, reason_kb=reason_kb, linear_dropout=0.0)
-    layer = NSMLayer(args, int(z["num_entity"]), int(z["R1"]) - 1, D)
+    layer = (NSMLayer_back if direction else NSMLayer)(args, int(z["num_entity"]), int(z["R1"]) - 1, D)
     layer.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
     layer = layer.to(dev)
     layer.train(grad)
-    X = {k: torch.tensor(z[k], device=dev, requires_grad=grad) for k in ("h0", "rel_features", "ins")}
+    X = {k: torch.tensor(z[k], device=dev, requires_grad=grad) for k in ("h0", "ins")}
+    X["rel_features"] = torch.tensor(z["rel_features_inv"] if direction else z["rel_features"], device=dev,
+                                     requires_grad=grad)
     with torch.set_grad_enabled(grad):
         layer.init_reason(local_entity=torch.from_numpy(z["local_entity"]).to(dev), kb_adj_mat=et,
                           local_entity_emb=X["h0"], rel_features=X["rel_features"])
+        if direction:
+            layer.rel_features_inv = X["rel_features"]          # as the reference's caller has to (nsm_gnn.py:122)
         dist = torch.from_numpy(z["seed_dist"]).float().to(dev)
         loss = 0.0
         for j in range(L):

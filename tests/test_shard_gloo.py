@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, B, q):
+def _worker(rank, world, port, B, q, balance="count"):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -41,8 +41,9 @@ def _worker(rank, world, port, B, q):
         full = otorch.run_stack(batch, feats, params)["dist"][-1]
         ref_batch = (batch.local_entity, batch.query_entities, batch.edge_tuple, np.zeros((B, 1)),
                      batch.seed_dist, None, np.zeros((B, cfg.N)))
-        lo, hi = shard.question_range(B, rank, world)
-        sb = shard.shard_batch(ref_batch, rank, world)
+        ranges = shard.shard_ranges(ref_batch, world, balance)
+        lo, hi = ranges[rank]
+        sb = shard.shard_batch(ref_batch, rank, world, balance)
         sub = synth.Batch(cfg=synth.GraphConfig(**{**cfg.__dict__, "B": hi - lo}), local_entity=sb[0],
                           query_entities=sb[1], seed_dist=sb[4], edge_tuple=sb[2],
                           num_entity=batch.num_entity, n_real=batch.n_real[lo:hi])
@@ -50,19 +51,19 @@ def _worker(rank, world, port, B, q):
         sfe["h0"] = feats["h0"][lo:hi]
         sfe["ins"] = feats["ins"][:, lo:hi]
         local = otorch.run_stack(sub, sfe, params)["dist"][-1]
-        gathered = shard.gather_rows(torch.from_numpy(local), B).numpy()
+        gathered = shard.gather_rows(torch.from_numpy(local), B, ranges=None if balance == "count" else ranges).numpy()
         ok = gathered.shape == full.shape and np.array_equal(gathered, full)
         q.put((rank, bool(ok), float(np.abs(gathered - full).max()) if gathered.shape == full.shape else -1.0))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("B", [6, 5])      # even split and ragged split (padding path)
-def test_shard_and_gather_world2(B):
+@pytest.mark.parametrize("B,balance", [(6, "count"), (5, "count"), (7, "facts")])   # even / ragged / fact-balanced split
+def test_shard_and_gather_world2(B, balance):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, q, balance)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
@@ -82,6 +83,64 @@ def test_question_range_partition():
             assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
             sizes = [h - l for l, h in rs]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_balanced_ranges_properties():
+    """Fact-balanced contiguous split: a partition of [0, B), every rank non-empty while
+    questions remain, never worse than the even-count split by more than the largest question."""
+    from gnnrag_amd import shard
+    rng = np.random.default_rng(3)
+    for _ in range(500):
+        B, world = int(rng.integers(1, 60)), int(rng.integers(1, 9))
+        w = rng.integers(0, 3000, B) * (rng.random(B) < 0.8)
+        r = shard.balanced_ranges(w, world)
+        assert len(r) == world and r[0][0] == 0 and r[-1][1] == B
+        assert all(a[1] == b[0] and a[0] <= a[1] for a, b in zip(r, r[1:]))
+        if B >= world:
+            assert all(h > l for l, h in r)
+        load = max(int(w[l:h].sum()) for l, h in r)
+        even = max(int(w[l:h].sum()) for l, h in (shard.question_range(B, k, world) for k in range(world)))
+        assert load <= even + int(w.max()), (w, world, r)
+    # WebQSP-like: a few huge subgraphs among many small ones
+    w = np.array([40, 35, 9000, 60, 20, 7000, 30, 45, 50, 8000, 25, 30])
+    r = shard.balanced_ranges(w, 4)
+    assert max(w[l:h].sum() for l, h in r) == 9000 + 75 or max(w[l:h].sum() for l, h in r) <= 9200
+
+
+def _bench_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    import contextlib
+    import io
+    import json
+    import bench
+    buf = io.StringIO()
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "3", "--warmup", "1", "--dry-run-cpu", "--scaling", "strong"]
+    with contextlib.redirect_stdout(buf):
+        bench.main()
+    lines = [l for l in buf.getvalue().splitlines() if l.startswith("{")]
+    q.put((rank, json.loads(lines[-1]) if lines else None))
+
+
+def test_bench_distributed_skeleton_world2():
+    """bench.py's multi-rank skeleton without GPUs (--dry-run-cpu: gloo, the CPU restatement as the per-rank step):
+    rendezvous from the launcher's environment, strong-scaling split of ONE global batch by facts, the all-gather,
+    the barrier-bracketed timing and its MAX over ranks, and exactly one JSON line from rank 0."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1] is None and res[0] is not None
+    out = res[0]
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["gathered_matches_unsharded"] is True
 
 
 REF = "/root/reference/gnn"
