@@ -355,11 +355,23 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
     with torch.no_grad():
         layer.local_entity_emb = devin.h0
         dense, _ = layer(devin.seed_dist, devin.ins[0], step=0)      # a realistic dense prior
+        P = layer._inference_params()
     seed = devin.seed_dist
-    h = devin.h0.reshape(B * N, D)
-    rl, e2e = layer.rel_linear1, layer.e2e_linear1
-    sf = layer.score_func
-    ins = devin.ins[0]
+    # the operands as the module hands them to the kernels: hidden sizes that are not a multiple of 4 (D = 50 of the
+    # released checkpoints) are zero-padded to the next multiple of 8 inside the module (byte / flop counts below keep
+    # the NOMINAL D: padding is this implementation's business)
+    Dk = P["Dp"]
+    padc = (lambda t: t if Dk == D else torch.nn.functional.pad(t, (0, Dk - D)).contiguous())
+    h = padc(devin.h0.reshape(B * N, D))
+    W_rel, b_rel, W_e2e, b_e2e = P["layers"][1][:4]
+
+    class _Lin:                                  # parameter views in the shapes the kernels get
+        def __init__(self, w, b):
+            self.weight, self.bias = w, b
+    rl, e2e = _Lin(W_rel, b_rel), _Lin(W_e2e, b_e2e)
+    sf = _Lin(P["w_score"], P["b_score"])
+    ins = padc(devin.ins[0])
+    relf, relf_inv = P["relfeat"], P["relfeat_inv"]
     box = {}
 
     def t(fn):
@@ -367,8 +379,8 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
         return float(np.mean(_events_ms(fn, reps)))
 
     ms = {}
-    ms["rel_transform_x2"] = t(lambda: (box.__setitem__("Tf", ops.linear(devin.rel_features, rl.weight, rl.bias)),
-                                        box.__setitem__("Ti", ops.linear(devin.rel_features_inv, rl.weight, rl.bias))))
+    ms["rel_transform_x2"] = t(lambda: (box.__setitem__("Tf", ops.linear(relf, rl.weight, rl.bias)),
+                                        box.__setitem__("Ti", ops.linear(relf_inv, rl.weight, rl.bias))))
     Tf, Ti = box["Tf"], box["Ti"]
     ms["aggregate_dense"] = t(lambda: box.__setitem__("agg", ops.aggregate(plan, dense, ins, Tf, Ti)))
     ms["aggregate_seed"] = t(lambda: ops.aggregate(plan, seed, ins, Tf, Ti))
@@ -395,8 +407,8 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
     tc = _events_ms(lambda: ops.stream_copy(src, dst), 10)
     copy_gbps = 2 * n * 4 / (np.median(tc) * 1e-3) / 1e9
 
-    fused = layer.path == 2 or (layer.path == 0 and 2.0 * plan.rel_total * I * D * D + B * N * D * D
-                                < 0.8 * B * N * (2 * I + 1) * D * D)
+    fused = layer.path == 2 or (layer.path == 0 and 2.0 * plan.rel_total * I * Dk * Dk + B * N * Dk * Dk
+                                < 0.8 * B * N * (2 * I + 1) * Dk * Dk)
     ba = bytes_agg(cfg, F_g)
 
     def hbm(kernel, dense_ms, seed_ms, extra=None):
@@ -439,7 +451,8 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
                 pmc_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (x2 FETCH correction), commit %s, same kernel sources" % pmc.get("commit", "?")
         except Exception as e:
             pmc, pmc_note = {}, "unreadable: %r" % (e,)
-    r_fused = hbm("gnnrag_aggregate_fused: " + ops.WALK_KERNEL_NAMES[ops.aggregate_fused_variant(plan, D)], ms["aggregate_fused_dense"],
+    r_fused = hbm("gnnrag_aggregate_fused: " + ops.WALK_KERNEL_NAMES[ops.aggregate_fused_variant(plan, Dk)] +
+                  ("" if Dk == D else " [hidden size %d zero-padded to %d]" % (D, Dk)), ms["aggregate_fused_dense"],
                   ms["aggregate_fused_seed"],
                   {"note": "fused walk: e2e_linear is pushed into per-question relation tables, so agg [BN,2I*D] is "
                            "never written; `achieved` still uses the pinned unfused byte count (SURVEY 8d), i.e. it "

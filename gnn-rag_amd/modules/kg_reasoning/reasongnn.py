@@ -49,6 +49,13 @@ class ReasonGNNLayer(BaseGNNLayer):
         self.use_stack = os.environ.get("GNNRAG_STACK", "1") != "0"
         self._stack = None
         self._ahead = None
+        # Hidden sizes that are not a multiple of 4 (the released checkpoints use entity_dim 50) would send every
+        # kernel down its scalar path and the walk to the table-row gather.  The inference path therefore works on
+        # ZERO-PADDED copies (D -> next multiple of 8): padded parameter rows / columns are zero, so the extra
+        # columns of every intermediate stay exactly 0 and the first D columns are what the unpadded computation
+        # gives; the node state is kept padded between calls and handed to the caller as a [:, :, :D] view.
+        self.pad_dim = os.environ.get("GNNRAG_PAD_DIM", "1") != "0"
+        self._padded = None
 
     def init_layers(self, args):
         D = self.entity_dim
@@ -84,6 +91,8 @@ class ReasonGNNLayer(BaseGNNLayer):
         self.build_matrix()
         self.query_entities = query_entities
         self._stack = None             # bound to this batch's structure and relation features on first use
+        self._stack_key = None
+        self._padded = None            # padded copies hold this batch's relation features
         self._ahead = None
 
     def forward(self, current_dist, relational_ins, step=0, return_score=False):
@@ -97,43 +106,95 @@ class ReasonGNNLayer(BaseGNNLayer):
                 self.local_entity_emb = h_out
                 self.possible_cand.append(self.local_entity_mask)
                 return (score_tp, new_dist) if return_score else (new_dist, h_out)
-        rel_linear = getattr(self, "rel_linear" + str(step))
-        e2e_linear = getattr(self, "e2e_linear" + str(step))
-        pos = pos_inv = None
-        if self.use_posemb:
-            pos = getattr(self, "pos_emb" + str(step)).weight
-            pos_inv = getattr(self, "pos_emb_inv" + str(step)).weight
-        B, N, D = self.batch_size, self.max_local_entity, self.entity_dim
+        P = self._inference_params()
+        W_rel, b_rel, W_e2e, b_e2e, pos, pos_inv = P["layers"][step]
         h_out, score_tp, new_dist = ops.reason_layer(
-            self.plan, self.local_entity_emb.detach().float(), current_dist.detach().float(),
-            relational_ins.detach().float(), self.rel_features.detach(), self.rel_features_inv.detach(),
-            rel_linear.weight, rel_linear.bias, e2e_linear.weight, e2e_linear.bias,
-            self.score_func.weight, self.score_func.bias, self.local_entity_mask,
-            pos=pos, pos_inv=pos_inv, ws=self._ws, path=self.path)
-        self.local_entity_emb = h_out
+            self.plan, self._state_in(P), current_dist.detach().float(), self._pad_last(relational_ins.detach().float(), P),
+            P["relfeat"], P["relfeat_inv"], W_rel, b_rel, W_e2e, b_e2e, P["w_score"], P["b_score"],
+            self.local_entity_mask, pos=pos, pos_inv=pos_inv, ws=self._ws, path=self.path)
+        self.local_entity_emb = self._state_out(h_out, P)
         self.possible_cand.append(self.local_entity_mask)
         if return_score:
             return score_tp, new_dist
         return new_dist, self.local_entity_emb
 
+    # ---- zero-padded inference copies (hidden size not a multiple of 4) ------------------------------------
+    def _inference_params(self):
+        """Parameters and relation features as the kernels get them: the module's own tensors, or - when the hidden
+        size is padded - zero-padded copies, rebuilt when a parameter changes (checked by storage and version)."""
+        D, I = self.entity_dim, self.num_ins
+        Dp = D if (D % 4 == 0 or not self.pad_dim) else (D + 7) // 8 * 8
+        mods = [(getattr(self, "rel_linear" + str(j)), getattr(self, "e2e_linear" + str(j))) for j in range(self.num_gnn)]
+        src = [self.score_func.weight, self.score_func.bias]
+        for rl, e2e in mods:
+            src += [rl.weight, rl.bias, e2e.weight, e2e.bias]
+        if self.use_posemb:
+            for j in range(self.num_gnn):
+                src += [getattr(self, "pos_emb" + str(j)).weight, getattr(self, "pos_emb_inv" + str(j)).weight]
+        key = (Dp, id(self.rel_features), id(self.rel_features_inv)) + tuple((t.data_ptr(), t._version) for t in src)
+        if self._padded is not None and self._padded["key"] == key:
+            return self._padded
+
+        def pad_cols(t):                     # [.., D] -> [.., Dp]
+            return t if Dp == D else F.pad(t.detach().float(), (0, Dp - D))
+
+        def pad_sq(t):                       # [D, D] -> [Dp, Dp]
+            return t if Dp == D else F.pad(t.detach().float(), (0, Dp - D, 0, Dp - D))
+
+        layers = []
+        for j, (rl, e2e) in enumerate(mods):
+            W_e2e = e2e.weight
+            if Dp != D:                      # every [D, D] column block of e2e_linear.weight moves to its padded place
+                W_e2e = torch.cat([pad_sq(e2e.weight[:, k * D:(k + 1) * D]) for k in range(2 * I + 1)], dim=1).contiguous()
+            pos = pos_inv = None
+            if self.use_posemb:
+                pos = pad_cols(getattr(self, "pos_emb" + str(j)).weight).contiguous()
+                pos_inv = pad_cols(getattr(self, "pos_emb_inv" + str(j)).weight).contiguous()
+            layers.append((pad_sq(rl.weight).contiguous(), pad_cols(rl.bias).contiguous(), W_e2e,
+                           pad_cols(e2e.bias).contiguous(), pos, pos_inv))
+        self._padded = dict(key=key, D=D, Dp=Dp, layers=layers,
+                            relfeat=pad_cols(self.rel_features.detach().float()).contiguous(),
+                            relfeat_inv=pad_cols(self.rel_features_inv.detach().float()).contiguous(),
+                            w_score=pad_cols(self.score_func.weight.reshape(-1)).contiguous(), b_score=self.score_func.bias)
+        return self._padded
+
+    @staticmethod
+    def _pad_last(t, P):
+        return t if P["Dp"] == P["D"] else F.pad(t, (0, P["Dp"] - P["D"]))
+
+    def _state_in(self, P):
+        """Node state as the kernels read it: the padded tensor behind the view handed out by the previous call, or
+        a padded copy of whatever the caller installed (TypeLayer's output, rearev.py:140-153)."""
+        h = self.local_entity_emb
+        if P["Dp"] == P["D"]:
+            return h.detach().float()
+        base = getattr(h, "_gnnrag_padded", None)
+        if base is not None and base.shape[-1] == P["Dp"]:
+            return base
+        return self._pad_last(h.detach().float(), P)
+
+    @staticmethod
+    def _state_out(h_pad, P):
+        """[.., Dp] kernel output -> what the caller sees: a [.., :D] view that remembers its padded base."""
+        if P["Dp"] == P["D"]:
+            return h_pad
+        view = h_pad[..., : P["D"]]
+        view._gnnrag_padded = h_pad
+        return view
+
     def _forward_stack(self, current_dist, relational_ins, step):
         """(h, score, dist) of layer `step` from a whole-iteration run, or None when the call does not continue the
         sequence the step-0 call ran ahead (then the single-layer path computes it)."""
         if step == 0:
-            if self._stack is None:
-                layers = []
-                for j in range(self.num_gnn):
-                    rl, e2e = getattr(self, "rel_linear" + str(j)), getattr(self, "e2e_linear" + str(j))
-                    pos = getattr(self, "pos_emb" + str(j)).weight if self.use_posemb else None
-                    pos_inv = getattr(self, "pos_emb_inv" + str(j)).weight if self.use_posemb else None
-                    layers.append((rl.weight, rl.bias, e2e.weight, e2e.bias, pos, pos_inv))
-                self._stack = ops.LayerStack(self.plan, self.rel_features.detach().float(),
-                                             self.rel_features_inv.detach().float(), layers, self.score_func.weight,
-                                             self.score_func.bias, self.local_entity_mask, self.num_ins, path=self.path)
-            h, score, dist = self._stack.run(self.local_entity_emb.detach().float(), current_dist.detach().float(),
-                                             relational_ins.detach().float())
+            P = self._inference_params()
+            if self._stack is None or self._stack_key != P["key"]:
+                self._stack = ops.LayerStack(self.plan, P["relfeat"], P["relfeat_inv"], P["layers"], P["w_score"],
+                                             P["b_score"], self.local_entity_mask, self.num_ins, path=self.path)
+                self._stack_key = P["key"]
+            h, score, dist = self._stack.run(self._state_in(P), current_dist.detach().float(),
+                                             self._pad_last(relational_ins.detach().float(), P))
             self._ahead = dict(ins=relational_ins, h=h, score=score, dist=dist, given=[dist[j] for j in range(self.num_gnn)],
-                               emb=[h[j] for j in range(self.num_gnn)])
+                               emb=[self._state_out(h[j], P) for j in range(self.num_gnn)])
             return self._ahead["emb"][0], score[0], self._ahead["given"][0]
         a = self._ahead
         if (a is None or step >= self.num_gnn or relational_ins is not a["ins"] or current_dist is not a["given"][step - 1]

@@ -43,7 +43,11 @@ class QueryReform(nn.Module):
         if torch.is_grad_enabled():
             seed_retrieve = torch.bmm(seed_info.unsqueeze(1), ent_emb).squeeze(1)       # :40 (autograd form)
         else:
-            seed_retrieve = ops.seed_retrieve(seed_info.float(), ent_emb.float())       # raises on CPU tensors
+            base = getattr(ent_emb, "_gnnrag_padded", None)        # node state kept zero-padded by ReasonGNNLayer
+            if base is not None:
+                seed_retrieve = ops.seed_retrieve(seed_info.float(), base)[:, : ent_emb.shape[-1]]
+            else:
+                seed_retrieve = ops.seed_retrieve(seed_info.float(), ent_emb.float())   # raises on CPU tensors
         return self.fusion(q_node, seed_retrieve)                                       # :44
 
 
