@@ -43,6 +43,32 @@ def uninstall() -> None:
             del sys.modules[ref_name]
 
 
+def cache_rel_features(model):
+    """``ReaRev.get_rel_feature`` (rearev.py:91-111) re-encodes the relation vocabulary on EVERY forward: a linear
+    over the relation embeddings, or - with ``--relation_word_emb True`` - ``question_emb`` + ``AttnEncoder`` over the
+    LM states of all relation texts ``[R1, W, dim]`` (18.8 GFLOP per batch for WebQSP's 6105 relations, as much as the
+    GNN itself).  Neither depends on the batch.  In evaluation (no grad, eval mode) the result is kept and reused
+    until a parameter it depends on changes (checked by storage and version of every model parameter); training calls
+    always recompute.  The reference file is untouched: the bound method is wrapped on the instance."""
+    import torch
+    inner = model.get_rel_feature
+    if getattr(inner, "_gnnrag_cached", False):
+        return model
+    state = {"key": None, "value": None}
+
+    def get_rel_feature():
+        if torch.is_grad_enabled() or model.training:
+            return inner()
+        key = tuple((p.data_ptr(), p._version) for p in model.parameters())
+        if state["key"] != key:
+            state["value"], state["key"] = inner(), key
+        return state["value"]
+
+    get_rel_feature._gnnrag_cached = True
+    model.get_rel_feature = get_rel_feature
+    return model
+
+
 def swap(model, args: dict):
     """Replaces the reasoning layer (and TypeLayer, if present) of a constructed ReaRev."""
     from .modules.kg_reasoning.reasongnn import ReasonGNNLayer
@@ -73,4 +99,6 @@ def swap(model, args: dict):
         new_r.train(old_r.training)
         setattr(model, "reform" + str(j), new_r)
         j += 1
+    if hasattr(model, "get_rel_feature"):
+        cache_rel_features(model)
     return model

@@ -176,3 +176,41 @@ def shard_model(model, group: Optional[dist.ProcessGroup] = None, balance: str =
 
     model.forward = forward
     return model
+
+
+def sharded_training_step(model, batch: tuple, group: Optional[dist.ProcessGroup] = None, balance: str = "facts"):
+    """Data-parallel training step over question shards (SURVEY.md section 8e "Training (later): all-reduce of
+    grads"): this rank runs ``model(shard, training=True)`` on its contiguous question range, scales the loss by its
+    share of the batch (``calc_loss_label`` divides by the LOCAL batch size, rearev.py:156-160), back-propagates, and
+    the parameter gradients of all ranks are summed with ONE all-reduce of a flat buffer (~2.5 MB at D = 200: latency
+    bound on xGMI, so one bucket) - afterwards every rank holds the gradient of the whole-batch loss and the caller's
+    optimizer step keeps the replicas identical.  Dropout / fact dropout draw from each rank's own RNG streams, as in
+    any data-parallel run.  Returns (batch-mean loss, local model outputs).  Single process: the plain step."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        out = model(batch, training=True)
+        out[0].backward()
+        return out[0].detach(), out
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    B = batch[0].shape[0]
+    ranges = shard_ranges(batch, world, balance)
+    lo, hi = ranges[rank]
+    params = [p for p in model.parameters() if p.requires_grad]
+    if hi > lo:
+        out = model(shard_batch(batch, rank, world, balance), training=True)
+        local = out[0] * (float(hi - lo) / B)
+        local.backward()
+        loss_part = local.detach().float().reshape(1)
+    else:                                                   # more ranks than questions: contributes zeros
+        out, loss_part = None, torch.zeros(1, device=params[0].device)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params] + [loss_part])
+    dist.all_reduce(flat, group=group)
+    off = 0
+    for p in params:
+        n = p.numel()
+        g = flat[off: off + n].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += n
+    return flat[off], out

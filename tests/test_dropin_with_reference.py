@@ -207,6 +207,44 @@ def test_swapped_model_reproduces_reference_forward(reference_setup, monkeypatch
     assert torch.equal(pred2, pred) and torch.equal(dist2, dist) and ops.LayerStack.calls == args["num_iter"]
 
 
+def test_relation_features_are_encoded_once_per_evaluation(reference_setup, monkeypatch):
+    """f-3: ``get_rel_feature`` (rearev.py:91-111) does not depend on the batch - after install.swap it runs once per
+    evaluation instead of once per forward, is recomputed when a parameter changes and always under autograd; the
+    predictions are those of the reference."""
+    args, dataset, model = reference_setup
+    from gnnrag_amd import install
+    test = dataset["test"]
+    _patch_backend(monkeypatch)
+    mine = install.swap(copy.deepcopy(model), args)
+    calls = {"n": 0}
+    lin = mine.relation_linear
+    orig = lin.forward
+
+    def counted(x):
+        calls["n"] += 1
+        return orig(x)
+    lin.forward = counted
+    mine.eval()
+    test.reset_batches(is_sequential=True)
+    outs = []
+    for it in range(2):
+        np.random.seed(11 + it)
+        batch = test.get_batch(it, 3, fact_dropout=0.0, test=True)
+        with torch.no_grad():
+            outs.append((mine(batch[:-1])[2], model(batch[:-1])[2]))
+    per_forward = 2                                   # relation_linear is applied to both directions (rearev.py:98-99)
+    assert calls["n"] == per_forward                  # encoded once for both batches
+    for a, b in outs:
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=0, atol=1e-6)
+    with torch.no_grad():
+        lin.weight.mul_(1.0)                          # an in-place update bumps the version: recomputed
+        mine(batch[:-1])
+    assert calls["n"] == 2 * per_forward
+    mine.train()
+    mine(batch[:-1], training=True)                   # training: always recomputed
+    assert calls["n"] == 3 * per_forward
+
+
 def test_unmodified_evaluator_reports_identical_metrics(reference_setup, monkeypatch):
     args, dataset, model = reference_setup
     from evaluate import Evaluator

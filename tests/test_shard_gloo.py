@@ -188,3 +188,60 @@ def test_sharded_reference_model_world2():
         assert p.exitcode == 0
     for rank, ok, err in res:
         assert ok, "rank %d: sharded forward differs (max err %g)" % (rank, err)
+
+
+def _train_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        import copy
+        import test_dropin_with_reference as td
+        from gnnrag_amd import shard
+        args, dataset, model = td.build_reference_setup()
+        train = dataset["train"]
+        train.reset_batches(is_sequential=True)
+        np.random.seed(3)
+        batch = train.get_batch(0, 5, fact_dropout=0.0)
+        model.train()
+        for m in model.modules():                       # dropout off: the two runs must see the same network
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        ref = copy.deepcopy(model)
+        loss_ref = ref(batch, training=True)[0]
+        loss_ref.backward()
+        loss, _ = shard.sharded_training_step(model, batch)
+        # (some gradients are mathematically zero - score_func.bias: softmax is shift invariant - so errors are
+        # measured against the largest gradient of the model, not per tensor)
+        scale = max(float(pr.grad.abs().max()) for pr in ref.parameters() if pr.grad is not None)
+        worst = 0.0
+        for (n, p), (_, pr) in zip(model.named_parameters(), ref.named_parameters()):
+            if pr.grad is None:
+                continue
+            worst = max(worst, float((p.grad - pr.grad).abs().max()) / scale)
+        ok = worst <= 1e-4 and abs(float(loss) - float(loss_ref)) <= 1e-5 * max(1.0, abs(float(loss_ref)))
+        q.put((rank, bool(ok), worst))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="live reference not available")
+def test_sharded_training_step_world2():
+    """Data-parallel training step of the live reference ReaRev (CPU) on 2 gloo ranks: per-rank loss on a
+    fact-balanced question shard, ONE all-reduce of the flat gradient - every rank ends with the gradient (and loss)
+    of the whole-batch step."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, err in res:
+        assert ok, "rank %d: sharded gradient differs (max rel err %g)" % (rank, err)
