@@ -29,6 +29,9 @@
 // (register blow-up), direct stores from the MFMA layout instead of the LDS-staged epilogue (-25 % on the
 // self-block update).
 #define GNNRAG_GEMM_MT1_NW 8     // the one-row-tile-per-wave variant may use 8-wave (128-row) workgroups
+#ifndef GNNRAG_UPDATE_B3
+#define GNNRAG_UPDATE_B3 1       // bf16x3 self-block update on the W-resident kernel of tables_b3.hip
+#endif
 #ifndef GNNRAG_TABLES_WRES
 #define GNNRAG_TABLES_WRES 1     // bf16x3 relation tables on the W-resident kernel of tables_b3.hip
 #endif
@@ -939,6 +942,10 @@ static int update_common(GemmArgs g, int64_t BN, int32_t D, hipStream_t stream, 
     // short K, exact fp32, aligned operands: the W-resident kernel (whole weight block in LDS)
     const bool al = aligned16(g.A0) && aligned16(g.W) && aligned16(g.C) && (!g.add || aligned16(g.add)) &&
                     g.ldw % 4 == 0 && g.wc0 % 4 == 0 && (!g.add || g.add_rows >= g.M);
+    if (GNNRAG_UPDATE_B3 && math != GNNRAG_MATH_FP32 && al && g.add && !g.A1 && g.K == D) {
+      const int rc = update_b3_launch(g.A0, g.add, g.W, g.bias, g.w_s, g.b_s, g.mask, g.C, g.score, BN, D, g.ldw, stream);
+      if (rc != GNNRAG_E_UNSUPPORTED) return rc;
+    }
     const int S = (GNNRAG_GEMM_WRES && math != GNNRAG_MATH_BF16X3 && al && g.M >= 4096) ? wres_stride(g) : 0;
     if (S) return launch_wres<EPI_UPDATE>(g, S, stream);
     return launch_gemm<EPI_UPDATE, AMODE_PLAIN>(g, stream, math);

@@ -40,6 +40,33 @@ struct TabArgs {
   int32_t npass;           // passes of kTabTPW tiles per wave
 };
 
+__device__ __forceinline__ int opaque_i(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+// sum of 4 values per lane over the 16 lanes of a DPP row (see gemm_f32.hip: row16_sum4); returns the total of value
+// index 2*(lane&1) + ((lane>>1)&1)
+template <int CTRL, int BANK>
+__device__ __forceinline__ float dpp_b3(float old, float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), CTRL, 0xf, BANK, false));
+}
+__device__ __forceinline__ float row16_sum4_b3(const float (&v)[4], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2;
+  float w2[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float send = b0 ? v[j] : v[j + 2];
+    w2[j] = (b0 ? v[j + 2] : v[j]) + dpp_b3<0xB1, 0xf>(send, send);
+  }
+  const float send = b1 ? w2[0] : w2[1];
+  float w = (b1 ? w2[1] : w2[0]) + dpp_b3<0x4E, 0xf>(send, send);
+  const float t4 = dpp_b3<0x104, 0x5>(w, w);
+  w += dpp_b3<0x114, 0xA>(t4, w);
+  w += dpp_b3<0x128, 0xf>(w, w);
+  return w;
+}
+
 // LDS row of column slot: the first four column tiles of a part are interleaved so that a lane holds four
 // consecutive columns (float4 stores in the epilogue), the others keep the plain order
 __device__ __forceinline__ int tab_lds_row(int j) {
@@ -260,6 +287,238 @@ __global__ __launch_bounds__(512, 2) void k_tables_b3(TabArgs a) {
     default: break;
   }
 #undef GNNRAG_TAB_CASE
+}
+
+// ---- the self-block update in bf16x3 on the same weight-plane layout -------------------------------------------------
+//   h'[m, :] = relu( h[m, :] . W_e2e[:, 0:D]^T + b + nbr[m, :] ),   score[m] = w_s . h'[m, :] + b_s + (1 - mask[m]) * -1e11
+// (reasongnn.py:161-168 with the neighbour blocks already reduced into nbr).  Workgroup = (row chunk, column part of
+// 7 / 6 column tiles): the part's three weight planes are split and staged ONCE and stay in LDS for all row tiles of
+// the chunk; every wave owns a contiguous run of 16-row tiles and, as in k_gemm_wres, reads a tile's A fragments in
+// the MFMA layout straight from global memory (two float4 = 8 consecutive k per lane and k block, 128-byte lines) a
+// whole tile ahead and splits them into planes in registers; the epilogue works from the registers.  A is read by
+// both parts of a chunk - they sit next to each other in the grid and on one XCD, so the second read hits L2.  The
+// two parts' score dots are two commutative atomic adds onto a zeroed score (x + y == y + x: deterministic); the part
+// that owns column 0 adds bias and mask term to its share first, so a masked slot still ends exactly at -1e11.
+struct UpdB3Args {
+  const float* A;        // h [M, D]
+  const float* W;        // e2e_linear.weight [D, ldw]; columns 0..D-1 are the self block
+  const float* bias;     // [D]
+  const float* add;      // nbr [M, D]
+  const float* w_s;      // [D]
+  const float* b_s;      // [1]
+  const float* mask;     // [M]
+  float* C;              // [M, D]
+  float* score;          // [M], zeroed before the launch
+  int32_t M, D, ldw, ct0;
+};
+
+template <int CTN>
+__device__ __forceinline__ void update_b3_part(const UpdB3Args& a, unsigned char* lds, int col0, bool first_part,
+                                               int chunk, int nchunks) {
+  constexpr int RB = kTabSlots * 16;
+  constexpr int PL = kTabNTH * 16 * RB;
+  constexpr int NKB = kTabNKB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int D = a.D;
+  const int ncol = min(CTN * 16, D - col0);
+  const int KC = D >> 2;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  float* Bl = reinterpret_cast<float*>(lds + 3 * PL + 64);      // bias / score weights of this part's columns
+  float* Sl = Bl + kTabNTH * 16;
+
+  if (tid < 16) reinterpret_cast<unsigned*>(lds + 3 * PL)[tid] = 0u;
+  for (int j = tid; j < kTabNTH * 16; j += 512) {
+    Bl[j] = (j < ncol && a.bias) ? a.bias[col0 + j] : 0.f;
+    Sl[j] = j < ncol ? a.w_s[col0 + j] : 0.f;
+  }
+  {   // weight planes of this column part (self block: columns 0..D-1 of e2e_linear.weight)
+    const int total = CTN * 16 * kTabSlots * 2;
+    constexpr int UN = 6;
+    for (int base = 0; base < total; base += 512 * UN) {
+      f32x4 v[UN];
+      int off[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int idx = base + u * 512 + tid;
+        const int j = idx / (kTabSlots * 2), kc = idx - j * (kTabSlots * 2);
+        v[u] = zero4;
+        off[u] = idx < total ? tab_lds_row(j) * RB + kc * 8 : -1;
+        if (idx < total && j < ncol && kc < KC)
+          v[u] = *reinterpret_cast<const f32x4*>(a.W + (size_t)(col0 + j) * a.ldw + 4 * kc);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (off[u] >= 0) {
+          const Split3 sp = split3(v[u]);
+          unsigned char* dst = lds + off[u];
+          *reinterpret_cast<uint2*>(dst) = sp.hi;
+          *reinterpret_cast<uint2*>(dst + PL) = sp.mid;
+          *reinterpret_cast<uint2*>(dst + 2 * PL) = sp.lo;
+        }
+      }
+    }
+  }
+  // this wave's 16-row tiles
+  const long long U = ((long long)a.M + 15) >> 4;
+  const int c0 = (int)(U * chunk / nchunks), c1 = (int)(U * (chunk + 1) / nchunks);
+  const int nch = c1 - c0;
+  int t = c0 + (int)((long long)nch * wave / 8);
+  const int tend = c0 + (int)((long long)nch * (wave + 1) / 8);
+  const int kmax = D - 8;
+  // raw A pieces of a tile: per k block two float4 (k = 32 kb + 8 fg .. + 7), unconditional (clamped addresses)
+  auto a_piece = [&](int tile, int kb, int half) -> f32x4 {
+    const int row = min(tile * 16 + fr, a.M - 1);
+    const int k = min(32 * kb + 8 * fg, kmax) + 4 * half;
+    return *reinterpret_cast<const f32x4*>(a.A + (size_t)row * D + k);
+  };
+  f32x4 ra[NKB][2];
+  if (t < tend) {
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      ra[kb][0] = a_piece(t, kb, 0);
+      ra[kb][1] = a_piece(t, kb, 1);
+    }
+  }
+  const float bs = a.b_s[0];
+  __syncthreads();
+
+  for (; t < tend; ++t) {
+    const int rbase = t * 16 + 4 * fg;                       // C layout: rows rbase + q, column slot fr
+    // the epilogue's operands: nbr in the register layout (interleaved group: 4 consecutive columns per lane)
+    f32x4 addg[4];                                           // group 0 (column tiles 0..3), per row q
+    float addt[CTN > 4 ? CTN - 4 : 1][4];                    // plain tiles 4.., per row q
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = min(rbase + q, a.M - 1);
+      const float* arow = a.add + (size_t)row * D + col0;
+      addg[q] = *reinterpret_cast<const f32x4*>(arow + min(4 * fr, ncol - 4));
+#pragma unroll
+      for (int nt = 4; nt < CTN; ++nt) addt[nt - 4][q] = arow[min(nt * 16 + fr, ncol - 1)];
+    }
+    float mrow = 0.f;
+    {
+      const int srow = min(rbase + (2 * (fr & 1) + ((fr >> 1) & 1)), a.M - 1);
+      mrow = a.mask[srow];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[CTN];
+#pragma unroll
+    for (int nt = 0; nt < CTN; ++nt) acc[nt] = zero4;
+    const int tload = t + 1 < tend ? t + 1 : t;
+    const int fg_t = opaque_i(fg);                           // keeps the (loop invariant) plane reads inside the tile loop
+    constexpr int PA[6] = {1, 2, 0, 1, 0, 0};
+    constexpr int PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const bool kok = 32 * kb + 8 * fg_t <= kmax;
+      const Split3 s0 = split3(kok ? ra[kb][0] : zero4);
+      const Split3 s1 = split3(kok ? ra[kb][1] : zero4);
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      bf16x8 ap[3];
+      ap[0] = __builtin_bit_cast(bf16x8, (u32x4){s0.hi.x, s0.hi.y, s1.hi.x, s1.hi.y});
+      ap[1] = __builtin_bit_cast(bf16x8, (u32x4){s0.mid.x, s0.mid.y, s1.mid.x, s1.mid.y});
+      ap[2] = __builtin_bit_cast(bf16x8, (u32x4){s0.lo.x, s0.lo.y, s1.lo.x, s1.lo.y});
+      ra[kb][0] = a_piece(tload, kb, 0);                     // refill: the next tile's k block kb
+      ra[kb][1] = a_piece(tload, kb, 1);
+      const unsigned char* wb = lds + fr * RB + kb * 64 + fg_t * 16;
+#pragma unroll
+      for (int nt = 0; nt < CTN; nt += 2) {
+        bf16x8 b0[3], b1[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          b0[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + nt * 16 * RB));
+          b1[pl] = b0[pl];
+          if (nt + 1 < CTN)
+            b1[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + (nt + 1) * 16 * RB));
+        }
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[PA[p]], b0[PB[p]], acc[nt], 0, 0, 0);
+          if (nt + 1 < CTN)
+            acc[nt + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[PA[p]], b1[PB[p]], acc[nt + 1], 0, 0, 0);
+        }
+      }
+    }
+    // epilogue from the registers
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 bias_g = *reinterpret_cast<const f32x4*>(Bl + min(4 * fr, kTabNTH * 16 - 4));
+    const f32x4 ws_g = *reinterpret_cast<const f32x4*>(Sl + min(4 * fr, kTabNTH * 16 - 4));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = rbase + q;
+      f32x4 v = {acc[0][q], acc[1][q], acc[2][q], acc[3][q]};
+      v = __builtin_elementwise_max((v + bias_g) + addg[q], zero4);
+      const int c = 4 * fr;
+      if (c + 4 > ncol) {                                    // (ncol % 4 == 0: a lane's group is all in or all out)
+        v = zero4;
+      } else if (row < a.M) {
+        *reinterpret_cast<f32x4*>(a.C + (size_t)row * D + col0 + c) = v;
+      }
+      part[q] += v[0] * ws_g[0] + v[1] * ws_g[1] + v[2] * ws_g[2] + v[3] * ws_g[3];
+#pragma unroll
+      for (int nt = 4; nt < CTN; ++nt) {
+        const int cc = nt * 16 + fr;
+        float x = fmaxf((acc[nt][q] + Bl[cc]) + addt[nt - 4][q], 0.f);
+        if (cc >= ncol) x = 0.f;
+        else if (row < a.M) a.C[(size_t)row * D + col0 + cc] = x;
+        part[q] += x * Sl[cc];
+      }
+    }
+    {
+      const float tot = row16_sum4_b3(part, lane);
+      const int srow = rbase + (2 * (fr & 1) + ((fr >> 1) & 1));
+      if (fr < 4 && srow < a.M) {
+        // this part's share of the score; the first part carries bias and mask term (fp32 adds: a masked slot's
+        // share is exactly -1e11 and stays there when the other part's share is added)
+        const float share = first_part ? (tot + bs) + (1.0f - mrow) * kVeryNeg : tot;
+        atomicAdd(a.score + srow, share);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void k_update_b3(UpdB3Args a, int nchunks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  // the two parts of a row chunk are neighbours in the grid AND on one XCD (blocks b and b + 8): block = 16*(c/8) + 8*h + c%8
+  const int blk = blockIdx.x;
+  const int h = (blk >> 3) & 1;
+  const int chunk = (blk >> 4) * 8 + (blk & 7);
+  if (chunk >= nchunks) return;
+  const int NT = (a.D + 15) >> 4;
+  if (h == 0) update_b3_part<kTabNTH>(a, lds, 0, true, chunk, nchunks);
+  else if (NT - a.ct0 == 6) update_b3_part<6>(a, lds, a.ct0 * 16, false, chunk, nchunks);
+}
+
+int update_b3_launch(const float* h, const float* nbr, const float* W, const float* b, const float* w_s, const float* b_s,
+                     const float* mask, float* h_out, float* score, int64_t BN, int32_t D, int32_t ldw,
+                     hipStream_t stream) {
+  if (D % 8 || (D + 31) / 32 != kTabNKB || (D + 15) / 16 != 13 || BN < 8192 || BN >= ((int64_t)1 << 31) || ldw % 4)
+    return GNNRAG_E_UNSUPPORTED;
+  if ((((uintptr_t)h | (uintptr_t)nbr | (uintptr_t)W | (uintptr_t)h_out) & 15) != 0) return GNNRAG_E_UNSUPPORTED;
+  UpdB3Args a;
+  memset(&a, 0, sizeof(a));
+  a.A = h; a.W = W; a.bias = b; a.add = nbr; a.w_s = w_s; a.b_s = b_s; a.mask = mask; a.C = h_out; a.score = score;
+  a.M = (int32_t)BN; a.D = D; a.ldw = ldw; a.ct0 = kTabNTH;
+  int cus = 0;
+  {
+    const int rc = device_cu_count(&cus);
+    if (rc) return rc;
+  }
+  const long long U = (BN + 15) / 16;
+  int chunks = cus / 2;
+  if (chunks < 1) chunks = 1;
+  if ((long long)chunks * 8 > U) chunks = (int)((U + 7) / 8);
+  GNNRAG_HIP(hipMemsetAsync(score, 0, (size_t)BN * sizeof(float), stream));
+  static DeviceMask cap;
+  {
+    const int rc = raise_lds_cap(k_update_b3, cap);
+    if (rc) return rc;
+  }
+  const int nblk = ((chunks + 7) / 8) * 16;
+  hipLaunchKernelGGL(k_update_b3, dim3(nblk), dim3(512), 160 * 1024, stream, a, chunks);
+  GNNRAG_LAUNCH_CHECK();
+  return 0;
 }
 
 int tables_b3_launch(const gnnrag_csr* csr, const float* T_fwd, const float* T_inv, const float* ins, const float* W,

@@ -15,8 +15,9 @@ from . import _lib
 MATH_FP32, MATH_BF16X3, MATH_MIXED = 0, 1, 2
 MATH_NAMES = {MATH_FP32: "fp32 (v_mfma_f32_16x16x4_f32, bit-exact fmaf chains)",
               MATH_BF16X3: "bf16x3 (exact 3-way bf16 split, 6 plane products on v_mfma_f32_16x16x32_bf16, fp32 accumulate)",
-              MATH_MIXED: "mixed (exact fp32 MFMA for the self-block update and small products, bf16x3 for the relation "
-                          "tables: per product the faster fp32-class form)"}
+              MATH_MIXED: "mixed (per kernel the faster fp32-class form: bf16x3 - exact 3-way bf16 split, 6 plane products, "
+                          "fp32 accumulate - for the relation tables and the self-block update, exact fp32 MFMA for the "
+                          "small products)"}
 # Math mode the wrappers below pass to the library (the library itself keeps no mode: it is an argument of
 # every dense entry point).  GNNRAG_MATH=fp32|bf16x3|mixed sets the binding's default.
 _default_math = {"fp32": MATH_FP32, "bf16x3": MATH_BF16X3, "mixed": MATH_MIXED}[os.environ.get("GNNRAG_MATH", "mixed")]

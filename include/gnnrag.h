@@ -120,9 +120,9 @@ int gnnrag_csr_permute_weight(const gnnrag_csr* csr, const float* w_per_fact, in
  *                      error <= 3*2^-24 (fp32 class), about 2.5x the fp32 MFMA rate. */
 #define GNNRAG_MATH_FP32   0
 #define GNNRAG_MATH_BF16X3 1
-/* GNNRAG_MATH_MIXED: per kernel the faster of the two fp32-class forms - exact fp32 on the W-resident update kernel
- * (weight block in one CU's LDS) and on the skinny kernel (small M), bf16x3 on the k-tiled kernel and for the
- * relation tables. */
+/* GNNRAG_MATH_MIXED: per kernel the faster of the two fp32-class forms - bf16x3 where a W-resident bf16x3 kernel
+ * exists (relation tables, self-block update at hidden size 193..208) and on the k-tiled kernel, exact fp32 on the
+ * W-resident fp32 update kernel (other hidden sizes) and on the skinny kernel (small M: the relation transforms). */
 #define GNNRAG_MATH_MIXED  2
 
 /* C[M,Nout] = act( A[M,K] . W[Nout,K]^T + bias[Nout] + add[row < add_rows, :] ), fp32 MFMA.

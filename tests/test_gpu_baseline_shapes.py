@@ -155,8 +155,19 @@ def test_c1_shape_single_question(dev):
             _check_stack(got, want, cfg.T * cfg.L, what="C1 torch path %d" % path)
 
 
+@pytest.fixture(params=["mixed", "bf16x3", "fp32"])
+def math_mode(request):
+    """C2 at full size is where the W-resident kernels run (k_gemm_wres / k_update_b3 / k_tables_b3 need >= 8192 rows):
+    each math mode of the binding is pinned in turn."""
+    import gnnrag_amd  # noqa: F401
+    from gnnrag_amd import ops
+    old = ops.set_dense_math({"mixed": ops.MATH_MIXED, "bf16x3": ops.MATH_BF16X3, "fp32": ops.MATH_FP32}[request.param])
+    yield request.param
+    ops.set_dense_math(old)
+
+
 @pytest.mark.parametrize("path", [2, 1], ids=["fused", "unfused"])
-def test_c2_full_batch_against_oracle_slices(dev, path):
+def test_c2_full_batch_against_oracle_slices(dev, path, math_mode):
     """C2 at FULL size (B = 64, the batch bench.py times) on the GPU; the oracle runs on two 2-question slices
     of the SAME batch (first and last questions, i.e. both ends of the XCD / work-item mapping)."""
     import oracle.rearev_torch_cpu as otorch
