@@ -136,6 +136,7 @@ def main():
         ops.CsrPlan(et[0], et[1], et[2], cfg.B, cfg.N, cfg.R1, dev, validate=False)
     torch.cuda.synchronize()
     csr_build_ms = (time.perf_counter() - t0) * 1e3 / 3
+    csr_cached_ms = cached_structure_ms(batch, dev, ops) if rank == 0 else None
 
     graph = None
     if args.launch == "graph":
@@ -214,6 +215,8 @@ def main():
                    "D": cfg.D, "I": cfg.I, "L": cfg.L, "parallelism": "question-sharded x%d" % world},
         "fact_layers_per_sec": facts / (elapsed / args.steps),
         "csr_build_ms": csr_build_ms, "csr_first_call_ms": csr_first_ms,
+        # f-1: per-question id blocks resident on the GPU (data/fact_mat.DeviceFactCache), batch = device concatenation
+        "csr_build_from_device_cache_ms": csr_cached_ms,
         # host-buffer boundary: int64 tuple -> int32 upload over PCIe + device structure build, once per batch,
         # amortised over ONE step (a ReaRev forward runs num_iter steps on the same structure); never `value`
         "value_incl_upload_and_build": typed_edges / (elapsed / args.steps + csr_build_ms * 1e-3),
@@ -236,6 +239,35 @@ def main():
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
         print(json.dumps(out))
+
+
+def cached_structure_ms(batch, dev, ops):
+    """Batch tuple + structure from per-question [3, F_g] int32 blocks that already live on the GPU
+    (``gnnrag_amd.data.fact_mat.DeviceFactCache`` - what an evaluation run sees from its second epoch / second pass
+    on): device concatenation + node offsets + the device structure build, wall clock per batch."""
+    import torch
+    from gnnrag_amd.data import fact_mat
+    cfg = batch.cfg
+    et = batch.edge_tuple
+    bid = np.asarray(et[3])
+    bounds = np.searchsorted(bid, np.arange(cfg.B + 1))
+
+    class _Loader:                                  # the three loader fields the cache reads (dataset_load.py:452-527)
+        max_local_entity, data_eff, use_self_loop, num_kb_relation = cfg.N, False, False, cfg.R1
+        kb_adj_mats = [tuple((np.asarray(et[k][bounds[b]:bounds[b + 1]]) - (b * cfg.N if k != 1 else 0)) for k in range(3))
+                       for b in range(cfg.B)]
+        global2local_entity_maps = [()] * cfg.B
+
+    fc = fact_mat.DeviceFactCache(_Loader(), dev)
+    ids = list(range(cfg.B))
+    fc.batch(ids)                                   # first use uploads the blocks
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        bf = fc.batch(ids)
+        ops.CsrPlan(bf[0], bf[1], bf[2], cfg.B, cfg.N, cfg.R1, dev, validate=False, hrt_device=bf.hrt_device)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3 / 3
 
 
 def strong_shard(gbatch, gfeats, rank, world):

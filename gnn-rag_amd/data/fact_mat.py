@@ -125,15 +125,101 @@ class FactCache:
         return hrt[0], hrt[1], hrt[2], batch_ids, np.arange(F, dtype=np.int64), cat(1), cat(2)
 
 
-def patch_loader(loader, cache: bool = False, keep_rng_stream: bool = False):
+class BatchFacts:
+    """``kb_adj_mat`` of a batch served from a :class:`DeviceFactCache`: behaves like the reference's 7-tuple
+    (``dataset_load.py:527``) for everything the MI355X modules read, but the three id arrays are rows of ONE int32
+    block that already lives on the GPU (``hrt_device`` [3, F]; items 0..2 are views of it) and the host-side members
+    (batch ids, fact ids, the two weight lists) are built only if somebody asks for them (``normalized_gnn`` /
+    ``norm_rel``).  The reference's own modules cannot consume it (they build ``torch.LongTensor`` from numpy arrays):
+    it is handed out only by ``patch_loader(..., device=...)``, i.e. next to ``install.swap``-ed modules."""
+
+    def __init__(self, hrt_device, sizes, parts, N):
+        self.hrt_device = hrt_device
+        self._sizes, self._parts, self._N = sizes, parts, N
+        self._lazy = {}
+
+    def __len__(self):
+        return 7
+
+    def _host(self, k):
+        if k not in self._lazy:
+            F = int(self._sizes.sum())
+            if k == 3:
+                v = np.repeat(np.arange(len(self._parts), dtype=np.int64), self._sizes)
+            elif k == 4:
+                v = np.arange(F, dtype=np.int64)
+            else:
+                v = np.concatenate([p[k - 4] for p in self._parts]) if self._parts else np.zeros(0)
+            self._lazy[k] = v
+        return self._lazy[k]
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return tuple(self[i] for i in range(7)[k])
+        if k < 0:
+            k += 7
+        if k in (0, 1, 2):
+            return self.hrt_device[k]
+        if 3 <= k < 7:
+            return self._host(k)
+        raise IndexError(k)
+
+    def __iter__(self):
+        return (self[i] for i in range(7))
+
+
+class DeviceFactCache(FactCache):
+    """:class:`FactCache` whose per-question id blocks live ON THE GPU ("cached per-question
+    int32 [structure] built once at load time, batch = concatenation with offsets"): a question's [3, F_g] int32 block
+    is uploaded the first time it is used; a batch is one device-side concatenation plus the node offsets - no host
+    concatenation of the facts and no per-batch PCIe transfer of them (4.7 ms + 9 MB per C2 batch before)."""
+
+    def __init__(self, loader, device, max_questions: int = 200000):
+        super().__init__(loader, max_questions)
+        import torch
+        self.device = torch.device(device)
+        self._dev = {}
+
+    def batch(self, sample_ids):
+        import torch
+        N = self.loader.max_local_entity
+        parts, blocks = [], []
+        for s_ in sample_ids:
+            s_ = int(s_)
+            q = self._question(s_)
+            d = self._dev.get(s_)
+            if d is None:
+                d = torch.from_numpy(np.ascontiguousarray(q[0])).to(self.device)
+                if len(self._dev) < self.max_questions:
+                    self._dev[s_] = d
+            parts.append(q)
+            blocks.append(d)
+        sizes = np.array([p[0].shape[1] for p in parts], dtype=np.int64)
+        if blocks:
+            hrt = torch.cat(blocks, dim=1)
+            off = torch.repeat_interleave(torch.arange(len(blocks), device=self.device, dtype=torch.int32) * N,
+                                          torch.from_numpy(sizes).to(self.device, non_blocking=True),
+                                          output_size=int(sizes.sum()))    # size given: no device->host sync
+            hrt[0] += off
+            hrt[2] += off
+        else:
+            hrt = torch.zeros((3, 0), dtype=torch.int32, device=self.device)
+        return BatchFacts(hrt, sizes, parts, N)
+
+
+def patch_loader(loader, cache: bool = False, keep_rng_stream: bool = False, device=None):
     """Rebinds ``loader._build_fact_mat`` to the vectorised builder (the reference file is untouched).
     ``cache=True`` additionally serves ``fact_dropout == 0`` batches from a :class:`FactCache`.  The cached
     path does not draw the per-question ``np.random.permutation`` the reference draws even without dropout
     (``dataset_load.py:489-490``), so a run that interleaves cached evaluation batches with training batches
     (``train_model.py`` evaluates on ``valid`` every epoch) consumes a different numpy RNG stream than the
     reference; ``keep_rng_stream=True`` draws and discards those permutations (same stream as the reference,
-    at the cost of most of the caching gain).  Use the plain cache for evaluation-only runs."""
-    fc = FactCache(loader) if cache else None
+    at the cost of most of the caching gain).  Use the plain cache for evaluation-only runs.  ``device``: keep the
+    per-question id blocks on that GPU (:class:`DeviceFactCache`; the tuple is then a :class:`BatchFacts`, readable by
+    the MI355X modules only)."""
+    fc = None
+    if cache:
+        fc = DeviceFactCache(loader, device) if device is not None else FactCache(loader)
 
     def build(self, sample_ids, fact_dropout):
         if fc is not None and fact_dropout == 0:

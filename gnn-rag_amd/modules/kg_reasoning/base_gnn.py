@@ -23,8 +23,11 @@ def plan_for(edge_list, B: int, N: int, R1: int, device) -> "ops.CsrPlan":
     key = (id(edge_list), B, N, R1, str(device))
     if _last_plan["key"] == key and _last_plan["tuple"] is edge_list:
         return _last_plan["plan"]
-    heads, rels, tails = edge_list[0], edge_list[1], edge_list[2]
-    plan = ops.CsrPlan(heads, rels, tails, B, N, R1, device)
+    hrt = getattr(edge_list, "hrt_device", None)          # data/fact_mat.BatchFacts: the id block is already on the GPU
+    if hrt is not None:
+        plan = ops.CsrPlan(None, None, None, B, N, R1, hrt.device, hrt_device=hrt)
+    else:
+        plan = ops.CsrPlan(edge_list[0], edge_list[1], edge_list[2], B, N, R1, device)
     _last_plan.update(key=key, plan=plan, tuple=edge_list)
     return plan
 

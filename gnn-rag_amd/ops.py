@@ -87,13 +87,22 @@ class CsrPlan:
     (``kb_adj_mat`` = heads, rels, tails, ..., ``gnn/dataset_load.py:527``).
     Replaces ``BaseGNNLayer.build_matrix`` (``base_gnn.py:19-51``)."""
 
-    def __init__(self, heads, rels, tails, B: int, N: int, R1: int, device, validate: bool = True):
+    def __init__(self, heads, rels, tails, B: int, N: int, R1: int, device, validate: bool = True,
+                 hrt_device: Optional[torch.Tensor] = None):
         lib = _lib.load()
-        heads = np.asarray(heads)
-        rels = np.asarray(rels)
-        tails = np.asarray(tails)
-        F = int(heads.shape[0])
-        if rels.shape[0] != F or tails.shape[0] != F:
+        if hrt_device is not None:
+            # the batch builder's [3, F] int32 block is already on the GPU (data/fact_mat.DeviceFactCache)
+            if (hrt_device.dtype != torch.int32 or hrt_device.dim() != 2 or hrt_device.shape[0] != 3
+                    or not hrt_device.is_cuda or not hrt_device.is_contiguous()):
+                raise ValueError("hrt_device must be a contiguous [3, F] int32 CUDA tensor")
+            heads = rels = tails = None
+            F = int(hrt_device.shape[1])
+        else:
+            heads = np.asarray(heads)
+            rels = np.asarray(rels)
+            tails = np.asarray(tails)
+            F = int(heads.shape[0])
+        if hrt_device is None and (rels.shape[0] != F or tails.shape[0] != F):
             raise ValueError("heads/rels/tails differ in length")
         if B <= 0 or N <= 0 or R1 <= 0:
             raise ValueError("B, N, R1 must be positive")
@@ -107,8 +116,12 @@ class CsrPlan:
             raise _lib.GnnragError("CsrPlan needs a GPU device, got %s" % self.device)
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        base = heads.base
-        if (F and isinstance(base, np.ndarray) and heads.dtype == np.int32 and base is rels.base
+        base = None if hrt_device is not None else heads.base
+        if hrt_device is not None:
+            if hrt_device.device != self.device and not (self.device.index is None):
+                raise _lib.GnnragError("hrt_device lives on %s, the plan on %s" % (hrt_device.device, self.device))
+            hrt = hrt_device if F else torch.zeros((3, 1), dtype=torch.int32, device=hrt_device.device)
+        elif (F and isinstance(base, np.ndarray) and heads.dtype == np.int32 and base is rels.base
                 and base is tails.base and base.dtype == np.int32 and base.shape == (3, F) and base.flags.c_contiguous
                 and heads.ctypes.data == base[0].ctypes.data and rels.ctypes.data == base[1].ctypes.data
                 and tails.ctypes.data == base[2].ctypes.data and heads.shape == rels.shape == tails.shape == (F,)
@@ -132,7 +145,9 @@ class CsrPlan:
             hrt = np.empty((3, max(F, 1)), dtype=np.int32)
             hrt[0, :F], hrt[1, :F], hrt[2, :F] = heads, rels, tails
         with torch.cuda.device(self.device):
-            if isinstance(hrt, np.ndarray):
+            if hrt_device is not None:
+                self._hrt = hrt                                                         # already resident
+            elif isinstance(hrt, np.ndarray):
                 self._hrt = torch.from_numpy(hrt).to(self.device, non_blocking=False)   # ONE int32 upload
             else:
                 self._hrt = hrt.to(self.device, non_blocking=True)                      # from the pinned block

@@ -73,7 +73,12 @@ def main():
                 if dataset.get(split) is not None:
                     # the per-question cache skips numpy RNG draws the reference makes (fact_mat.patch_loader):
                     # evaluation-only runs use it as it is, training runs keep the reference's RNG stream
-                    patch_loader(dataset[split], cache=(split != "train"), keep_rng_stream=not is_eval)
+                    # GNNRAG_DEVICE_FACTS=1 (single-rank evaluation): per-question id blocks stay on the GPU
+                    dev = None
+                    if os.environ.get("GNNRAG_DEVICE_FACTS") and is_eval and world == 1 and split != "train":
+                        import torch
+                        dev = torch.device("cuda", torch.cuda.current_device())
+                    patch_loader(dataset[split], cache=(split != "train"), keep_rng_stream=not is_eval, device=dev)
             return dataset
 
         dataset_load.load_data = load_data
