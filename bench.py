@@ -411,9 +411,10 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
         return float(np.mean(_events_ms(fn, reps)))
 
     ms = {}
-    ms["rel_transform_x2"] = t(lambda: (box.__setitem__("Tf", ops.linear(relf, rl.weight, rl.bias)),
-                                        box.__setitem__("Ti", ops.linear(relf_inv, rl.weight, rl.bias))))
-    Tf, Ti = box["Tf"], box["Ti"]
+    # relation projections of ALL L layers and both directions: one launch per step (rel_transform.hip)
+    rel_layers = [(lp[0], lp[1], None, None) for lp in P["layers"]]
+    ms["rel_transform_all_layers"] = t(lambda: box.__setitem__("T", ops.rel_transform(relf, relf_inv, rel_layers)))
+    Tf, Ti = box["T"][0, 0], box["T"][0, 1]
     ms["aggregate_dense"] = t(lambda: box.__setitem__("agg", ops.aggregate(plan, dense, ins, Tf, Ti)))
     ms["aggregate_seed"] = t(lambda: ops.aggregate(plan, seed, ins, Tf, Ti))
     agg = box["agg"]

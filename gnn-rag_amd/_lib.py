@@ -85,6 +85,9 @@ SIGNATURES = {
     "gnnrag_masked_softmax": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, _VP]),
     "gnnrag_typelayer": (C.c_int, [C.POINTER(CsrStruct), _VP, C.c_int, _VP, C.c_int32, _VP, C.c_size_t, _VP]),
     "gnnrag_layer_workspace_bytes": (C.c_size_t, [C.POINTER(CsrStruct), C.c_int32, C.c_int32]),
+    "gnnrag_stack_workspace_bytes": (C.c_size_t, [C.POINTER(CsrStruct), C.c_int32, C.c_int32, C.c_int32]),
+    "gnnrag_rel_transform": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.POINTER(LayerParams), C.c_int32, _VP,
+                                      _VP]),
     "gnnrag_reason_layer": (C.c_int, [C.POINTER(CsrStruct)] + [_VP] * 9 + [C.c_int32] + [_VP] * 8 +
                             [_VP, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP]),
     "gnnrag_reason_stack": (C.c_int, [C.POINTER(CsrStruct), C.c_int32, C.POINTER(LayerParams)] + [_VP] * 5 +
@@ -99,7 +102,7 @@ SIGNATURES = {
     "gnnrag_error_string": (C.c_char_p, [C.c_int]),
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 PATH_AUTO, PATH_UNFUSED, PATH_FUSED = 0, 1, 2
 E_TUPLE = -4
 _lib = None

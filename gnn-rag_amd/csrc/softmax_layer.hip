@@ -97,8 +97,8 @@ static LayerWs layer_ws(const gnnrag_csr* csr, int32_t D, int32_t I) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   const size_t BN = (size_t)csr->B * csr->N;
-  w.T_fwd = take((size_t)csr->R1 * D * sizeof(float));
-  w.T_inv = take((size_t)csr->R1 * D * sizeof(float));
+  w.T_fwd = take((size_t)2 * csr->R1 * D * sizeof(float));          // [2][R1][D]: forward, inverse
+  w.T_inv = w.T_fwd + (size_t)csr->R1 * D * sizeof(float);
   // the two paths never run in the same call: their big buffers share one region
   const size_t a_bytes = BN * 2 * I * D * sizeof(float);
   const size_t p_bytes = align_up((size_t)2 * (csr->rel_total > 0 ? csr->rel_total : 1) * D * sizeof(float), 256);
@@ -141,29 +141,14 @@ extern "C" size_t gnnrag_layer_workspace_bytes(const gnnrag_csr* csr, int32_t D,
   return layer_ws(csr, D, I).total;
 }
 
-extern "C" int gnnrag_reason_layer(const gnnrag_csr* csr, const float* h, const float* dist, const float* ins,
-                                   const float* relfeat_fwd, const float* relfeat_inv, const float* W_rel,
-                                   const float* b_rel, const float* pos_fwd, const float* pos_inv,
-                                   int32_t pos_rows, const float* W_e2e, const float* b_e2e,
-                                   const float* w_score, const float* b_score, const float* mask,
-                                   float* h_out, float* score_out, float* dist_out, void* workspace,
-                                   size_t workspace_bytes, int32_t D, int32_t I, int32_t path, int32_t math,
-                                   gnnrag_stream_t stream) {
-  if (!csr || !h || !dist || !ins || !relfeat_fwd || !relfeat_inv || !W_rel || !b_rel || !W_e2e || !b_e2e ||
-      !w_score || !b_score || !mask || !h_out || !score_out || !dist_out || !workspace || D <= 0 || I <= 0)
-    return GNNRAG_E_BADARG;
-  if (path < GNNRAG_PATH_AUTO || path > GNNRAG_PATH_FUSED) return GNNRAG_E_BADARG;
-  const LayerWs w = layer_ws(csr, D, I);
-  if (workspace_bytes < w.total) return GNNRAG_E_WORKSPACE;
-  char* base = (char*)workspace;
-  float* T_fwd = (float*)(base + w.T_fwd);
-  float* T_inv = (float*)(base + w.T_inv);
+// one layer behind its relation projections T_fwd / T_inv (already computed)
+static int layer_body(const gnnrag_csr* csr, const LayerWs& w, char* base, const float* h, const float* dist,
+                      const float* ins, const float* T_fwd, const float* T_inv, const float* W_e2e,
+                      const float* b_e2e, const float* w_score, const float* b_score, const float* mask,
+                      float* h_out, float* score_out, float* dist_out, int32_t D, int32_t I, int32_t path,
+                      int32_t math, gnnrag_stream_t stream) {
   const int64_t BN = (int64_t)csr->B * csr->N;
   int rc;
-  // T_d = rel_linear(rel_features_d) (+ pos_emb_d): once per relation row, not once per fact
-  rc = gnnrag_linear_pair(relfeat_fwd, relfeat_inv, csr->R1, D, W_rel, b_rel, pos_fwd, pos_inv,
-                          pos_fwd ? pos_rows : 0, T_fwd, T_inv, D, math, stream);
-  if (rc) return rc;
   if (path == GNNRAG_PATH_AUTO)
     path = fused_is_cheaper(csr->B, csr->N, csr->rel_total, D, I) ? GNNRAG_PATH_FUSED : GNNRAG_PATH_UNFUSED;
   if (path == GNNRAG_PATH_FUSED) {
@@ -187,14 +172,79 @@ extern "C" int gnnrag_reason_layer(const gnnrag_csr* csr, const float* h, const 
   return gnnrag_masked_softmax(score_out, dist_out, csr->B, csr->N, stream);
 }
 
+// T[j][d] = rel_linear{j}(rel_features_d) (+ pos_emb{j}_d) for n layers into T [n][2][R1][D]: once per relation
+// row, not once per fact; all layers in one launch when the float4 kernel applies (rel_transform.hip)
+static int rel_projections(const gnnrag_csr* csr, int32_t n, const gnnrag_layer_params* layers,
+                           const float* relfeat_fwd, const float* relfeat_inv, int32_t pos_rows, float* T, int32_t D,
+                           int32_t math, gnnrag_stream_t stream) {
+  if ((D & 3) == 0) return gnnrag_rel_transform(relfeat_fwd, relfeat_inv, csr->R1, D, n, layers, pos_rows, T, stream);
+  const size_t RD = (size_t)csr->R1 * D;
+  for (int j = 0; j < n; ++j) {
+    const gnnrag_layer_params& p = layers[j];
+    const int rc = gnnrag_linear_pair(relfeat_fwd, relfeat_inv, csr->R1, D, p.W_rel, p.b_rel, p.pos_fwd, p.pos_inv,
+                                      p.pos_fwd ? pos_rows : 0, T + 2 * j * RD, T + (2 * j + 1) * RD, D, math, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" size_t gnnrag_stack_workspace_bytes(const gnnrag_csr* csr, int32_t L, int32_t D, int32_t I) {
+  if (!csr || L <= 0 || D <= 0 || I <= 0) return 0;
+  // one layer's workspace + the relation projections of all L layers (one contiguous block, computed up front)
+  return layer_ws(csr, D, I).total + align_up((size_t)L * 2 * csr->R1 * D * sizeof(float), 256);
+}
+
+extern "C" int gnnrag_reason_layer(const gnnrag_csr* csr, const float* h, const float* dist, const float* ins,
+                                   const float* relfeat_fwd, const float* relfeat_inv, const float* W_rel,
+                                   const float* b_rel, const float* pos_fwd, const float* pos_inv,
+                                   int32_t pos_rows, const float* W_e2e, const float* b_e2e,
+                                   const float* w_score, const float* b_score, const float* mask,
+                                   float* h_out, float* score_out, float* dist_out, void* workspace,
+                                   size_t workspace_bytes, int32_t D, int32_t I, int32_t path, int32_t math,
+                                   gnnrag_stream_t stream) {
+  if (!csr || !h || !dist || !ins || !relfeat_fwd || !relfeat_inv || !W_rel || !b_rel || !W_e2e || !b_e2e ||
+      !w_score || !b_score || !mask || !h_out || !score_out || !dist_out || !workspace || D <= 0 || I <= 0)
+    return GNNRAG_E_BADARG;
+  if (path < GNNRAG_PATH_AUTO || path > GNNRAG_PATH_FUSED) return GNNRAG_E_BADARG;
+  const LayerWs w = layer_ws(csr, D, I);
+  if (workspace_bytes < w.total) return GNNRAG_E_WORKSPACE;
+  char* base = (char*)workspace;
+  float* T_fwd = (float*)(base + w.T_fwd);
+  float* T_inv = (float*)(base + w.T_inv);
+  const gnnrag_layer_params p = {W_rel, b_rel, pos_fwd, pos_inv, W_e2e, b_e2e};
+  const int rc = rel_projections(csr, 1, &p, relfeat_fwd, relfeat_inv, pos_rows, T_fwd, D, math, stream);
+  if (rc) return rc;
+  return layer_body(csr, w, base, h, dist, ins, T_fwd, T_inv, W_e2e, b_e2e, w_score, b_score, mask, h_out, score_out,
+                    dist_out, D, I, path, math, stream);
+}
+
 extern "C" int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnrag_layer_params* layers,
                                    const float* h0, const float* dist0, const float* ins,
                                    const float* relfeat_fwd, const float* relfeat_inv, int32_t pos_rows,
                                    const float* w_score, const float* b_score, const float* mask, float* h_out,
                                    float* score_out, float* dist_out, void* workspace, size_t workspace_bytes,
                                    int32_t D, int32_t I, int32_t path, int32_t math, gnnrag_stream_t stream) {
-  if (!csr || L <= 0 || !layers || !h0 || !dist0 || !h_out || !score_out || !dist_out) return GNNRAG_E_BADARG;
+  if (!csr || L <= 0 || !layers || !h0 || !dist0 || !ins || !relfeat_fwd || !relfeat_inv || !w_score || !b_score ||
+      !mask || !h_out || !score_out || !dist_out || !workspace || D <= 0 || I <= 0)
+    return GNNRAG_E_BADARG;
+  if (path < GNNRAG_PATH_AUTO || path > GNNRAG_PATH_FUSED) return GNNRAG_E_BADARG;
+  for (int j = 0; j < L; ++j)
+    if (!layers[j].W_rel || !layers[j].b_rel || !layers[j].W_e2e || !layers[j].b_e2e) return GNNRAG_E_BADARG;
+  const LayerWs w = layer_ws(csr, D, I);
+  if (workspace_bytes < w.total) return GNNRAG_E_WORKSPACE;
+  char* base = (char*)workspace;
   const size_t BN = (size_t)csr->B * csr->N;
+  const size_t RD = (size_t)csr->R1 * D;
+  // with a gnnrag_stack_workspace_bytes workspace the relation projections of ALL layers are computed first, in one
+  // launch (they depend on neither the node state nor the distribution), into the [L][2][R1][D] block behind the
+  // layer workspace; with a layer-sized workspace each layer projects its own in front of its kernels
+  const bool upfront = L > 1 && workspace_bytes >= gnnrag_stack_workspace_bytes(csr, L, D, I);
+  float* T0 = (float*)(base + w.T_fwd);
+  float* Tall = (float*)(base + w.total);
+  if (upfront) {
+    const int rc = rel_projections(csr, L, layers, relfeat_fwd, relfeat_inv, pos_rows, Tall, D, math, stream);
+    if (rc) return rc;
+  }
   const float* h = h0;
   const float* dist = dist0;
   for (int j = 0; j < L; ++j) {
@@ -202,9 +252,13 @@ extern "C" int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnra
     float* hj = h_out + (size_t)j * BN * D;
     float* sj = score_out + (size_t)j * BN;
     float* dj = dist_out + (size_t)j * BN;
-    const int rc = gnnrag_reason_layer(csr, h, dist, ins, relfeat_fwd, relfeat_inv, p.W_rel, p.b_rel, p.pos_fwd,
-                                       p.pos_inv, pos_rows, p.W_e2e, p.b_e2e, w_score, b_score, mask, hj, sj, dj,
-                                       workspace, workspace_bytes, D, I, path, math, stream);
+    float* T = upfront ? Tall + (size_t)j * 2 * RD : T0;
+    if (!upfront) {
+      const int rc = rel_projections(csr, 1, &p, relfeat_fwd, relfeat_inv, pos_rows, T, D, math, stream);
+      if (rc) return rc;
+    }
+    const int rc = layer_body(csr, w, base, h, dist, ins, T, T + RD, p.W_e2e, p.b_e2e, w_score, b_score, mask, hj, sj,
+                              dj, D, I, path, math, stream);
     if (rc) return rc;
     h = hj;
     dist = dj;

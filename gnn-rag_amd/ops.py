@@ -305,6 +305,38 @@ def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out
 
 
+def rel_transform(relfeat: torch.Tensor, relfeat_inv: torch.Tensor, layers) -> torch.Tensor:
+    """Relation projections of all layers in one launch (reasongnn.py:75-79, :102-105):
+    ``out[j, d] = rel_linear{j}(rel_features_d) (+ pos_emb{j}_d on its rows)``, d = 0 forward / 1 inverse.
+    ``layers``: sequence of (W_rel [D,D], b_rel [D], pos_emb.weight or None, pos_emb_inv.weight or None).
+    Returns [L, 2, R1, D]."""
+    lib = _lib.load()
+    relfeat = _chk(relfeat, "rel_features")
+    R1, D = relfeat.shape
+    relfeat_inv = _chk(relfeat_inv, "rel_features_inv", shape=(R1, D))
+    L = len(layers)
+    params = (_lib.LayerParams * max(L, 1))()
+    keep, pos_rows = [], 0
+    for j, (W, b, pos, pos_inv) in enumerate(layers):
+        W = _chk(W, "rel_linear.weight", shape=(D, D))
+        b = _chk(b, "rel_linear.bias", shape=(D,))
+        keep += [W, b]
+        params[j].W_rel, params[j].b_rel = W.data_ptr(), b.data_ptr()
+        if pos is not None:
+            pos = _chk(pos, "pos_emb.weight")
+            pos_inv = _chk(pos_inv, "pos_emb_inv.weight", shape=tuple(pos.shape))
+            if pos.shape[1] != D or (pos_rows and pos.shape[0] != pos_rows):
+                raise ValueError("pos_emb must be [rows, D], the same size in every layer")
+            pos_rows = pos.shape[0]
+            keep += [pos, pos_inv]
+            params[j].pos_fwd, params[j].pos_inv = pos.data_ptr(), pos_inv.data_ptr()
+    out = torch.empty((L, 2, R1, D), dtype=torch.float32, device=relfeat.device)
+    with torch.cuda.device(relfeat.device):
+        _lib.check(lib.gnnrag_rel_transform(relfeat.data_ptr(), relfeat_inv.data_ptr(), R1, D, L, params, pos_rows,
+                                            out.data_ptr(), _stream()), "gnnrag_rel_transform")
+    return out
+
+
 def aggregate(plan: CsrPlan, dist: torch.Tensor, ins: torch.Tensor, T_fwd: torch.Tensor,
               T_inv: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
@@ -598,7 +630,8 @@ class LayerStack:
             pr.pos_fwd, pr.pos_inv = (t[4].data_ptr(), t[5].data_ptr()) if pos is not None else (None, None)
         self._keep = keep                                        # the tensors behind the raw pointers stay alive
         self.device = relfeat.device
-        nbytes = max(lib.gnnrag_layer_workspace_bytes(C.byref(plan.c), D, self.I), 256)
+        # the stack-sized workspace: relation projections of all L layers up front in one launch
+        nbytes = max(lib.gnnrag_stack_workspace_bytes(C.byref(plan.c), self.L, D, self.I), 256)
         self._ws_buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self._graph = None
         self.h = self.score = self.dist = None                   # graph mode: the fixed buffers of the captured sequence

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GNNRAG_ABI_VERSION 6
+#define GNNRAG_ABI_VERSION 7
 
 #define GNNRAG_E_BADARG      (-1)  /* null pointer / negative size / inconsistent sizes   */
 #define GNNRAG_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set (see DESIGN)  */
@@ -290,6 +290,18 @@ typedef struct gnnrag_layer_params {
   const float* W_e2e;    /* e2e_linear{j}.weight [D, (2I+1) D]               */
   const float* b_e2e;    /* e2e_linear{j}.bias [D]                           */
 } gnnrag_layer_params;
+/* Workspace of gnnrag_reason_stack that lets it compute the relation projections of all L layers up front in ONE
+ * launch (gnnrag_layer_workspace_bytes + an [L][2][R1][D] block).  With only gnnrag_layer_workspace_bytes the stack
+ * call still works and projects per layer (same results bit for bit). */
+size_t gnnrag_stack_workspace_bytes(const gnnrag_csr* csr, int32_t L, int32_t D, int32_t I);
+
+/* T_out[j][d][r, :] = rel_linear{j}(rel_features_d[r, :]) (+ pos_emb{j}_d[r, :] for r < pos_rows), j < L, d = 0
+ * forward / 1 inverse (reasongnn.py:75-79, :102-105): the relation projections of all layers in one launch, exact
+ * fp32 on the matrix cores.  `layers` is a HOST array (only W_rel, b_rel, pos_fwd, pos_inv are read; pos_* are
+ * ignored when pos_rows == 0).  D % 4 == 0, else GNNRAG_E_UNSUPPORTED.  T_out: [L, 2, R1, D] floats. */
+int gnnrag_rel_transform(const float* relfeat_fwd, const float* relfeat_inv, int64_t R1, int32_t D, int32_t L,
+                         const gnnrag_layer_params* layers, int32_t pos_rows, float* T_out, gnnrag_stream_t stream);
+
 int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnrag_layer_params* layers,
                         const float* h0, const float* dist0, const float* ins,
                         const float* relfeat_fwd, const float* relfeat_inv, int32_t pos_rows,

@@ -115,6 +115,32 @@ def test_linear_vs_fp64(dev, M, K, Nout, with_add, relu):
     np.testing.assert_allclose(got, want, rtol=0, atol=5e-6 * np.sqrt(K))
 
 
+@pytest.mark.parametrize("R1,D,L,pos_rows", [(602, 200, 3, 0), (602, 200, 3, 602), (12, 56, 2, 7), (1, 8, 1, 0),
+                                             (6106, 200, 4, 0), (130, 36, 9, 130)])
+def test_rel_transform_all_layers_in_one_launch_vs_fp64(dev, R1, D, L, pos_rows):
+    """gnnrag_rel_transform (k_rel_transform): rel_linear{j}(rel_features_d) (+ pos_emb{j}_d) for every layer j and
+    both directions from one launch (L = 9 takes two launches), against fp64; reasongnn.py:75-79, :102-105."""
+    from gnnrag_amd import ops
+    rng = np.random.default_rng(R1 + D + L)
+    A = [rng.standard_normal((R1, D)).astype(np.float32) for _ in range(2)]
+    layers, want = [], np.zeros((L, 2, R1, D))
+    for j in range(L):
+        W = (rng.standard_normal((D, D)) / np.sqrt(D)).astype(np.float32)
+        b = rng.standard_normal(D).astype(np.float32)
+        pos = [rng.standard_normal((pos_rows, D)).astype(np.float32) for _ in range(2)] if pos_rows else [None, None]
+        for d in range(2):
+            want[j, d] = A[d].astype(np.float64) @ W.astype(np.float64).T + b
+            if pos_rows:
+                want[j, d, :pos_rows] += pos[d]
+        layers.append(tuple(None if x is None else torch.from_numpy(x).to(dev) for x in (W, b, pos[0], pos[1])))
+    got = ops.rel_transform(torch.from_numpy(A[0]).to(dev), torch.from_numpy(A[1]).to(dev), layers).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=5e-6 * np.sqrt(D))
+    # the skinny k-tiled kernel the projections ran on before (same exact-fp32 matrix-core arithmetic class)
+    old = ops.linear(torch.from_numpy(A[1]).to(dev), layers[-1][0], layers[-1][1], layers[-1][3],
+                     math=ops.MATH_FP32).cpu().numpy()
+    np.testing.assert_allclose(got[-1, 1], old, rtol=0, atol=2e-6 * np.sqrt(D))
+
+
 def _to_dev(dev, *arrs):
     return [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in arrs]
 
