@@ -87,7 +87,9 @@ SIGNATURES = {
     "gnnrag_layer_workspace_bytes": (C.c_size_t, [C.POINTER(CsrStruct), C.c_int32, C.c_int32]),
     "gnnrag_stack_workspace_bytes": (C.c_size_t, [C.POINTER(CsrStruct), C.c_int32, C.c_int32, C.c_int32]),
     "gnnrag_rel_transform": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.POINTER(LayerParams), C.c_int32, _VP,
-                                      _VP]),
+                                      _VP, _VP]),
+    "gnnrag_rel_planes_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "gnnrag_relation_tables_planes": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, C.c_int32, C.c_int32, _VP]),
     "gnnrag_reason_layer": (C.c_int, [C.POINTER(CsrStruct)] + [_VP] * 9 + [C.c_int32] + [_VP] * 8 +
                             [_VP, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP]),
     "gnnrag_reason_stack": (C.c_int, [C.POINTER(CsrStruct), C.c_int32, C.POINTER(LayerParams)] + [_VP] * 5 +

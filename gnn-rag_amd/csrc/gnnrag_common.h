@@ -91,6 +91,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 int tables_b3_launch(const gnnrag_csr* csr, const float* T_fwd, const float* T_inv, const float* ins, const float* W,
                      float* P, int32_t D, int32_t I, hipStream_t stream);
 
+// relation tables from pre-split relation planes (written by gnnrag_rel_transform) and per-question weights
+// (tables_b3.hip, "V form"); planes: [2 directions][3 planes][R1][896 B] of ONE layer
+size_t tables_vq_planes_bytes(int64_t R1);
+bool tables_vq_shape_ok(int32_t D, int32_t I);
+int tables_vq_launch(const gnnrag_csr* csr, const void* planes, const float* ins, const float* W, float* P, int32_t D,
+                     int32_t I, hipStream_t stream);
+
 // the self-block update in bf16x3 on the W-resident kernel of tables_b3.hip (score must be writable scratch: it is
 // zeroed and accumulated by two atomic adds per row); GNNRAG_E_UNSUPPORTED outside its shapes
 int update_b3_launch(const float* h, const float* nbr, const float* W, const float* b, const float* w_s, const float* b_s,

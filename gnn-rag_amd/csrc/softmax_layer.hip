@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_stream_copy(const f32x4* __restrict__ s
   for (; i < n4; i += stride) dst[i] = src[i];
 }
 
-struct LayerWs { size_t T_fwd, T_inv, agg, P, nbr, partial, partial_bytes, total; };
+struct LayerWs { size_t T_fwd, T_inv, planes, agg, P, nbr, partial, partial_bytes, total; };
 
 // flops of the dense part per layer call: unfused = one [BN,(2I+1)D]x[(2I+1)D,D] GEMM; fused = the
 // per-question relation tables [2*rel_total, I*D]x[I*D, D] (rel_total = sum over questions of the
@@ -99,6 +99,8 @@ static LayerWs layer_ws(const gnnrag_csr* csr, int32_t D, int32_t I) {
   const size_t BN = (size_t)csr->B * csr->N;
   w.T_fwd = take((size_t)2 * csr->R1 * D * sizeof(float));          // [2][R1][D]: forward, inverse
   w.T_inv = w.T_fwd + (size_t)csr->R1 * D * sizeof(float);
+  // bf16 planes of relu(+-T) for the V form of the relation tables (one layer), where that kernel's shapes apply
+  w.planes = take(tables_vq_shape_ok(D, I) ? tables_vq_planes_bytes(csr->R1) : 0);
   // the two paths never run in the same call: their big buffers share one region
   const size_t a_bytes = BN * 2 * I * D * sizeof(float);
   const size_t p_bytes = align_up((size_t)2 * (csr->rel_total > 0 ? csr->rel_total : 1) * D * sizeof(float), 256);
@@ -143,7 +145,7 @@ extern "C" size_t gnnrag_layer_workspace_bytes(const gnnrag_csr* csr, int32_t D,
 
 // one layer behind its relation projections T_fwd / T_inv (already computed)
 static int layer_body(const gnnrag_csr* csr, const LayerWs& w, char* base, const float* h, const float* dist,
-                      const float* ins, const float* T_fwd, const float* T_inv, const float* W_e2e,
+                      const float* ins, const float* T_fwd, const float* T_inv, const void* planes, const float* W_e2e,
                       const float* b_e2e, const float* w_score, const float* b_score, const float* mask,
                       float* h_out, float* score_out, float* dist_out, int32_t D, int32_t I, int32_t path,
                       int32_t math, gnnrag_stream_t stream) {
@@ -154,7 +156,10 @@ static int layer_body(const gnnrag_csr* csr, const LayerWs& w, char* base, const
   if (path == GNNRAG_PATH_FUSED) {
     float* P = (float*)(base + w.P);
     float* nbr = (float*)(base + w.nbr);
-    rc = gnnrag_relation_tables(csr, T_fwd, T_inv, ins, W_e2e, P, D, I, math, stream);
+    rc = GNNRAG_E_UNSUPPORTED;
+    if (planes && math != GNNRAG_MATH_FP32 && csr->rel_total > 0)
+      rc = tables_vq_launch(csr, planes, ins, W_e2e, P, D, I, (hipStream_t)stream);
+    if (rc == GNNRAG_E_UNSUPPORTED) rc = gnnrag_relation_tables(csr, T_fwd, T_inv, ins, W_e2e, P, D, I, math, stream);
     if (rc) return rc;
     rc = gnnrag_aggregate_fused(csr, dist, P, nbr, D, base + w.partial, w.partial_bytes, stream);
     if (rc) return rc;
@@ -175,9 +180,13 @@ static int layer_body(const gnnrag_csr* csr, const LayerWs& w, char* base, const
 // T[j][d] = rel_linear{j}(rel_features_d) (+ pos_emb{j}_d) for n layers into T [n][2][R1][D]: once per relation
 // row, not once per fact; all layers in one launch when the float4 kernel applies (rel_transform.hip)
 static int rel_projections(const gnnrag_csr* csr, int32_t n, const gnnrag_layer_params* layers,
-                           const float* relfeat_fwd, const float* relfeat_inv, int32_t pos_rows, float* T, int32_t D,
-                           int32_t math, gnnrag_stream_t stream) {
-  if ((D & 3) == 0) return gnnrag_rel_transform(relfeat_fwd, relfeat_inv, csr->R1, D, n, layers, pos_rows, T, stream);
+                           const float* relfeat_fwd, const float* relfeat_inv, int32_t pos_rows, float* T,
+                           void* planes, int32_t D, int32_t math, gnnrag_stream_t stream) {
+  if ((D & 3) == 0) {
+    const int rc = gnnrag_rel_transform(relfeat_fwd, relfeat_inv, csr->R1, D, n, layers, pos_rows, T, planes, stream);
+    // (unaligned operands: the k-tiled kernel below; the caller's planes stay unwritten, so it must not use them)
+    if (rc != GNNRAG_E_UNSUPPORTED || planes) return rc;
+  }
   const size_t RD = (size_t)csr->R1 * D;
   for (int j = 0; j < n; ++j) {
     const gnnrag_layer_params& p = layers[j];
@@ -191,7 +200,9 @@ static int rel_projections(const gnnrag_csr* csr, int32_t n, const gnnrag_layer_
 extern "C" size_t gnnrag_stack_workspace_bytes(const gnnrag_csr* csr, int32_t L, int32_t D, int32_t I) {
   if (!csr || L <= 0 || D <= 0 || I <= 0) return 0;
   // one layer's workspace + the relation projections of all L layers (one contiguous block, computed up front)
-  return layer_ws(csr, D, I).total + align_up((size_t)L * 2 * csr->R1 * D * sizeof(float), 256);
+  // + their bf16 planes where the V-form tables kernel applies
+  return layer_ws(csr, D, I).total + align_up((size_t)L * 2 * csr->R1 * D * sizeof(float), 256) +
+         align_up(tables_vq_shape_ok(D, I) ? (size_t)L * tables_vq_planes_bytes(csr->R1) : 0, 256);
 }
 
 extern "C" int gnnrag_reason_layer(const gnnrag_csr* csr, const float* h, const float* dist, const float* ins,
@@ -212,9 +223,14 @@ extern "C" int gnnrag_reason_layer(const gnnrag_csr* csr, const float* h, const 
   float* T_fwd = (float*)(base + w.T_fwd);
   float* T_inv = (float*)(base + w.T_inv);
   const gnnrag_layer_params p = {W_rel, b_rel, pos_fwd, pos_inv, W_e2e, b_e2e};
-  const int rc = rel_projections(csr, 1, &p, relfeat_fwd, relfeat_inv, pos_rows, T_fwd, D, math, stream);
+  // the planes are only worth writing when the fused path with a bf16x3 product will read them
+  const bool fused = path == GNNRAG_PATH_FUSED ||
+                     (path == GNNRAG_PATH_AUTO && fused_is_cheaper(csr->B, csr->N, csr->rel_total, D, I));
+  void* planes = fused && math != GNNRAG_MATH_FP32 && tables_vq_shape_ok(D, I) && csr->rel_total >= 1024
+                     ? (void*)(base + w.planes) : nullptr;
+  const int rc = rel_projections(csr, 1, &p, relfeat_fwd, relfeat_inv, pos_rows, T_fwd, planes, D, math, stream);
   if (rc) return rc;
-  return layer_body(csr, w, base, h, dist, ins, T_fwd, T_inv, W_e2e, b_e2e, w_score, b_score, mask, h_out, score_out,
+  return layer_body(csr, w, base, h, dist, ins, T_fwd, T_inv, planes, W_e2e, b_e2e, w_score, b_score, mask, h_out, score_out,
                     dist_out, D, I, path, math, stream);
 }
 
@@ -241,8 +257,14 @@ extern "C" int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnra
   const bool upfront = L > 1 && workspace_bytes >= gnnrag_stack_workspace_bytes(csr, L, D, I);
   float* T0 = (float*)(base + w.T_fwd);
   float* Tall = (float*)(base + w.total);
+  const bool fused = path == GNNRAG_PATH_FUSED ||
+                     (path == GNNRAG_PATH_AUTO && fused_is_cheaper(csr->B, csr->N, csr->rel_total, D, I));
+  const bool want_planes = fused && math != GNNRAG_MATH_FP32 && tables_vq_shape_ok(D, I) && csr->rel_total >= 1024;
+  const size_t plane_bytes = tables_vq_planes_bytes(csr->R1);
+  char* planes_all = base + w.total + align_up((size_t)L * 2 * RD * sizeof(float), 256);
   if (upfront) {
-    const int rc = rel_projections(csr, L, layers, relfeat_fwd, relfeat_inv, pos_rows, Tall, D, math, stream);
+    const int rc = rel_projections(csr, L, layers, relfeat_fwd, relfeat_inv, pos_rows, Tall,
+                                   want_planes ? planes_all : nullptr, D, math, stream);
     if (rc) return rc;
   }
   const float* h = h0;
@@ -253,11 +275,12 @@ extern "C" int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnra
     float* sj = score_out + (size_t)j * BN;
     float* dj = dist_out + (size_t)j * BN;
     float* T = upfront ? Tall + (size_t)j * 2 * RD : T0;
+    void* planes = !want_planes ? nullptr : upfront ? (void*)(planes_all + (size_t)j * plane_bytes) : (void*)(base + w.planes);
     if (!upfront) {
-      const int rc = rel_projections(csr, 1, &p, relfeat_fwd, relfeat_inv, pos_rows, T, D, math, stream);
+      const int rc = rel_projections(csr, 1, &p, relfeat_fwd, relfeat_inv, pos_rows, T, planes, D, math, stream);
       if (rc) return rc;
     }
-    const int rc = layer_body(csr, w, base, h, dist, ins, T, T + RD, p.W_e2e, p.b_e2e, w_score, b_score, mask, hj, sj,
+    const int rc = layer_body(csr, w, base, h, dist, ins, T, T + RD, planes, p.W_e2e, p.b_e2e, w_score, b_score, mask, hj, sj,
                               dj, D, I, path, math, stream);
     if (rc) return rc;
     h = hj;

@@ -23,7 +23,13 @@
 
 namespace gnnrag {
 
-constexpr int kTabTPW = 3;        // row tiles per wave and pass (accumulators in registers; 5 spill: 140 + 40 + 36 VGPRs)
+#ifndef GNNRAG_TAB_TPW
+#define GNNRAG_TAB_TPW 3
+#endif
+#ifndef GNNRAG_TAB_MINBLK
+#define GNNRAG_TAB_MINBLK 2       // waves per SIMD: one 8-wave workgroup per CU (the planes fill its LDS) = 2, 256 registers each
+#endif
+constexpr int kTabTPW = GNNRAG_TAB_TPW;        // row tiles per wave and pass (accumulators in registers; 5 spill: 140 + 40 + 36 VGPRs)
 constexpr int kTabNTH = 7;        // column tiles per column part (two parts cover up to 13 tiles = 208 columns)
 constexpr int kTabNKB = 7;        // k blocks of 32: 192 < D <= 208 (the hidden size of the BASELINE configs is 200)
 constexpr int kTabSlots = 26;     // LDS row stride of a weight plane in 16-byte slots (26 % 4 == 2: conflict free)
@@ -264,7 +270,7 @@ __device__ __forceinline__ void tables_b3_part(const TabArgs& a, unsigned char* 
   }
 }
 
-__global__ __launch_bounds__(512, 2) void k_tables_b3(TabArgs a) {
+__global__ __launch_bounds__(512, GNNRAG_TAB_MINBLK) void k_tables_b3(TabArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int NT = (a.D + 15) >> 4;
   const int h = blockIdx.z;
@@ -287,6 +293,248 @@ __global__ __launch_bounds__(512, 2) void k_tables_b3(TabArgs a) {
     default: break;
   }
 #undef GNNRAG_TAB_CASE
+}
+
+// ---- relation tables from PRE-SPLIT relation planes and per-question weights ("V form") -------------------------------
+// relu(t * q) = max(q, 0) * relu(t) + max(-q, 0) * relu(-t) for every real t, q - so with Tp = relu(T_d), Tn = relu(-T_d)
+//
+//   P[d, (b, r), :] = sum_i W_{i,d} . relu(T_d[r, :] * ins[b, i, :])  =  [Tp[r, :], Tn[r, :]] . V_{b,d}
+//   V_{b,d}[k, :]     = sum_i W_{i,d}[:, k] * max( ins[b,i,k], 0)          (rows 0 .. D-1,   "half" 0)
+//   V_{b,d}[D + k, :] = sum_i W_{i,d}[:, k] * max(-ins[b,i,k], 0)          (rows D .. 2D-1,  "half" 1)
+//
+// The left operand no longer depends on the question: its three bf16 planes are written ONCE per layer by the relation
+// projection kernel (rel_transform.hip: a few hundred rows, L2 resident) and arrive in the MFMA loop as ready 16-byte
+// fragments - no multiply / relu / 3-way split beside the MFMAs (the VALU work that held k_tables_b3 at ~1/3 of the
+// matrix rate; a packed-fp32 VALU instruction beside MFMAs costs far more than its issue slot on this chip), and the
+// k extent is 2 D for every number of instructions I.  The question moves into the RIGHT operand: workgroup =
+// (question, row chunk, direction, column part); it builds V's three planes for its column part and one half at a
+// time in LDS (I weight blocks x the question's instruction rows; same layout as above), all row tiles of the
+// question (<= 5 per wave: one pass at C2) multiply against them with the accumulators held across both halves.
+// Same 6 plane products and fp32 accumulation as above; V is rounded to fp32 once per element before its exact split.
+constexpr int kVqHalf = 32 * kTabNKB;          // bf16 elements per half row of the relation planes (224: k >= D are zero)
+constexpr int kVqRowB = 2 * kVqHalf * 2;       // bytes per plane row: [relu(T) | relu(-T)]
+#ifndef GNNRAG_VQ_TPW
+#define GNNRAG_VQ_TPW 5
+#endif
+#ifndef GNNRAG_UPD_ABL
+#define GNNRAG_UPD_ABL 0         // timing-only ablations of k_update_b3: 1 no LDS reads, 2 no A refills, 4 no nbr
+#endif                           // loads, 8 no stores, 16 no 3-way split
+#ifndef GNNRAG_VQ_ABL
+#define GNNRAG_VQ_ABL 0          // timing-only ablations (wrong results): 1 no LDS fragment reads, 2 no A refills,
+#endif                           // 4 no V staging, 8 no epilogue stores
+#ifndef GNNRAG_VQ_UN
+#define GNNRAG_VQ_UN 3
+#endif
+constexpr int kVqTPW = GNNRAG_VQ_TPW;          // row tiles per wave and pass
+
+struct VqArgs {
+  const unsigned char* planes;   // [2 directions][3 planes][R1][kVqRowB]
+  const float* ins;              // [B, I, D]
+  const float* W;                // e2e_linear.weight [D, (2I+1) D]
+  float* P;                      // [2, M, D]
+  const int2* rows;              // [M] (question, relation id) of every compact row
+  const int* rel_off;            // [B+1] first compact row of each question
+  int32_t M, D, I, ldw, R1;
+  int32_t ct0;                   // column tiles of part 0
+  int32_t nchunk;                // row chunks per question (> 1 only when the batch has few questions)
+};
+
+// V planes of one half and one column part -> LDS:  V[n, k] = sum_i W[col0 + n, (1 + 2 i + d) D + k] * max(+-ins[g, i, k], 0)
+// UN pieces (4 k each) per thread and round; indices are recomputed rather than kept (register pressure)
+template <int CTN, int UN>
+__device__ __forceinline__ void vq_stage(const VqArgs& a, unsigned char* lds, const float* qarea, int col0, int ncol,
+                                         int d, int s) {
+  constexpr int RB = kTabSlots * 16;
+  constexpr int PL = kTabNTH * 16 * RB;
+  const int tid = threadIdx.x;
+  const int D = a.D, I = a.I, KC = D >> 2;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int total = CTN * 16 * kTabSlots * 2;               // 8-byte pieces (4 k) per plane
+  for (int base = 0; base < total; base += 512 * UN) {
+    f32x4 v[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) v[u] = zero4;
+    for (int i = 0; i < I; ++i) {
+      f32x4 w[UN];
+      const float* wsrc = a.W + (size_t)col0 * a.ldw + (1 + 2 * i + d) * D;
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int idx = base + u * 512 + tid;
+        const int j = idx / (kTabSlots * 2), kc = idx - j * (kTabSlots * 2);
+        // dead pieces (k >= D, columns past the part) read a valid address and are zeroed below
+        w[u] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)min(j, ncol - 1) * a.ldw + 4 * min(kc, KC - 1));
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int idx = base + u * 512 + tid;
+        const int kc = idx % (kTabSlots * 2);
+        f32x4 q = *reinterpret_cast<const f32x4*>(qarea + i * D + 4 * min(kc, KC - 1));
+        q = __builtin_elementwise_max(s ? -q : q, zero4);
+        v[u] += w[u] * q;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int idx = base + u * 512 + tid;
+      const int j = idx / (kTabSlots * 2), kc = idx - j * (kTabSlots * 2);
+      if (idx < total) {
+        const Split3 sp = split3(j < ncol && kc < KC ? v[u] : zero4);
+        unsigned char* dst = lds + tab_lds_row(j) * RB + kc * 8;
+        *reinterpret_cast<uint2*>(dst) = sp.hi;
+        *reinterpret_cast<uint2*>(dst + PL) = sp.mid;
+        *reinterpret_cast<uint2*>(dst + 2 * PL) = sp.lo;
+      }
+    }
+  }
+}
+
+template <int CTN>
+__device__ __forceinline__ void tables_vq_part(const VqArgs& a, unsigned char* lds, int col0) {
+  constexpr int RB = kTabSlots * 16;
+  constexpr int PL = kTabNTH * 16 * RB;
+  constexpr int NKB = kTabNKB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int d = blockIdx.y;
+  const int g = blockIdx.x / a.nchunk, ch = blockIdx.x - g * a.nchunk;
+  const int D = a.D, I = a.I;
+  const int r0 = a.rel_off[g], r1 = a.rel_off[g + 1];
+  if (r1 <= r0) return;                                       // a question without facts has no rows
+  const int ncol = min(CTN * 16, D - col0);
+  const int KC = D >> 2;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  float* P = a.P + (size_t)d * a.M * D;
+  const unsigned char* planes = a.planes + (size_t)d * 3 * a.R1 * kVqRowB;
+  const size_t plane_stride = (size_t)a.R1 * kVqRowB;
+
+  // 16-row tiles of the question start at its first row; the chunk's tiles are dealt out contiguously to the 8 waves
+  const int U = (r1 - r0 + 15) >> 4;
+  const int c0 = U * ch / a.nchunk, c1 = U * (ch + 1) / a.nchunk;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);        // scalar: the tile-count branches below stay uniform
+  const int w0 = c0 + (c1 - c0) * wv / 8, w1 = c0 + (c1 - c0) * (wv + 1) / 8;
+  const int npass = ((c1 - c0 + 7) / 8 + kVqTPW - 1) / kVqTPW;     // workgroup-uniform (the barriers below)
+
+  if (tid < 16) reinterpret_cast<unsigned*>(lds + 3 * PL)[tid] = 0u;   // slack behind the last plane stays finite
+  float* qarea = reinterpret_cast<float*>(lds + 3 * PL + 64);          // ins[g, :, :]
+  for (int x = tid * 4; x < I * D; x += 512 * 4)
+    *reinterpret_cast<f32x4*>(qarea + x) = *reinterpret_cast<const f32x4*>(a.ins + (size_t)g * I * D + x);
+
+  for (int pass = 0; pass < npass; ++pass) {
+    const int tbase = w0 + pass * kVqTPW;
+    const int ntile = max(0, min(kVqTPW, w1 - tbase));        // wave-uniform
+    f32x4 acc[kVqTPW][CTN];
+#pragma unroll
+    for (int j = 0; j < kVqTPW; ++j)
+#pragma unroll
+      for (int nt = 0; nt < CTN; ++nt) acc[j][nt] = zero4;
+    // this lane's plane row of every tile (rows past the question / the wave's run read a valid row, never stored)
+    int aoff[kVqTPW];
+#pragma unroll
+    for (int j = 0; j < kVqTPW; ++j) {
+      const int m = min(r0 + (tbase + (j < ntile ? j : 0)) * 16 + fr, r1 - 1);
+      aoff[j] = a.rows[m].y * kVqRowB + fg * 16;
+    }
+
+    for (int s = 0; s < 2; ++s) {           // (rolled: the peeled form spills ~300 registers)
+      __syncthreads();                                        // q rows staged / the previous half's fragment reads done
+      // ---- V planes of this half ----
+      if (!(GNNRAG_VQ_ABL & 4)) vq_stage<CTN, GNNRAG_VQ_UN>(a, lds, qarea, col0, ncol, d, s);
+      __syncthreads();
+
+      // ---- MFMA phase: a tile's A fragments of k block kb + 1 are requested as soon as its MFMAs of kb are issued,
+      // i.e. the other tiles' MFMAs (kVqTPW - 1 times 6 CTN) before their use ----
+      bf16x8 ap[kVqTPW][3];
+#pragma unroll
+      for (int j = 0; j < kVqTPW; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          ap[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(planes + pl * plane_stride + aoff[j] +
+                                                                                 s * (kVqHalf * 2)));
+      for (int kb = 0; kb < NKB; ++kb) {        // (not unrolled: register pressure)
+        const int kbn = min(kb + 1, NKB - 1);   // (the last block requests itself again: no branch around a load)
+        const unsigned char* wb = lds + fr * RB + kb * 64 + fg * 16;
+        constexpr int PA[6] = {1, 2, 0, 1, 0, 0};
+        constexpr int PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+        for (int j = 0; j < kVqTPW; ++j) {
+          if (j < ntile) {                                    // wave-uniform
+#pragma unroll
+            for (int nt = 0; nt < CTN; nt += 2) {
+              bf16x8 b0[3], b1[3];
+#pragma unroll
+              for (int pl = 0; pl < 3; ++pl) {
+#if GNNRAG_VQ_ABL & 1
+                b0[pl] = ap[j][pl];
+                b1[pl] = ap[j][(pl + 1) % 3];
+#else
+                b0[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + nt * 16 * RB));
+                b1[pl] = b0[pl];
+                if (nt + 1 < CTN)
+                  b1[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + (nt + 1) * 16 * RB));
+#endif
+              }
+#pragma unroll
+              for (int p = 0; p < 6; ++p) {
+                acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[j][PA[p]], b0[PB[p]], acc[j][nt], 0, 0, 0);
+                if (nt + 1 < CTN)
+                  acc[j][nt + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[j][PA[p]], b1[PB[p]], acc[j][nt + 1], 0, 0, 0);
+              }
+            }
+          }
+#if !(GNNRAG_VQ_ABL & 2)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)                      // refill: this tile's fragments of the next k block
+            ap[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(planes + pl * plane_stride + aoff[j] +
+                                                                                   s * (kVqHalf * 2) + kbn * 64));
+#endif
+        }
+      }
+    }
+
+    // ---- epilogue: the pass's tiles leave the registers (C layout: rows 4 fg + q, column slot fr) ----
+#pragma unroll
+    for (int j = 0; j < kVqTPW; ++j) {
+      if (j < ntile) {
+        const int rbase = r0 + (tbase + j) * 16 + 4 * fg;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = rbase + q;
+          if (row < r1 && (!(GNNRAG_VQ_ABL & 8) || acc[j][0][q] == 1234.5f)) {
+            float* prow = P + (size_t)row * D + col0;
+            static_assert(CTN >= 4, "a column part holds at least the interleaved group");
+            {
+              const f32x4 v = {acc[j][0][q], acc[j][1][q], acc[j][2][q], acc[j][3][q]};
+              const int c = 4 * fr;
+              if (c + 4 <= ncol) *reinterpret_cast<f32x4*>(prow + c) = v;
+              else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (c + e < ncol) prow[c + e] = v[e];
+              }
+            }
+#pragma unroll
+            for (int nt = 4; nt < CTN; ++nt) {
+              const int c = nt * 16 + fr;
+              if (c < ncol) prow[c] = acc[j][nt][q];
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void k_tables_vq(VqArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int NT = (a.D + 15) >> 4;
+  const int h = blockIdx.z;
+  const int ctn = h == 0 ? a.ct0 : NT - a.ct0;
+  const int col0 = h == 0 ? 0 : a.ct0 * 16;
+  switch (ctn) {
+    case 6: tables_vq_part<6>(a, lds, col0); break;
+    case 7: tables_vq_part<7>(a, lds, col0); break;
+    default: break;
+  }
 }
 
 // ---- the self-block update in bf16x3 on the same weight-plane layout -------------------------------------------------
@@ -392,9 +640,15 @@ __device__ __forceinline__ void update_b3_part(const UpdB3Args& a, unsigned char
     for (int q = 0; q < 4; ++q) {
       const int row = min(rbase + q, a.M - 1);
       const float* arow = a.add + (size_t)row * D + col0;
+#if GNNRAG_UPD_ABL & 4
+      addg[q] = zero4;
+#pragma unroll
+      for (int nt = 4; nt < CTN; ++nt) addt[nt - 4][q] = 0.f;
+#else
       addg[q] = *reinterpret_cast<const f32x4*>(arow + min(4 * fr, ncol - 4));
 #pragma unroll
       for (int nt = 4; nt < CTN; ++nt) addt[nt - 4][q] = arow[min(nt * 16 + fr, ncol - 1)];
+#endif
     }
     float mrow = 0.f;
     {
@@ -412,28 +666,41 @@ __device__ __forceinline__ void update_b3_part(const UpdB3Args& a, unsigned char
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
       const bool kok = 32 * kb + 8 * fg_t <= kmax;
-      const Split3 s0 = split3(kok ? ra[kb][0] : zero4);
-      const Split3 s1 = split3(kok ? ra[kb][1] : zero4);
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       bf16x8 ap[3];
+#if GNNRAG_UPD_ABL & 16
+      ap[0] = __builtin_bit_cast(bf16x8, ra[kb][0]);
+      ap[1] = __builtin_bit_cast(bf16x8, ra[kb][1]);
+      ap[2] = __builtin_bit_cast(bf16x8, ra[kb][0] + ra[kb][1]);
+#else
+      const Split3 s0 = split3(kok ? ra[kb][0] : zero4);
+      const Split3 s1 = split3(kok ? ra[kb][1] : zero4);
       ap[0] = __builtin_bit_cast(bf16x8, (u32x4){s0.hi.x, s0.hi.y, s1.hi.x, s1.hi.y});
       ap[1] = __builtin_bit_cast(bf16x8, (u32x4){s0.mid.x, s0.mid.y, s1.mid.x, s1.mid.y});
       ap[2] = __builtin_bit_cast(bf16x8, (u32x4){s0.lo.x, s0.lo.y, s1.lo.x, s1.lo.y});
+#endif
+#if !(GNNRAG_UPD_ABL & 2)
       ra[kb][0] = a_piece(tload, kb, 0);                     // refill: the next tile's k block kb
       ra[kb][1] = a_piece(tload, kb, 1);
+#endif
       const unsigned char* wb = lds + fr * RB + kb * 64 + fg_t * 16;
 #pragma unroll
       for (int nt = 0; nt < CTN; nt += 2) {
         bf16x8 b0[3], b1[3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
+#if GNNRAG_UPD_ABL & 1
+          b0[pl] = ap[pl];
+          b1[pl] = ap[(pl + 1) % 3];
+#else
           b0[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + nt * 16 * RB));
           b1[pl] = b0[pl];
           if (nt + 1 < CTN)
             b1[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + (nt + 1) * 16 * RB));
+#endif
         }
 #pragma unroll
-        for (int p = 0; p < 6; ++p) {
+        for (int p = (GNNRAG_UPD_ABL & 32 ? 3 : 0); p < 6; ++p) {
           acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[PA[p]], b0[PB[p]], acc[nt], 0, 0, 0);
           if (nt + 1 < CTN)
             acc[nt + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[PA[p]], b1[PB[p]], acc[nt + 1], 0, 0, 0);
@@ -452,7 +719,7 @@ __device__ __forceinline__ void update_b3_part(const UpdB3Args& a, unsigned char
       const int c = 4 * fr;
       if (c + 4 > ncol) {                                    // (ncol % 4 == 0: a lane's group is all in or all out)
         v = zero4;
-      } else if (row < a.M) {
+      } else if (row < a.M && (!(GNNRAG_UPD_ABL & 8) || v[0] == 1234.5f)) {
         *reinterpret_cast<f32x4*>(a.C + (size_t)row * D + col0 + c) = v;
       }
       part[q] += v[0] * ws_g[0] + v[1] * ws_g[1] + v[2] * ws_g[2] + v[3] * ws_g[3];
@@ -461,7 +728,7 @@ __device__ __forceinline__ void update_b3_part(const UpdB3Args& a, unsigned char
         const int cc = nt * 16 + fr;
         float x = fmaxf((acc[nt][q] + Bl[cc]) + addt[nt - 4][q], 0.f);
         if (cc >= ncol) x = 0.f;
-        else if (row < a.M) a.C[(size_t)row * D + col0 + cc] = x;
+        else if (row < a.M && (!(GNNRAG_UPD_ABL & 8) || x == 1234.5f)) a.C[(size_t)row * D + col0 + cc] = x;
         part[q] += x * Sl[cc];
       }
     }
@@ -493,7 +760,7 @@ __global__ __launch_bounds__(512, 2) void k_update_b3(UpdB3Args a, int nchunks) 
 int update_b3_launch(const float* h, const float* nbr, const float* W, const float* b, const float* w_s, const float* b_s,
                      const float* mask, float* h_out, float* score, int64_t BN, int32_t D, int32_t ldw,
                      hipStream_t stream) {
-  if (D % 8 || (D + 31) / 32 != kTabNKB || (D + 15) / 16 != 13 || BN < 8192 || BN >= ((int64_t)1 << 31) || ldw % 4)
+  if (D % 8 || (D + 31) / 32 != kTabNKB || (D + 15) / 16 != 13 || BN < 8192 || BN * D >= ((int64_t)1 << 31) || ldw % 4)
     return GNNRAG_E_UNSUPPORTED;
   if ((((uintptr_t)h | (uintptr_t)nbr | (uintptr_t)W | (uintptr_t)h_out) & 15) != 0) return GNNRAG_E_UNSUPPORTED;
   UpdB3Args a;
@@ -517,6 +784,46 @@ int update_b3_launch(const float* h, const float* nbr, const float* W, const flo
   }
   const int nblk = ((chunks + 7) / 8) * 16;
   hipLaunchKernelGGL(k_update_b3, dim3(nblk), dim3(512), 160 * 1024, stream, a, chunks);
+  GNNRAG_LAUNCH_CHECK();
+  return 0;
+}
+
+size_t tables_vq_planes_bytes(int64_t R1) { return (size_t)2 * 3 * R1 * kVqRowB; }
+
+bool tables_vq_shape_ok(int32_t D, int32_t I) {
+  return D % 8 == 0 && (D + 31) / 32 == kTabNKB && (D + 15) / 16 == 13 && I >= 1 &&
+         (size_t)I * D * sizeof(float) <= (size_t)kTabQBytes;
+}
+
+int tables_vq_launch(const gnnrag_csr* csr, const void* planes, const float* ins, const float* W, float* P, int32_t D,
+                     int32_t I, hipStream_t stream) {
+  if (!tables_vq_shape_ok(D, I) || csr->rel_total < 1024) return GNNRAG_E_UNSUPPORTED;
+  if ((((uintptr_t)planes | (uintptr_t)ins | (uintptr_t)W | (uintptr_t)P) & 15) != 0) return GNNRAG_E_UNSUPPORTED;
+  VqArgs a;
+  memset(&a, 0, sizeof(a));
+  a.planes = (const unsigned char*)planes; a.ins = ins; a.W = W; a.P = P;
+  a.rows = (const int2*)csr->rel_rows; a.rel_off = csr->rel_off;
+  a.M = csr->rel_total; a.D = D; a.I = I; a.ldw = (2 * I + 1) * D; a.R1 = csr->R1;
+  const int NT = (D + 15) / 16;
+  a.ct0 = (NT + 1) / 2;
+  int cus = 0;
+  {
+    const int rc = device_cu_count(&cus);
+    if (rc) return rc;
+  }
+  // one workgroup per (question, direction, column part) fills the chip from 64 questions on; smaller batches cut a
+  // question's rows into chunks (each builds the question's V again), as long as a chunk keeps >= 8 tiles
+  int nchunk = cus / (csr->B * 4);
+  const int tiles_max = (csr->rel_max + 15) / 16;
+  if (nchunk > tiles_max / 8) nchunk = tiles_max / 8;
+  if (nchunk < 1) nchunk = 1;
+  a.nchunk = nchunk;
+  static DeviceMask cap;
+  {
+    const int rc = raise_lds_cap(k_tables_vq, cap);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_tables_vq, dim3(csr->B * nchunk, 2, 2), dim3(512), 160 * 1024, stream, a);
   GNNRAG_LAUNCH_CHECK();
   return 0;
 }
@@ -559,3 +866,10 @@ int tables_b3_launch(const gnnrag_csr* csr, const float* T_fwd, const float* T_i
 }
 
 }  // namespace gnnrag
+
+extern "C" int gnnrag_relation_tables_planes(const gnnrag_csr* csr, const void* planes, const float* ins, const float* W,
+                                             float* P, int32_t D, int32_t I, gnnrag_stream_t stream) {
+  if (!csr || !planes || !ins || !W || !P || D <= 0 || I <= 0 || csr->rel_total < 0) return GNNRAG_E_BADARG;
+  if (csr->rel_total == 0) return 0;
+  return gnnrag::tables_vq_launch(csr, planes, ins, W, P, D, I, (hipStream_t)stream);
+}

@@ -305,11 +305,12 @@ def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out
 
 
-def rel_transform(relfeat: torch.Tensor, relfeat_inv: torch.Tensor, layers) -> torch.Tensor:
+def rel_transform(relfeat: torch.Tensor, relfeat_inv: torch.Tensor, layers, planes: bool = False):
     """Relation projections of all layers in one launch (reasongnn.py:75-79, :102-105):
     ``out[j, d] = rel_linear{j}(rel_features_d) (+ pos_emb{j}_d on its rows)``, d = 0 forward / 1 inverse.
     ``layers``: sequence of (W_rel [D,D], b_rel [D], pos_emb.weight or None, pos_emb_inv.weight or None).
-    Returns [L, 2, R1, D]."""
+    Returns [L, 2, R1, D]; with ``planes=True`` also the bf16 planes of relu(+-T) ([L, 2, 3, R1, 448] int16 view) that
+    :func:`relation_tables_planes` multiplies."""
     lib = _lib.load()
     relfeat = _chk(relfeat, "rel_features")
     R1, D = relfeat.shape
@@ -331,10 +332,35 @@ def rel_transform(relfeat: torch.Tensor, relfeat_inv: torch.Tensor, layers) -> t
             keep += [pos, pos_inv]
             params[j].pos_fwd, params[j].pos_inv = pos.data_ptr(), pos_inv.data_ptr()
     out = torch.empty((L, 2, R1, D), dtype=torch.float32, device=relfeat.device)
+    pl = None
+    if planes:
+        nbytes = lib.gnnrag_rel_planes_bytes(R1, D, L)
+        if nbytes == 0:
+            raise _lib.GnnragError("relation planes need a hidden size <= 224")
+        pl = torch.empty((L, 2, 3, R1, nbytes // (L * 6 * R1 * 2)), dtype=torch.int16, device=relfeat.device)
     with torch.cuda.device(relfeat.device):
         _lib.check(lib.gnnrag_rel_transform(relfeat.data_ptr(), relfeat_inv.data_ptr(), R1, D, L, params, pos_rows,
-                                            out.data_ptr(), _stream()), "gnnrag_rel_transform")
-    return out
+                                            out.data_ptr(), _ptr(pl), _stream()), "gnnrag_rel_transform")
+    return (out, pl) if planes else out
+
+
+def relation_tables_planes(plan: "CsrPlan", planes: torch.Tensor, ins: torch.Tensor, W_e2e: torch.Tensor) -> torch.Tensor:
+    """Relation tables of ONE layer in the bf16x3 math mode from its pre-split relation planes (``rel_transform(...,
+    planes=True)[1][j]``, [2, 3, R1, 448] int16): ``gnnrag_relation_tables_planes``.  Raises outside the kernel's
+    shapes (193 <= D <= 208, rel_total >= 1024)."""
+    lib = _lib.load()
+    ins = _chk(ins, "relational_ins")
+    B, I, D = ins.shape
+    if (planes.dtype != torch.int16 or tuple(planes.shape[:3]) != (2, 3, plan.R1) or not planes.is_contiguous()
+            or B != plan.B):
+        raise ValueError("planes must be a contiguous [2, 3, R1, 448] int16 tensor of this plan's relation count")
+    W_e2e = _chk(W_e2e, "e2e_linear.weight", shape=(D, (2 * I + 1) * D))
+    _on_plan_device(plan, ins, "relational_ins")
+    P = torch.empty((2, max(plan.rel_total, 1), D), dtype=torch.float32, device=ins.device)
+    with torch.cuda.device(ins.device):
+        _lib.check(lib.gnnrag_relation_tables_planes(C.byref(plan.c), planes.data_ptr(), ins.data_ptr(), W_e2e.data_ptr(),
+                                                     P.data_ptr(), D, I, _stream()), "gnnrag_relation_tables_planes")
+    return P[:, :plan.rel_total]
 
 
 def aggregate(plan: CsrPlan, dist: torch.Tensor, ins: torch.Tensor, T_fwd: torch.Tensor,

@@ -298,9 +298,24 @@ size_t gnnrag_stack_workspace_bytes(const gnnrag_csr* csr, int32_t L, int32_t D,
 /* T_out[j][d][r, :] = rel_linear{j}(rel_features_d[r, :]) (+ pos_emb{j}_d[r, :] for r < pos_rows), j < L, d = 0
  * forward / 1 inverse (reasongnn.py:75-79, :102-105): the relation projections of all layers in one launch, exact
  * fp32 on the matrix cores.  `layers` is a HOST array (only W_rel, b_rel, pos_fwd, pos_inv are read; pos_* are
- * ignored when pos_rows == 0).  D % 4 == 0, else GNNRAG_E_UNSUPPORTED.  T_out: [L, 2, R1, D] floats. */
+ * ignored when pos_rows == 0).  D % 4 == 0, else GNNRAG_E_UNSUPPORTED.  T_out: [L, 2, R1, D] floats.
+ * planes_out (may be NULL; D <= 224): gnnrag_rel_planes_bytes(R1, D, L) bytes, [L][2][3][R1][448] bf16 - per layer
+ * and direction the three planes of the exact 3-way bf16 split of [relu(T[r, :]) | relu(-T[r, :])], each half padded
+ * with zeros to 224 columns: the left operand of gnnrag_relation_tables_planes. */
+size_t gnnrag_rel_planes_bytes(int64_t R1, int32_t D, int32_t L);
 int gnnrag_rel_transform(const float* relfeat_fwd, const float* relfeat_inv, int64_t R1, int32_t D, int32_t L,
-                         const gnnrag_layer_params* layers, int32_t pos_rows, float* T_out, gnnrag_stream_t stream);
+                         const gnnrag_layer_params* layers, int32_t pos_rows, float* T_out, void* planes_out,
+                         gnnrag_stream_t stream);
+
+/* gnnrag_relation_tables in the bf16x3 math mode from ONE layer's pre-split relation planes (gnnrag_rel_transform's
+ * planes_out for that layer: [2][3][R1][448] bf16): since relu(t q) = max(q,0) relu(t) + max(-q,0) relu(-t),
+ *   P[d,row(b,r),:] = [relu(T_d[r,:]), relu(-T_d[r,:])] . V_{b,d},
+ *   V_{b,d} = [sum_i W_{i,d}^T diag(max(ins[b,i,:],0)) ; sum_i W_{i,d}^T diag(max(-ins[b,i,:],0))]   (W_{i,d} as above)
+ * - the left operand is question independent and arrives as ready matrix-core fragments, the question sits in the
+ * per-question right operand built in LDS.  Shapes: 193 <= D <= 208, D % 8 == 0, rel_total >= 1024; otherwise
+ * GNNRAG_E_UNSUPPORTED (nothing launched; use gnnrag_relation_tables). */
+int gnnrag_relation_tables_planes(const gnnrag_csr* csr, const void* planes, const float* ins, const float* W,
+                                  float* P, int32_t D, int32_t I, gnnrag_stream_t stream);
 
 int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnrag_layer_params* layers,
                         const float* h0, const float* dist0, const float* ins,

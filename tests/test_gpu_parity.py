@@ -647,6 +647,54 @@ def test_relation_tables_bf16x3_w_resident_kernel(dev, B, R, used, I, N):
     assert np.abs(Pb3 - want).max() <= TOL_INTERNAL * scale
 
 
+@pytest.mark.parametrize("B,R,used,I,N", [(4, 600, None, 2, 1200), (9, 1500, 260, 3, 1500), (64, 600, None, 2, 400),
+                                          (70, 900, 40, 1, 300)])
+def test_relation_tables_from_relation_planes(dev, B, R, used, I, N):
+    """The V form of the relation tables (k_tables_vq): relu(t q) = max(q,0) relu(t) + max(-q,0) relu(-t) moves the
+    question into a per-question right operand and leaves [relu(T), relu(-T)] as a question-independent left operand
+    whose bf16 planes the projection kernel writes.  Checks (1) the planes: hi + mid + lo == relu(+-T) EXACTLY,
+    zero padding; (2) the tables against the float64 definition and the exact-fp32 kernel - few questions (row chunks
+    per question), many questions, very different relation counts per question, 1-3 instructions."""
+    from gnnrag_amd import ops, synth
+    D = 200
+    cfg = synth.GraphConfig(name="tabv", B=B, N=N, E=6 * N, R=R, D=D, I=I, L=1, T=1, seed=B + R, rel_per_question=used,
+                            n_real_min=N // 3)
+    batch = synth.make_batch(cfg)
+    et = batch.edge_tuple
+    plan = ops.CsrPlan(et[0], et[1], et[2], cfg.B, cfg.N, cfg.R1, dev)
+    assert plan.rel_total >= 1024
+    rng = np.random.default_rng(7)
+    relf = [rng.standard_normal((cfg.R1, D)).astype(np.float32) for _ in range(2)]
+    layers = []
+    for j in range(2):
+        Wr = (rng.standard_normal((D, D)) / np.sqrt(D) * 0.4).astype(np.float32)
+        br = (0.1 * rng.standard_normal(D)).astype(np.float32)
+        layers.append((torch.from_numpy(Wr).to(dev), torch.from_numpy(br).to(dev), None, None))
+    T, planes = ops.rel_transform(torch.from_numpy(relf[0]).to(dev), torch.from_numpy(relf[1]).to(dev), layers, planes=True)
+    Tn = T.cpu().numpy()
+    pl = planes.cpu().numpy().view(np.uint16).astype(np.uint32)               # [L, 2, 3, R1, 448]
+    as_f32 = (pl << 16).view(np.float32)
+    total = as_f32[:, :, 0].astype(np.float64) + as_f32[:, :, 1] + as_f32[:, :, 2]
+    assert np.array_equal(total[..., :D], np.maximum(Tn, 0).astype(np.float64))
+    assert np.array_equal(total[..., 224:224 + D], np.maximum(-Tn, 0).astype(np.float64))
+    assert not pl[..., D:224].any() and not pl[..., 224 + D:].any()
+    ins = (0.3 * rng.standard_normal((B, I, D))).astype(np.float32)
+    W = rng.uniform(-0.05, 0.05, size=(D, (2 * I + 1) * D)).astype(np.float32)
+    dins, dW = torch.from_numpy(ins).to(dev), torch.from_numpy(W).to(dev)
+    rows = plan.rel_rows()
+    for j in (1, 0):
+        Pv = ops.relation_tables_planes(plan, planes[j], dins, dW).cpu().numpy()
+        P32 = ops.relation_tables(plan, T[j, 0], T[j, 1], dins, dW, math=ops.MATH_FP32).cpu().numpy()
+        want = np.zeros((2, plan.rel_total, D))
+        for d in range(2):
+            for i in range(I):
+                A = np.maximum(Tn[j, d][rows[:, 1]].astype(np.float64) * ins[rows[:, 0], i].astype(np.float64), 0.0)
+                want[d] += A @ W[:, (1 + 2 * i + d) * D:(2 + 2 * i + d) * D].astype(np.float64).T
+        scale = max(1.0, np.abs(want).max())
+        assert np.abs(Pv - want).max() <= TOL_INTERNAL * scale
+        assert np.abs(P32 - want).max() <= TOL_INTERNAL * scale
+
+
 @pytest.mark.parametrize("cfgname", ["tiny50", "mid"])
 def test_whole_iteration_call_and_graph_replay_are_bit_identical(dev, cfgname):
     """f-3: the L layer calls of a ReaRev iteration as ONE library call (gnnrag_reason_stack, run ahead by the module's

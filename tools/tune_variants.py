@@ -32,6 +32,14 @@ VARIANTS = {
     "abl_mem_only": {"GNNRAG_GEMM_ABL": 1 + 8},
     "timing": {"GNNRAG_GEMM_TIMING": 1},        # per-wave phase stamps of k_gemm_wres (tools/gemm_timeline_wres.py)
     "no_wres": {"GNNRAG_GEMM_WRES": 0},         # the k-tiled kernel for the self-block update
+    # timing-only ablations of k_tables_vq / k_update_b3 (tables_b3.hip).  CAUTION: the *_nolds variants feed the A
+    # fragments in place of the LDS weight fragments, which makes the column tiles' MFMA chains identical - the compiler
+    # merges them (4x fewer MFMAs): they bound nothing.  upd_halfmfma (3 of 6 plane products) is the honest MFMA probe.
+    "vq_nolds": {"GNNRAG_VQ_ABL": 1}, "vq_noa": {"GNNRAG_VQ_ABL": 2}, "vq_nostage": {"GNNRAG_VQ_ABL": 4},
+    "upd_nolds": {"GNNRAG_UPD_ABL": 1}, "upd_noa": {"GNNRAG_UPD_ABL": 2}, "upd_noadd": {"GNNRAG_UPD_ABL": 4},
+    "upd_nostore": {"GNNRAG_UPD_ABL": 8}, "upd_nosplit": {"GNNRAG_UPD_ABL": 16}, "upd_mfma_only": {"GNNRAG_UPD_ABL": 31},
+    "upd_nomem": {"GNNRAG_UPD_ABL": 14}, "upd_halfmfma": {"GNNRAG_UPD_ABL": 32}, "upd_halfmfma_nomem": {"GNNRAG_UPD_ABL": 32 + 14}, 
+    "vq_noepi": {"GNNRAG_VQ_ABL": 8}, "vq_mfma_only": {"GNNRAG_VQ_ABL": 15}, "vq_mfma_epi": {"GNNRAG_VQ_ABL": 7}, "vq_un2": {"GNNRAG_VQ_UN": 2},
 }
 
 CHILD = r'''
@@ -62,6 +70,11 @@ with torch.no_grad():
         fn = lambda: ops.aggregate_fused(layer.plan, prior, P)
         fn()
         ms[name] = float(np.mean(bench._events_ms(fn, 20)))
+    if os.environ.get("GNNRAG_TUNE_GEMM"):
+        _, planes = ops.rel_transform(devin.rel_features, devin.rel_features_inv, [(rl.weight, rl.bias, None, None)], planes=True)
+        fn = lambda: ops.relation_tables_planes(layer.plan, planes[0], devin.ins[0], e2e.weight)
+        fn()
+        ms["tables_vq"] = float(np.mean(bench._events_ms(fn, 10)))
     for math in ((0, 1) if os.environ.get("GNNRAG_TUNE_GEMM") else ()):
         ops.set_dense_math(math)
         fns = {"tables": lambda: ops.relation_tables(layer.plan, Tf, Ti, devin.ins[0], e2e.weight),
