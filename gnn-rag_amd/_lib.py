@@ -88,6 +88,8 @@ SIGNATURES = {
     "gnnrag_stack_workspace_bytes": (C.c_size_t, [C.POINTER(CsrStruct), C.c_int32, C.c_int32, C.c_int32]),
     "gnnrag_rel_transform": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.POINTER(LayerParams), C.c_int32, _VP,
                                       _VP, _VP]),
+    "gnnrag_gemm_tn_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "gnnrag_gemm_tn": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, _VP, _VP, C.c_size_t, _VP]),
     "gnnrag_rel_planes_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "gnnrag_relation_tables_planes": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, C.c_int32, C.c_int32, _VP]),
     "gnnrag_reason_layer": (C.c_int, [C.POINTER(CsrStruct)] + [_VP] * 9 + [C.c_int32] + [_VP] * 8 +
@@ -104,7 +106,7 @@ SIGNATURES = {
     "gnnrag_error_string": (C.c_char_p, [C.c_int]),
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 PATH_AUTO, PATH_UNFUSED, PATH_FUSED = 0, 1, 2
 E_TUPLE = -4
 _lib = None

@@ -4,8 +4,8 @@ Training (``Trainer_KBQA.train_epoch``, reference ``train_model.py:209-233``) di
 through ``reason_layer`` / ``reason_layer_inv`` (``reasongnn.py:61-116``) and ``TypeLayer``
 (``layer_init.py:25-62``).  Here the typed-edge aggregation and its backward are HIP kernels
 (``gnnrag_aggregate`` / ``gnnrag_aggregate_backward``, ``gnnrag_typelayer`` /
-``gnnrag_typelayer_backward``); the dense projections around them stay ``nn.Linear`` calls, which
-autograd already knows."""
+``gnnrag_typelayer_backward``); the dense projections around them run on the library's matrix-core kernels in
+both directions (:class:`LinearFn`: ``gnnrag_linear`` for y and dx, ``gnnrag_gemm_tn`` for dW)."""
 from __future__ import annotations
 
 import torch
@@ -51,3 +51,38 @@ class TypeAggFn(torch.autograd.Function):
         (h0,) = ctx.saved_tensors
         g_pre = (g_h0.float() * (h0 > 0)).contiguous()
         return None, ops.typelayer_backward(ctx.plan, g_pre, ctx.use_w_rel), None
+
+
+class LinearFn(torch.autograd.Function):
+    """``y = act(x W^T + b)`` (``nn.Linear`` + optional ReLU) on the hand-written kernels, forward and backward:
+    forward and ``dx = dy W`` are ``gnnrag_linear`` calls (the second with the transposed weight, a [K, Nout] copy of
+    a few hundred KB), ``dW = dy^T x`` is ``gnnrag_gemm_tn``; ``db`` is a column sum.  x: [M, K] fp32 contiguous."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, relu):
+        x = x.detach().float().contiguous()
+        Wd = W.detach().float().contiguous()
+        y = ops.linear(x, Wd, None if b is None else b.detach().float().contiguous(), relu=relu)
+        ctx.relu = relu
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, Wd, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, W, y = ctx.saved_tensors
+        g = gy.float()
+        if ctx.relu:
+            g = g * (y > 0)
+        g = g.contiguous()
+        gx = ops.linear(g, W.t().contiguous()) if ctx.needs_input_grad[0] else None
+        gW = ops.gemm_tn(g, x) if ctx.needs_input_grad[1] else None
+        gb = g.sum(dim=0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gW, gb, None
+
+
+def linear(x: torch.Tensor, W: torch.Tensor, b=None, relu: bool = False) -> torch.Tensor:
+    """Differentiable ``act(x W^T + b)`` over the last dimension of x on :class:`LinearFn`."""
+    shp = x.shape
+    y = LinearFn.apply(x.reshape(-1, shp[-1]), W, b, relu)
+    return y.view(*shp[:-1], W.shape[0])

@@ -21,7 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ...autograd import AggregateFn
+from ...autograd import AggregateFn, linear as ag_linear
 from .base_gnn import BaseGNNLayer
 
 VERY_NEG_NUMBER = -100000000000
@@ -55,6 +55,8 @@ class ReasonGNNLayer(BaseGNNLayer):
         # columns of every intermediate stay exactly 0 and the first D columns are what the unpadded computation
         # gives; the node state is kept padded between calls and handed to the caller as a [:, :, :D] view.
         self.pad_dim = os.environ.get("GNNRAG_PAD_DIM", "1") != "0"
+        # training: dense projections on the library's kernels forward and backward (0: nn.Linear / rocBLAS)
+        self.native_dense = os.environ.get("GNNRAG_NATIVE_DENSE", "1") != "0"
         self._padded = None
 
     def init_layers(self, args):
@@ -210,8 +212,13 @@ class ReasonGNNLayer(BaseGNNLayer):
         rel_linear = getattr(self, "rel_linear" + str(step))
         e2e_linear = getattr(self, "e2e_linear" + str(step))
         B, N, D = self.batch_size, self.max_local_entity, self.entity_dim
-        T_fwd = rel_linear(self.rel_features.float())
-        T_inv = rel_linear(self.rel_features_inv.float())
+        # the dense projections on the library's kernels in both directions (autograd.LinearFn) when their float4 /
+        # 16-byte requirements hold; nn.Linear (rocBLAS) otherwise
+        native = self.native_dense and D % 4 == 0 and self.rel_features.is_cuda
+        lin = (lambda x, m, relu=False: ag_linear(x, m.weight, m.bias, relu)) if native else \
+              (lambda x, m, relu=False: F.relu(m(x)) if relu else m(x))
+        T_fwd = lin(self.rel_features.float(), rel_linear)
+        T_inv = lin(self.rel_features_inv.float(), rel_linear)
         if self.use_posemb:
             pos = getattr(self, "pos_emb" + str(step)).weight
             pos_inv = getattr(self, "pos_emb_inv" + str(step)).weight
@@ -219,8 +226,16 @@ class ReasonGNNLayer(BaseGNNLayer):
             T_fwd = T_fwd + torch.cat([pos, pad], dim=0)
             T_inv = T_inv + torch.cat([pos_inv, pad], dim=0)
         agg = AggregateFn.apply(self.plan, current_dist.float(), relational_ins.float(), T_fwd, T_inv)
-        state = torch.cat((self.local_entity_emb.float(), agg.view(B, N, -1)), dim=2)      # [h | fwd_0 | inv_0 | ...]
-        self.local_entity_emb = F.relu(e2e_linear(self.linear_drop(state)))
+        if native:
+            # e2e_linear over cat(h, agg) as two products (no [BN, (2I+1)D] copy of the concatenation): dropout acts
+            # elementwise, so dropping the two parts separately is the same operator (reasongnn.py:161-163)
+            W = e2e_linear.weight
+            pre = ag_linear(self.linear_drop(self.local_entity_emb.float()).reshape(B * N, D), W[:, :D], e2e_linear.bias) \
+                + ag_linear(self.linear_drop(agg), W[:, D:], None)
+            self.local_entity_emb = F.relu(pre).view(B, N, D)
+        else:
+            state = torch.cat((self.local_entity_emb.float(), agg.view(B, N, -1)), dim=2)  # [h | fwd_0 | inv_0 | ...]
+            self.local_entity_emb = F.relu(e2e_linear(self.linear_drop(state)))
         mask = self.local_entity_mask
         self.possible_cand.append(mask)
         score = self.score_func(self.linear_drop(self.local_entity_emb)).squeeze(dim=2) + (1 - mask) * VERY_NEG_NUMBER

@@ -363,6 +363,24 @@ def relation_tables_planes(plan: "CsrPlan", planes: torch.Tensor, ins: torch.Ten
     return P[:, :plan.rel_total]
 
 
+def gemm_tn(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """``A^T @ B`` for two row-major operands with the same (large) row count - the weight gradient of a dense
+    projection, ``dW = dY^T X`` (``gnnrag_gemm_tn``: exact fp32 MFMA, fixed summation order)."""
+    lib = _lib.load()
+    A = _chk(A, "A")
+    B = _chk(B, "B")
+    if A.dim() != 2 or B.dim() != 2 or A.shape[0] != B.shape[0]:
+        raise ValueError("A is %s, B is %s" % (tuple(A.shape), tuple(B.shape)))
+    M, N1 = A.shape
+    N2 = B.shape[1]
+    out = torch.empty((N1, N2), dtype=torch.float32, device=A.device)
+    ws = torch.empty(max(lib.gnnrag_gemm_tn_workspace_bytes(M, N1, N2), 16), dtype=torch.uint8, device=A.device)
+    with torch.cuda.device(A.device):
+        _lib.check(lib.gnnrag_gemm_tn(A.data_ptr(), B.data_ptr(), M, N1, N2, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      _stream()), "gnnrag_gemm_tn")
+    return out
+
+
 def aggregate(plan: CsrPlan, dist: torch.Tensor, ins: torch.Tensor, T_fwd: torch.Tensor,
               T_inv: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()

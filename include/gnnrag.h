@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GNNRAG_ABI_VERSION 7
+#define GNNRAG_ABI_VERSION 8
 
 #define GNNRAG_E_BADARG      (-1)  /* null pointer / negative size / inconsistent sizes   */
 #define GNNRAG_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set (see DESIGN)  */
@@ -236,6 +236,15 @@ int gnnrag_aggregate_backward(const gnnrag_csr* csr, const gnnrag_relorder* relo
 int gnnrag_typelayer_backward(const gnnrag_csr* csr, const gnnrag_relorder* relorder, const float* g_pre,
                               const float* w_rel_per_fact, int use_w_rel, float* g_T,
                               int32_t D, void* workspace, size_t workspace_bytes, gnnrag_stream_t stream);
+
+/* Weight gradient of a dense projection (what autograd derives for nn.Linear.weight):
+ *   C[N1, N2] = A[M, N1]^T . B[M, N2]      e.g. dW = dY^T . X with A = dY [M, Nout], B = X [M, K].
+ * Exact fp32 on the matrix cores; the row range is cut into chunks whose partial blocks are added in chunk order
+ * (no atomics).  N1 % 4 == 0, N2 % 4 == 0, 16-byte aligned operands, else GNNRAG_E_UNSUPPORTED.
+ * workspace: gnnrag_gemm_tn_workspace_bytes(M, N1, N2) bytes of device scratch. */
+size_t gnnrag_gemm_tn_workspace_bytes(int64_t M, int32_t N1, int32_t N2);
+int gnnrag_gemm_tn(const float* A, const float* B, int64_t M, int32_t N1, int32_t N2, float* C,
+                   void* workspace, size_t workspace_bytes, gnnrag_stream_t stream);
 
 /* Per-question relation tables of the fused path, one row per (question b, relation r used by b):
  *   P[d,row(b,r),:] = sum_i W_e2e[:, (1+2i+d)D : (2+2i+d)D] . relu(T_d[r,:] * ins[b,i,:])   [2,rel_total,D]

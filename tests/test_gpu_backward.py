@@ -205,3 +205,47 @@ def test_training_mode_with_dropout_runs_and_is_stochastic(dev):
                 assert p.grad is not None and torch.isfinite(p.grad).all(), k
         outs.append(dist.detach().cpu().numpy())
     assert np.abs(outs[0] - outs[1]).max() > 0
+
+
+@pytest.mark.parametrize("M,N1,N2", [(1000, 200, 200), (128000, 200, 200), (4097, 200, 1000), (37, 8, 12), (1, 4, 4),
+                                      (5000, 56, 56), (70000, 200, 400)])
+def test_gemm_tn_weight_gradient_vs_fp64(dev, M, N1, N2):
+    """gnnrag_gemm_tn: dW = dY^T X (the nn.Linear weight gradient, train_model.py:209-233) against float64, incl. row
+    counts that are not a multiple of the chunk / k-step sizes and output sizes that are not a multiple of 64; the sum
+    order is fixed (two runs agree bit for bit)."""
+    from gnnrag_amd import ops
+    rng = np.random.default_rng(M + N1)
+    A = rng.standard_normal((M, N1)).astype(np.float32)
+    B = rng.standard_normal((M, N2)).astype(np.float32)
+    dA, dB = _dev(dev, A, B)
+    got = ops.gemm_tn(dA, dB)
+    want = A.astype(np.float64).T @ B.astype(np.float64)
+    _close(got.cpu().numpy(), want, 1e-5, "gemm_tn")
+    assert torch.equal(got, ops.gemm_tn(dA, dB))
+
+
+@pytest.mark.parametrize("M,K,Nout,relu,bias", [(3000, 200, 200, True, True), (513, 1000, 200, False, True),
+                                                (602, 200, 200, False, False), (9000, 200, 200, True, True)])
+def test_linear_autograd_function_matches_torch(dev, M, K, Nout, relu, bias):
+    """autograd.LinearFn (forward and dx on gnnrag_linear, dW on gnnrag_gemm_tn) against torch's own nn.Linear autograd
+    in float64."""
+    from gnnrag_amd.autograd import linear
+    rng = np.random.default_rng(K + M)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((Nout, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(Nout).astype(np.float32)
+    gy = rng.standard_normal((M, Nout)).astype(np.float32)
+    tx, tW, tb = (torch.from_numpy(v).double().requires_grad_(True) for v in (x, W, b))
+    ty = torch.nn.functional.linear(tx, tW, tb if bias else None)
+    if relu:
+        ty = torch.relu(ty)
+    ty.backward(torch.from_numpy(gy).double())
+    dx, dW, db, dgy = _dev(dev, x, W, b, gy)
+    dx.requires_grad_(True); dW.requires_grad_(True); db.requires_grad_(True)
+    y = linear(dx, dW, db if bias else None, relu)
+    y.backward(dgy)
+    _close(y.detach().cpu().numpy(), ty.detach().numpy(), TOL_KERNEL, "y")
+    _close(dx.grad.cpu().numpy(), tx.grad.numpy(), TOL_KERNEL, "dx")
+    _close(dW.grad.cpu().numpy(), tW.grad.numpy(), TOL_KERNEL, "dW")
+    if bias:
+        _close(db.grad.cpu().numpy(), tb.grad.numpy(), TOL_KERNEL, "db")
