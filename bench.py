@@ -144,17 +144,23 @@ def main():
             layer.local_entity_emb = devin.h0
             stack.run_layers(layer, cfg, devin)                   # builds layer._stack, raises launch attributes
             graph = layer._stack
-            graph.capture(devin.h0, devin.seed_dist, devin.ins[0].clone())
+            # the module runs hidden sizes that are not a multiple of 4 zero-padded (C1 / C3: 50 -> 56): the captured
+            # sequence gets the operands in that form too
+            P = layer._inference_params()
+            gpad = (lambda t: t if P["Dp"] == P["D"] else torch.nn.functional.pad(t, (0, P["Dp"] - P["D"])))
+            g_h0 = gpad(devin.h0).contiguous()
+            g_ins = [gpad(devin.ins[t]).contiguous() for t in range(cfg.T)]
+            graph.capture(g_h0, devin.seed_dist, g_ins[0].clone())
         h0_slot = graph.h[cfg.L - 1]
 
     def step():
         if graph is not None:
             # a step starts from h0 (like the eager step): the captured sequence reads its node state from h[L-1];
             # T iterations = T replays, the instructions of iteration t written into the captured buffer first
-            h0_slot.copy_(devin.h0, non_blocking=True)
+            h0_slot.copy_(g_h0.view_as(h0_slot), non_blocking=True)
             for t in range(cfg.T):
                 if cfg.T > 1:
-                    graph._graph_in[1].copy_(devin.ins[t], non_blocking=True)
+                    graph._graph_in[1].copy_(g_ins[t], non_blocking=True)
                 d = graph.replay()[2][cfg.L - 1]
         else:
             layer.local_entity_emb = devin.h0
