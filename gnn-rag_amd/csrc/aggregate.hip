@@ -431,6 +431,9 @@ __global__ __launch_bounds__(256) void k_heavy_reduce(const WalkArgs a, int na) 
 // shares them with width-4 shuffles.  Node sets are handed out by an LDS ticket so a set with a
 // hub does not hold up its wave's other sets.  All slice workgroups of a question run on one
 // XCD (workgroup b -> XCD b % 8), so their partial-line writes to out[] merge in that L2.
+#ifndef GNNRAG_SLICE_ABL
+#define GNNRAG_SLICE_ABL 0      // timing-only ablations of k_walk_slice (wrong results): 1 no table staging loads,
+#endif                          // 2 no output stores, 8 no (p, rel) pair loads
 constexpr int kSliceW = 16;                 // floats per slice (4 lanes x float4)
 constexpr int kSliceThreads = 1024;
 
@@ -492,8 +495,9 @@ __device__ __forceinline__ void set_load_first(SetRows& s, const int2* const (&p
   for (int d = 0; d < 2; ++d)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
-      s.first[d][h] = (s.valid && !s.big && 4 * h + sub < s.len[d]) ? prd[d][s.beg[d] + 4 * h + sub]
-                                                                    : make_int2(0, 0);
+      s.first[d][h] = (s.valid && !s.big && 4 * h + sub < s.len[d])
+                          ? ((GNNRAG_SLICE_ABL & 8) ? make_int2(0x3f800000, sub) : prd[d][s.beg[d] + 4 * h + sub])
+                          : make_int2(0, 0);
 }
 
 // value of lane k of this lane's quad (DPP quad_perm broadcast: VALU speed, no LDS crossbar)
@@ -644,7 +648,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
     const int r = rem / GR, k = rem % GR;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     const float* tab = a.T[d] + (size_t)roff * D;
-    if (col0 + 4 * k < D) v = *reinterpret_cast<const f32x4*>(tab + (size_t)r * D + col0 + 4 * k);
+    if (!(GNNRAG_SLICE_ABL & 1) && col0 + 4 * k < D) v = *reinterpret_cast<const f32x4*>(tab + (size_t)r * D + col0 + 4 * k);
     *reinterpret_cast<f32x4*>(Ts + ((size_t)d * Rg + r) * SW + 4 * k) = v;
   }
   __syncthreads();
@@ -756,8 +760,8 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
         int2 c0 = s0.first[d][0], c1 = s0.first[d][1];
         for (int j = 0; j < len; j += 8) {
           int2 n0 = make_int2(0, 0), n1 = make_int2(0, 0);
-          if (j + 8 + sub < len) n0 = prd[d][beg + j + 8 + sub];
-          if (j + 12 + sub < len) n1 = prd[d][beg + j + 12 + sub];
+          if (!(GNNRAG_SLICE_ABL & 8) && j + 8 + sub < len) n0 = prd[d][beg + j + 8 + sub];
+          if (!(GNNRAG_SLICE_ABL & 8) && j + 12 + sub < len) n1 = prd[d][beg + j + 12 + sub];
           slice_fma4<MODE, NI>(acc, c0, Td[d], q);
           // second half of the step only if some node of the set still has facts there (most rows of the
           // inverse direction hold one or two facts)
@@ -768,7 +772,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
         if (ND == 2 || d == 1) {
 #pragma unroll
           for (int i = 0; i < NA; ++i)
-            if (col_ok[i])
+            if (col_ok[i] && (!(GNNRAG_SLICE_ABL & 2) || acc.v[i][0] == 1234.5f))
               *reinterpret_cast<f32x4*>(slice_out<MODE>(a, s0.n, i, d, col0 + Acc::coff(i) + 4 * sub)) = acc.v[i];
           acc.zero();
         }

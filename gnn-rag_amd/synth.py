@@ -65,6 +65,8 @@ CONFIGS = {
                       n_real_min=50),
     # C2 with the full Freebase relation vocabulary of WebQSP (6105 relations), a few hundred per question
     "C2fb": GraphConfig(name="C2fb", B=64, N=2000, E=10000, R=6105, D=200, I=2, L=3, rel_per_question=300),
+    # C2 with uniformly drawn heads (no hubs): what the degree skew costs the walks (not a BASELINE config)
+    "C2u": GraphConfig(name="C2u", B=64, N=2000, E=10000, R=600, D=200, I=2, L=3, zipf_heads=False),
     # small cases for parity tests
     "tiny": GraphConfig(name="tiny", B=3, N=48, E=150, R=11, D=200, I=2, L=3),
     "tinyfb": GraphConfig(name="tinyfb", B=5, N=64, E=300, R=1500, D=200, I=2, L=3, rel_per_question=40,

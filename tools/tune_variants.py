@@ -35,6 +35,10 @@ VARIANTS = {
     # timing-only ablations of k_tables_vq / k_update_b3 (tables_b3.hip).  CAUTION: the *_nolds variants feed the A
     # fragments in place of the LDS weight fragments, which makes the column tiles' MFMA chains identical - the compiler
     # merges them (4x fewer MFMAs): they bound nothing.  upd_halfmfma (3 of 6 plane products) is the honest MFMA probe.
+    # k_walk_slice (aggregate.hip): 1 no table staging loads, 2 no output stores, 8 no pair loads; GNNRAG_TUNE_WORKLOAD=C2u
+    # runs the same on uniformly drawn heads (what the degree skew costs)
+    "sl_nostage": {"GNNRAG_SLICE_ABL": 1}, "sl_nostore": {"GNNRAG_SLICE_ABL": 2},
+    "sl_nopairs": {"GNNRAG_SLICE_ABL": 8}, "sl_nomem": {"GNNRAG_SLICE_ABL": 11},
     "vq_nolds": {"GNNRAG_VQ_ABL": 1}, "vq_noa": {"GNNRAG_VQ_ABL": 2}, "vq_nostage": {"GNNRAG_VQ_ABL": 4},
     "upd_nolds": {"GNNRAG_UPD_ABL": 1}, "upd_noa": {"GNNRAG_UPD_ABL": 2}, "upd_noadd": {"GNNRAG_UPD_ABL": 4},
     "upd_nostore": {"GNNRAG_UPD_ABL": 8}, "upd_nosplit": {"GNNRAG_UPD_ABL": 16}, "upd_mfma_only": {"GNNRAG_UPD_ABL": 31},
@@ -50,7 +54,7 @@ import gnnrag_amd
 from gnnrag_amd import ops, stack, synth
 import bench
 dev = torch.device("cuda", 0)
-cfg = synth.CONFIGS["C2"]
+cfg = synth.CONFIGS[os.environ.get("GNNRAG_TUNE_WORKLOAD", "C2")]
 batch = synth.make_batch(cfg); feats = synth.make_features(cfg); params = synth.make_layer_params(cfg)
 devin = stack.DeviceInputs(batch, feats, dev)
 layer = stack.build_layer(cfg, batch, params, dev)
