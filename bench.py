@@ -166,8 +166,21 @@ def main():
             layer.local_entity_emb = devin.h0
             d, _ = stack.run_layers(layer, cfg, devin)
         if distributed:
-            d = shard.gather_rows(d, global_B, ranges=ranges)
+            # the all-gather of this step's distribution is enqueued behind it and waited for one step later: it
+            # overlaps the next step's kernels (an evaluation loop reads batch k's result after enqueueing batch k + 1)
+            fin = shard.gather_rows_async(d, global_B, ranges=ranges)
+            prev, pending[0] = pending[0], fin
+            d = prev() if prev is not None else d
         return d
+
+    pending = [None]
+
+    def drain():
+        if pending[0] is not None:
+            out = pending[0]()
+            pending[0] = None
+            return out
+        return None
 
     for _ in range(args.warmup):
         step()
@@ -178,6 +191,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step()
+    last = drain() if distributed else last                  # the last step's all-gather is inside the timed region
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -199,6 +213,7 @@ def main():
             step()
             b.record()
         torch.cuda.synchronize()
+        drain()
         ts = np.array([a.elapsed_time(b) for a, b in evs])
         spread = {"n": int(len(ts)), "p05": float(np.percentile(ts, 5)), "p50": float(np.percentile(ts, 50)),
                   "p95": float(np.percentile(ts, 95)), "max": float(ts.max()), "mean": float(ts.mean()),

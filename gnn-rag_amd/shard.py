@@ -100,51 +100,49 @@ def shard_batch(batch: tuple, rank: int, world: int, balance: str = "count") -> 
     return tuple(out)
 
 
+def gather_rows_async(local: torch.Tensor, B: int, group: Optional[dist.ProcessGroup] = None, ranges=None):
+    """:func:`gather_rows` split in two: the collective is ENQUEUED (``async_op=True``: RCCL runs it on its own stream
+    behind an event on the caller's) and a ``finish()`` callable is returned that makes the caller's stream wait for it
+    and assembles ``[B, ...]``.  Lets a loop over batches overlap a batch's all-gather with the next batch's kernels:
+    the distribution of batch k is only read after batch k + 1 has been enqueued."""
+    if not dist.is_available() or not dist.is_initialized():
+        if local.shape[0] != B:
+            raise ValueError("not distributed, but the local shard is not the whole batch")
+        return lambda: local
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if ranges is None:
+        ranges = [question_range(B, r, world) for r in range(world)]
+    lo, hi = ranges[rank]
+    if local.shape[0] != hi - lo:
+        raise ValueError("rank %d holds %d rows, expected %d" % (rank, local.shape[0], hi - lo))
+    rows = max(h - l for l, h in ranges)
+    tail = tuple(local.shape[1:])
+    if hi - lo == rows:
+        send = local.contiguous()                        # full-size shard: it goes out as it is
+    else:
+        send = local.new_zeros((rows,) + tail)
+        send[: hi - lo] = local
+    recv = local.new_empty((world * rows,) + tail)
+    work = dist.all_gather_into_tensor(recv, send, group=group, async_op=True)
+
+    def finish():
+        work.wait()
+        if all(h - l == rows for l, h in ranges):
+            return recv
+        return torch.cat([recv[r * rows: r * rows + (h - l)] for r, (l, h) in enumerate(ranges)], dim=0)
+
+    finish._keep = (send, recv)                          # the buffers stay alive until the collective has run
+    return finish
+
+
 def gather_rows(local: torch.Tensor, B: int, group: Optional[dist.ProcessGroup] = None,
                 ranges=None) -> torch.Tensor:
     """All-gathers per-question rows ``[b_local, ...]`` of contiguous shards into ``[B, ...]``.
     One collective (``all_gather_into_tensor``; RCCL on GPUs, gloo in the CPU tests);
     shards are padded to the largest shard so every rank contributes the same count.  ``ranges``: the [lo, hi) of
     every rank (``shard_ranges``) when the split is not the even one."""
-    if not dist.is_available() or not dist.is_initialized():
-        if local.shape[0] != B:
-            raise ValueError("not distributed, but the local shard is not the whole batch")
-        return local
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    if ranges is not None:
-        lo, hi = ranges[rank]
-        if local.shape[0] != hi - lo:
-            raise ValueError("rank %d holds %d rows, expected %d" % (rank, local.shape[0], hi - lo))
-        rows = max(h - l for l, h in ranges)
-        send = local.contiguous()
-        if hi - lo != rows:
-            send = local.new_zeros((rows,) + tuple(local.shape[1:]))
-            send[: hi - lo] = local
-        recv = local.new_empty((world * rows,) + tuple(local.shape[1:]))
-        dist.all_gather_into_tensor(recv, send, group=group)
-        if all(h - l == rows for l, h in ranges):
-            return recv
-        return torch.cat([recv[r * rows: r * rows + (h - l)] for r, (l, h) in enumerate(ranges)], dim=0)
-    lo, hi = question_range(B, rank, world)
-    if local.shape[0] != hi - lo:
-        raise ValueError("rank %d holds %d rows, expected %d" % (rank, local.shape[0], hi - lo))
-    rows = (B + world - 1) // world
-    tail = tuple(local.shape[1:])
-    if hi - lo == rows:
-        send = local.contiguous()                        # even split: the shard goes out as it is
-    else:
-        send = local.new_zeros((rows,) + tail)
-        send[: hi - lo] = local
-    recv = local.new_empty((world * rows,) + tail)
-    dist.all_gather_into_tensor(recv, send, group=group)
-    if B % world == 0:
-        return recv
-    parts = []
-    for r in range(world):
-        l, h = question_range(B, r, world)
-        parts.append(recv[r * rows: r * rows + (h - l)])
-    return torch.cat(parts, dim=0)
+    return gather_rows_async(local, B, group, ranges)()
 
 
 def shard_model(model, group: Optional[dist.ProcessGroup] = None, balance: str = "facts"):
