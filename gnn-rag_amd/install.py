@@ -10,7 +10,8 @@ Two ways:
    ``modules.layer_init``, ``modules.query_update``), so ``from modules.kg_reasoning.reasongnn import
    ReasonGNNLayer`` (rearev.py:8) resolves to the HIP-backed class.
 2. ``swap(model)`` AFTER construction: replaces ``model.reasoning`` / ``model.type_layer`` /
-   ``model.reform{j}`` of an existing ReaRev instance, carrying the parameters over.
+   ``model.reform{j}`` of an existing ReaRev instance (or the ``NSMLayer`` / ``NSMLayer_back`` layers and the
+   TypeLayer of an NSM instance), carrying the parameters over.
 """
 from __future__ import annotations
 
@@ -69,11 +70,37 @@ def cache_rel_features(model):
     return model
 
 
+def _swap_nsm(model, args: dict):
+    """``models/NSM/nsm.py``: ``reasoning`` / ``reasoning2`` (NSMLayer) and ``reasoning_back`` (NSMLayer_back)."""
+    from .modules.kg_reasoning import nsm_gnn
+    num_relation = getattr(model, "num_relation", None)
+    for name in ("reasoning", "reasoning2", "reasoning_back"):
+        old = getattr(model, name, None)
+        if old is None:
+            continue
+        cls = nsm_gnn.NSMLayer_back if type(old).__name__ == "NSMLayer_back" else nsm_gnn.NSMLayer
+        # old.num_relation is overwritten by init_reason (nsm_gnn.py:44); the constructor value is kept by BaseModel
+        new = cls(args, old.num_entity, num_relation if num_relation is not None else old.num_relation, old.entity_dim)
+        new.load_state_dict(old.state_dict(), strict=True)
+        new.to(next(old.parameters()).device)
+        new.train(old.training)
+        setattr(model, name, new)
+
+
 def swap(model, args: dict):
-    """Replaces the reasoning layer (and TypeLayer, if present) of a constructed ReaRev."""
+    """Replaces the reasoning layer(s) (and TypeLayer, if present) of a constructed ReaRev or NSM model."""
     from .modules.kg_reasoning.reasongnn import ReasonGNNLayer
     from .modules.layer_init import TypeLayer
     old = model.reasoning
+    if type(old).__name__ in ("NSMLayer", "NSMLayer_back"):
+        _swap_nsm(model, args)
+        if getattr(model, "type_layer", None) is not None:
+            tl_old = model.type_layer
+            tl = TypeLayer(tl_old.in_features, tl_old.out_features, tl_old.linear_drop, tl_old.device, tl_old.norm_rel)
+            tl.load_state_dict(tl_old.state_dict(), strict=True)
+            tl.to(next(tl_old.parameters()).device)
+            model.type_layer = tl
+        return model
     # old.num_relation is overwritten by init_reason (reasongnn.py:55); the constructor value,
     # which sizes pos_emb, is kept by BaseModel (base_model.py:21)
     num_relation = getattr(model, "num_relation", old.num_relation)

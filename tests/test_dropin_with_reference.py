@@ -28,6 +28,10 @@ class FakePlan:
         self.B, self.N, self.R1, self.F = B, N, R1, len(self.et[0])
         self.w_gnn = self.w_rel = None
 
+    @property
+    def rel_total(self):
+        return len(np.unique((self.et[0] // self.N).astype(np.int64) * (self.R1 + 1) + self.et[1]))
+
     def attach_w_gnn(self, w):
         self.w_gnn = list(w)
 
@@ -113,6 +117,19 @@ def _patch_backend(monkeypatch):
                 hs.append(h.reshape(B, N, -1)); ss.append(sc.reshape(B, N)); ds.append(d.reshape(B, N))
             return torch.stack(hs), torch.stack(ss), torch.stack(ds)
 
+    def aggregate_fused(plan, dist, P):
+        """Only the use the NSM layers make of it (nsm_gnn._reach): tables whose rows are all equal per direction,
+        so nbr = sum_d reach_d (x) P[d, 0, :] with reach_d[n] = sum over facts arriving at n of w_f^2 dist[src]."""
+        assert all(bool((P[d] == P[d][:1]).all()) for d in range(2))
+        h, r, t = (torch.as_tensor(x, dtype=torch.long) for x in plan.et)
+        w = torch.tensor(plan.w_gnn, dtype=torch.float32) ** 2 if plan.w_gnn is not None else torch.ones(plan.F)
+        flat = dist.reshape(-1).float()
+        out = torch.zeros(plan.B * plan.N, P.shape[2])
+        out.index_add_(0, t, (w * flat[h])[:, None] * P[0][0][None, :])
+        out.index_add_(0, h, (w * flat[t])[:, None] * P[1][0][None, :])
+        return out
+
+    monkeypatch.setattr(ops, "aggregate_fused", aggregate_fused)
     monkeypatch.setattr(ops, "LayerStack", FakeStack)
     monkeypatch.setattr(ops, "CsrPlan", FakePlan)
     monkeypatch.setattr(ops, "aggregate", aggregate)
@@ -293,6 +310,42 @@ def test_training_step_matches_reference_autograd(reference_setup, monkeypatch):
     for k in g_ref:
         scale = max(float(g_ref[k].abs().max()), 1e-4)
         assert float((g[k] - g_ref[k]).abs().max()) <= 2e-4 * scale, k
+
+
+@pytest.mark.parametrize("reason_kb", [False, True])
+def test_swapped_nsm_model_reproduces_reference_forward(reference_setup, monkeypatch, reason_kb):
+    """`models/NSM/nsm.py` through the drop-in: the reference's own NSM model (LSTM instructions, TypeLayer start,
+    `num_step` NSMLayer calls, nsm.py:179-222) with `install.swap`-ed layers gives the reference's `pred_dist`, `pred`
+    and loss; with `reason_kb` the reachability masks (`possible_cand`) are identical.  (`NSMLayer_back` cannot be
+    reached through the reference's model: `nsm_gnn.py:122` reads `rel_features_inv`, which `NSM.init_reason` never
+    sets - it is covered at layer level, tests/test_nsm_layer.py.)"""
+    args, dataset, _ = reference_setup
+    from models.NSM.nsm import NSM
+    from gnnrag_amd import install
+    nsm_args = dict(args, model_name="NSM", num_step=3, reason_kb=reason_kb, loss_type="kl", lambda_constrain=0.0,
+                    lambda_back=0.0)
+    torch.manual_seed(5)
+    model = NSM(nsm_args, len(dataset["entity2id"]), dataset["test"].num_kb_relation, dataset["num_word"])
+    model.eval()
+    test = dataset["test"]
+    test.reset_batches(is_sequential=True)
+    np.random.seed(11)
+    batch = test.get_batch(0, 4, fact_dropout=0.0, test=True)
+    with torch.no_grad():
+        loss_ref, pred_ref, dist_ref, _ = model(batch[:-1])
+    cand_ref = [c.clone() for c in model.reasoning.possible_cand]
+    _patch_backend(monkeypatch)
+    mine = install.swap(copy.deepcopy(model), nsm_args)
+    assert type(mine.reasoning).__module__.startswith("gnnrag_amd.") and type(mine.reasoning).__name__ == "NSMLayer"
+    assert type(mine.reasoning2).__module__.startswith("gnnrag_amd.")
+    assert type(mine.type_layer).__module__.startswith("gnnrag_amd.")
+    with torch.no_grad():
+        loss, pred, dist, _ = mine(batch[:-1])
+    np.testing.assert_allclose(dist.numpy(), dist_ref.numpy(), rtol=0, atol=1e-6)
+    assert torch.equal(pred, pred_ref) and abs(float(loss) - float(loss_ref)) <= 1e-6
+    assert len(mine.reasoning.possible_cand) == len(cand_ref) == 3
+    for a, b in zip(mine.reasoning.possible_cand, cand_ref):
+        assert torch.equal(a, b)
 
 
 def test_launcher_substitutes_everything_then_refuses_the_cpu(tmp_path):
