@@ -108,6 +108,7 @@ SIGNATURES = {
 
 ABI_VERSION = 8
 PATH_AUTO, PATH_UNFUSED, PATH_FUSED = 0, 1, 2
+PATH_ONLY_FWD, PATH_ONLY_INV = 0x10, 0x20        # OR-ed into the path: one-direction layers (NSM)
 E_TUPLE = -4
 _lib = None
 

@@ -106,6 +106,7 @@ struct WalkArgs {
   const int32_t* big_cnt;     // LDS walk: per-question count / list of nodes with > big_deg facts in a direction
   const int32_t* big_nodes;
   int32_t big_deg;
+  int32_t skip_dir;           // LDS walk: 1 + direction to leave out (one-direction layers, NSM), 0 = walk both
 };
 
 template <int MODE, int NI> struct AccN { static constexpr int n = (MODE == MODE_REASON) ? NI : 1; };
@@ -484,7 +485,7 @@ __device__ __forceinline__ void set_load_rows(SetRows& s, const WalkArgs& a, int
     s.len[d] = 0;
     if (s.valid) {
       s.beg[d] = a.row_ptr[d][s.n];
-      s.len[d] = a.row_ptr[d][s.n + 1] - s.beg[d];
+      s.len[d] = a.skip_dir == d + 1 ? 0 : a.row_ptr[d][s.n + 1] - s.beg[d];
       s.big |= s.len[d] > a.big_deg;
     }
   }
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
     for (int d = 0; d < 2; ++d) {
       const int beg = a.row_ptr[d][n];
       e[1 + 2 * d] = beg;
-      e[2 + 2 * d] = a.row_ptr[d][n + 1] - beg;
+      e[2 + 2 * d] = a.skip_dir == d + 1 ? 0 : a.row_ptr[d][n + 1] - beg;
     }
   }
   // stage the two table slices (float4 granules; rows are D*4 bytes apart).  FUSED: the question's own
@@ -644,6 +645,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
   constexpr int GR = SW / 4;                           // float4 granules per staged row
   for (int idx = tid; idx < 2 * Rg * GR; idx += kSliceThreads) {
     const int d = idx >= Rg * GR;
+    if (a.skip_dir == d + 1) continue;                 // (a direction that is not walked is never read)
     const int rem = idx - d * (Rg * GR);
     const int r = rem / GR, k = rem % GR;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -988,8 +990,14 @@ extern "C" int gnnrag_aggregate(const gnnrag_csr* csr, const float* dist, const 
 extern "C" int gnnrag_aggregate_fused(const gnnrag_csr* csr, const float* dist, const float* P, float* out,
                                       int32_t D, void* workspace, size_t workspace_bytes,
                                       gnnrag_stream_t stream_) {
-  if (!csr || !dist || !P || !out || D <= 0 || csr->rel_total < 0) return GNNRAG_E_BADARG;
-  hipStream_t stream = (hipStream_t)stream_;
+  return gnnrag::aggregate_fused_dirs(csr, dist, P, out, D, 0, workspace, workspace_bytes, (hipStream_t)stream_);
+}
+
+// skip_dir: 0 both directions, 1 + d = leave direction d out (its tables are not read; LDS walk only - the gather walk
+// walks both, the caller's tables for the other direction must then be zero)
+int gnnrag::aggregate_fused_dirs(const gnnrag_csr* csr, const float* dist, const float* P, float* out, int32_t D,
+                                 int32_t skip_dir, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (!csr || !dist || !P || !out || D <= 0 || csr->rel_total < 0 || skip_dir < 0 || skip_dir > 2) return GNNRAG_E_BADARG;
   WalkArgs a;
   memset(&a, 0, sizeof(a));
   const int rc = fill_common(a, csr, D, workspace, workspace_bytes, 1);
@@ -1004,6 +1012,7 @@ extern "C" int gnnrag_aggregate_fused(const gnnrag_csr* csr, const float* dist, 
   a.dist = dist;
   a.out = out;
   a.I = 1;
+  a.skip_dir = skip_dir;
   switch (gnnrag_aggregate_fused_variant(csr, D)) {
     case GNNRAG_WALK_L2_GATHER: return launch_walk<MODE_FUSED>(a, 1, stream);   // tables too big for LDS
     // 32-column slices when two of them still fit a CU's LDS (questions that use up to ~300 relations): half

@@ -95,8 +95,13 @@ int tables_b3_launch(const gnnrag_csr* csr, const float* T_fwd, const float* T_i
 // (tables_b3.hip, "V form"); planes: [2 directions][3 planes][R1][896 B] of ONE layer
 size_t tables_vq_planes_bytes(int64_t R1);
 bool tables_vq_shape_ok(int32_t D, int32_t I);
+// only_dir: -1 both directions, else the one direction whose tables are built (the other's are left unwritten)
 int tables_vq_launch(const gnnrag_csr* csr, const void* planes, const float* ins, const float* W, float* P, int32_t D,
-                     int32_t I, hipStream_t stream);
+                     int32_t I, int32_t only_dir, hipStream_t stream);
+
+// gnnrag_aggregate_fused with one direction left out (skip_dir = 1 + d; 0 = both): aggregate.hip
+int aggregate_fused_dirs(const gnnrag_csr* csr, const float* dist, const float* P, float* out, int32_t D,
+                         int32_t skip_dir, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 // the self-block update in bf16x3 on the W-resident kernel of tables_b3.hip (score must be writable scratch: it is
 // zeroed and accumulated by two atomic adds per row); GNNRAG_E_UNSUPPORTED outside its shapes

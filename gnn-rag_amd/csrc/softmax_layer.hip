@@ -92,6 +92,12 @@ static bool fused_is_cheaper(int64_t B, int64_t N, int64_t rel_total, int64_t D,
   return fused < 0.8 * unfused;
 }
 
+static bool path_ok(int32_t path) {
+  const int base = path & 0xf, flags = path & ~0xf;
+  if (base < GNNRAG_PATH_AUTO || base > GNNRAG_PATH_FUSED) return false;
+  return flags == 0 || flags == GNNRAG_PATH_ONLY_FWD || flags == GNNRAG_PATH_ONLY_INV;
+}
+
 static LayerWs layer_ws(const gnnrag_csr* csr, int32_t D, int32_t I) {
   LayerWs w;
   size_t off = 0;
@@ -151,17 +157,24 @@ static int layer_body(const gnnrag_csr* csr, const LayerWs& w, char* base, const
                       int32_t math, gnnrag_stream_t stream) {
   const int64_t BN = (int64_t)csr->B * csr->N;
   int rc;
+  // one-direction layers (NSM): only that direction's tables are built and walked where the kernels at hand can
+  // leave a direction out (V-form tables + LDS walk); otherwise both directions run and the caller's zero weight
+  // block makes the other one contribute exactly 0
+  const int only = (path & GNNRAG_PATH_ONLY_FWD) ? 0 : (path & GNNRAG_PATH_ONLY_INV) ? 1 : -1;
+  path &= 0xf;
   if (path == GNNRAG_PATH_AUTO)
     path = fused_is_cheaper(csr->B, csr->N, csr->rel_total, D, I) ? GNNRAG_PATH_FUSED : GNNRAG_PATH_UNFUSED;
   if (path == GNNRAG_PATH_FUSED) {
     float* P = (float*)(base + w.P);
     float* nbr = (float*)(base + w.nbr);
+    const bool one_dir = only >= 0 && gnnrag_aggregate_fused_variant(csr, D) != GNNRAG_WALK_L2_GATHER;
     rc = GNNRAG_E_UNSUPPORTED;
     if (planes && math != GNNRAG_MATH_FP32 && csr->rel_total > 0)
-      rc = tables_vq_launch(csr, planes, ins, W_e2e, P, D, I, (hipStream_t)stream);
+      rc = tables_vq_launch(csr, planes, ins, W_e2e, P, D, I, one_dir ? only : -1, (hipStream_t)stream);
     if (rc == GNNRAG_E_UNSUPPORTED) rc = gnnrag_relation_tables(csr, T_fwd, T_inv, ins, W_e2e, P, D, I, math, stream);
     if (rc) return rc;
-    rc = gnnrag_aggregate_fused(csr, dist, P, nbr, D, base + w.partial, w.partial_bytes, stream);
+    rc = aggregate_fused_dirs(csr, dist, P, nbr, D, one_dir ? 2 - only : 0, base + w.partial, w.partial_bytes,
+                              (hipStream_t)stream);
     if (rc) return rc;
     rc = gnnrag_update_score_fused(h, nbr, W_e2e, b_e2e, w_score, b_score, mask, h_out, score_out, BN, D, I,
                                    math, stream);
@@ -216,7 +229,7 @@ extern "C" int gnnrag_reason_layer(const gnnrag_csr* csr, const float* h, const 
   if (!csr || !h || !dist || !ins || !relfeat_fwd || !relfeat_inv || !W_rel || !b_rel || !W_e2e || !b_e2e ||
       !w_score || !b_score || !mask || !h_out || !score_out || !dist_out || !workspace || D <= 0 || I <= 0)
     return GNNRAG_E_BADARG;
-  if (path < GNNRAG_PATH_AUTO || path > GNNRAG_PATH_FUSED) return GNNRAG_E_BADARG;
+  if (!path_ok(path)) return GNNRAG_E_BADARG;
   const LayerWs w = layer_ws(csr, D, I);
   if (workspace_bytes < w.total) return GNNRAG_E_WORKSPACE;
   char* base = (char*)workspace;
@@ -224,8 +237,8 @@ extern "C" int gnnrag_reason_layer(const gnnrag_csr* csr, const float* h, const 
   float* T_inv = (float*)(base + w.T_inv);
   const gnnrag_layer_params p = {W_rel, b_rel, pos_fwd, pos_inv, W_e2e, b_e2e};
   // the planes are only worth writing when the fused path with a bf16x3 product will read them
-  const bool fused = path == GNNRAG_PATH_FUSED ||
-                     (path == GNNRAG_PATH_AUTO && fused_is_cheaper(csr->B, csr->N, csr->rel_total, D, I));
+  const bool fused = (path & 0xf) == GNNRAG_PATH_FUSED ||
+                     ((path & 0xf) == GNNRAG_PATH_AUTO && fused_is_cheaper(csr->B, csr->N, csr->rel_total, D, I));
   void* planes = fused && math != GNNRAG_MATH_FP32 && tables_vq_shape_ok(D, I) && csr->rel_total >= 1024
                      ? (void*)(base + w.planes) : nullptr;
   const int rc = rel_projections(csr, 1, &p, relfeat_fwd, relfeat_inv, pos_rows, T_fwd, planes, D, math, stream);
@@ -243,7 +256,7 @@ extern "C" int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnra
   if (!csr || L <= 0 || !layers || !h0 || !dist0 || !ins || !relfeat_fwd || !relfeat_inv || !w_score || !b_score ||
       !mask || !h_out || !score_out || !dist_out || !workspace || D <= 0 || I <= 0)
     return GNNRAG_E_BADARG;
-  if (path < GNNRAG_PATH_AUTO || path > GNNRAG_PATH_FUSED) return GNNRAG_E_BADARG;
+  if (!path_ok(path)) return GNNRAG_E_BADARG;
   for (int j = 0; j < L; ++j)
     if (!layers[j].W_rel || !layers[j].b_rel || !layers[j].W_e2e || !layers[j].b_e2e) return GNNRAG_E_BADARG;
   const LayerWs w = layer_ws(csr, D, I);
@@ -257,8 +270,8 @@ extern "C" int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnra
   const bool upfront = L > 1 && workspace_bytes >= gnnrag_stack_workspace_bytes(csr, L, D, I);
   float* T0 = (float*)(base + w.T_fwd);
   float* Tall = (float*)(base + w.total);
-  const bool fused = path == GNNRAG_PATH_FUSED ||
-                     (path == GNNRAG_PATH_AUTO && fused_is_cheaper(csr->B, csr->N, csr->rel_total, D, I));
+  const bool fused = (path & 0xf) == GNNRAG_PATH_FUSED ||
+                     ((path & 0xf) == GNNRAG_PATH_AUTO && fused_is_cheaper(csr->B, csr->N, csr->rel_total, D, I));
   const bool want_planes = fused && math != GNNRAG_MATH_FP32 && tables_vq_shape_ok(D, I) && csr->rel_total >= 1024;
   const size_t plane_bytes = tables_vq_planes_bytes(csr->R1);
   char* planes_all = base + w.total + align_up((size_t)L * 2 * RD * sizeof(float), 256);

@@ -337,6 +337,7 @@ struct VqArgs {
   int32_t M, D, I, ldw, R1;
   int32_t ct0;                   // column tiles of part 0
   int32_t nchunk;                // row chunks per question (> 1 only when the batch has few questions)
+  int32_t dir0;                  // first direction of the launch (grid y counts on from it)
 };
 
 // V planes of one half and one column part -> LDS:  V[n, k] = sum_i W[col0 + n, (1 + 2 i + d) D + k] * max(+-ins[g, i, k], 0)
@@ -395,7 +396,7 @@ __device__ __forceinline__ void tables_vq_part(const VqArgs& a, unsigned char* l
   constexpr int NKB = kTabNKB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
-  const int d = blockIdx.y;
+  const int d = a.dir0 + blockIdx.y;
   const int g = blockIdx.x / a.nchunk, ch = blockIdx.x - g * a.nchunk;
   const int D = a.D, I = a.I;
   const int r0 = a.rel_off[g], r1 = a.rel_off[g + 1];
@@ -796,8 +797,8 @@ bool tables_vq_shape_ok(int32_t D, int32_t I) {
 }
 
 int tables_vq_launch(const gnnrag_csr* csr, const void* planes, const float* ins, const float* W, float* P, int32_t D,
-                     int32_t I, hipStream_t stream) {
-  if (!tables_vq_shape_ok(D, I) || csr->rel_total < 1024) return GNNRAG_E_UNSUPPORTED;
+                     int32_t I, int32_t only_dir, hipStream_t stream) {
+  if (!tables_vq_shape_ok(D, I) || csr->rel_total < 1024 || only_dir > 1) return GNNRAG_E_UNSUPPORTED;
   if ((((uintptr_t)planes | (uintptr_t)ins | (uintptr_t)W | (uintptr_t)P) & 15) != 0) return GNNRAG_E_UNSUPPORTED;
   VqArgs a;
   memset(&a, 0, sizeof(a));
@@ -813,7 +814,9 @@ int tables_vq_launch(const gnnrag_csr* csr, const void* planes, const float* ins
   }
   // one workgroup per (question, direction, column part) fills the chip from 64 questions on; smaller batches cut a
   // question's rows into chunks (each builds the question's V again), as long as a chunk keeps >= 8 tiles
-  int nchunk = cus / (csr->B * 4);
+  const int ndir = only_dir < 0 ? 2 : 1;
+  a.dir0 = only_dir < 0 ? 0 : only_dir;
+  int nchunk = cus / (csr->B * 2 * ndir);
   const int tiles_max = (csr->rel_max + 15) / 16;
   if (nchunk > tiles_max / 8) nchunk = tiles_max / 8;
   if (nchunk < 1) nchunk = 1;
@@ -823,7 +826,7 @@ int tables_vq_launch(const gnnrag_csr* csr, const void* planes, const float* ins
     const int rc = raise_lds_cap(k_tables_vq, cap);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(k_tables_vq, dim3(csr->B * nchunk, 2, 2), dim3(512), 160 * 1024, stream, a);
+  hipLaunchKernelGGL(k_tables_vq, dim3(csr->B * nchunk, ndir, 2), dim3(512), 160 * 1024, stream, a);
   GNNRAG_LAUNCH_CHECK();
   return 0;
 }
@@ -871,5 +874,5 @@ extern "C" int gnnrag_relation_tables_planes(const gnnrag_csr* csr, const void* 
                                              float* P, int32_t D, int32_t I, gnnrag_stream_t stream) {
   if (!csr || !planes || !ins || !W || !P || D <= 0 || I <= 0 || csr->rel_total < 0) return GNNRAG_E_BADARG;
   if (csr->rel_total == 0) return 0;
-  return gnnrag::tables_vq_launch(csr, planes, ins, W, P, D, I, (hipStream_t)stream);
+  return gnnrag::tables_vq_launch(csr, planes, ins, W, P, D, I, -1, (hipStream_t)stream);
 }

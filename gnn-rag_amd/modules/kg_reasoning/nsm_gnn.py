@@ -8,7 +8,9 @@ layer is the ReaRev layer with ONE instruction and ONE direction, plus an option
 
 No new kernel: with ``W' = [W_self | W_nbr | 0]`` (``[W_self | 0 | W_nbr]`` for the backward layer) the fused
 ReaRev path (``gnnrag_reason_layer``, I = 1) computes exactly this - the other direction's relation
-tables are ``0 . relu(..)`` = 0 - and ``possible_tail`` is the same walk over a table of ones.  Same
+tables are ``0 . relu(..)`` = 0 - and ``possible_tail`` is the same walk over a table of ones.  The call carries
+``GNNRAG_PATH_ONLY_FWD`` / ``_INV``: where the V-form table kernel and the LDS walk apply, the unused direction's
+tables are neither built nor walked (bit-identical results, tests/test_gpu_parity.py).  Same
 class names, constructors, parameter names and return values as the reference.  With autograd enabled
 the aggregation is the HIP autograd function, the rest ``nn.Linear`` / ``nn.Dropout``."""
 from __future__ import annotations
@@ -18,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ..._lib import PATH_FUSED
+from ..._lib import PATH_FUSED, PATH_ONLY_FWD, PATH_ONLY_INV
 from ...autograd import AggregateFn
 from .base_gnn import BaseGNNLayer
 
@@ -110,7 +112,7 @@ class NSMBaseLayer(BaseGNNLayer):
                 self.plan, self.local_entity_emb.detach().float(), current_dist.detach().float(),
                 ins.detach().float(), relfeat.detach(), relfeat.detach(), rel_linear.weight, rel_linear.bias,
                 self._padded_e2e(e2e_linear), e2e_linear.bias, self.score_func.weight, self.score_func.bias,
-                answer_mask, ws=self._ws, path=PATH_FUSED)
+                answer_mask, ws=self._ws, path=PATH_FUSED | (PATH_ONLY_INV if self._direction else PATH_ONLY_FWD))
             self.local_entity_emb = h_out
         self.possible_cand.append(answer_mask)
         if return_score:

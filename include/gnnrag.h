@@ -272,6 +272,12 @@ int gnnrag_update_score_fused(const float* h, const float* nbr, const float* W_e
 #define GNNRAG_PATH_AUTO    0
 #define GNNRAG_PATH_UNFUSED 1
 #define GNNRAG_PATH_FUSED   2
+/* OR-ed into `path`: a layer that aggregates along ONE direction (NSMLayer: head -> tail, NSMLayer_back: tail ->
+ * head; the caller's e2e weight block of the other direction must be zero).  Where the kernels at hand can leave a
+ * direction out (V-form tables + LDS walk) only that direction's tables are built and walked; elsewhere both run and
+ * the zero block makes the other contribute exactly 0 - results are identical either way. */
+#define GNNRAG_PATH_ONLY_FWD 0x10
+#define GNNRAG_PATH_ONLY_INV 0x20
 size_t gnnrag_layer_workspace_bytes(const gnnrag_csr* csr, int32_t D, int32_t I);
 int gnnrag_reason_layer(const gnnrag_csr* csr,
                         const float* h, const float* dist, const float* ins,

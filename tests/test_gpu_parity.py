@@ -695,6 +695,42 @@ def test_relation_tables_from_relation_planes(dev, B, R, used, I, N):
         assert np.abs(P32 - want).max() <= TOL_INTERNAL * scale
 
 
+@pytest.mark.parametrize("direction", [0, 1], ids=["fwd", "inv"])
+def test_one_direction_layer_skips_the_other_direction(dev, direction, capsys):
+    """NSM layers aggregate along ONE direction (nsm_gnn.py:87-112 / :118-142): with GNNRAG_PATH_ONLY_FWD / _INV only
+    that direction's relation tables are built (V form) and walked (LDS walk).  Bit-identical to the both-direction
+    call with a zero weight block for the other direction, which is what small / odd shapes still run."""
+    from gnnrag_amd import _lib, ops, stack, synth
+    cfg = synth.GraphConfig(name="nsm1d", B=16, N=2000, E=10000, R=600, D=200, I=1, L=1, T=1, seed=31 + direction)
+    batch = synth.make_batch(cfg)
+    feats = synth.make_features(cfg)
+    params = synth.make_layer_params(cfg)
+    devin = stack.DeviceInputs(batch, feats, dev)
+    et = batch.edge_tuple
+    plan = ops.CsrPlan(et[0], et[1], et[2], cfg.B, cfg.N, cfg.R1, dev)
+    assert ops.aggregate_fused_variant(plan, cfg.D) != ops.WALK_L2_GATHER and plan.rel_total >= 1024
+    D = cfg.D
+    P = {k: torch.from_numpy(v).to(dev) for k, v in params.items()}
+    W = P["e2e_linear0.weight"].clone()                               # [D, 3D]: self | fwd | inv
+    W[:, (2 - direction) * D:(3 - direction) * D] = 0                 # the direction that is not walked
+    mask = torch.ones(cfg.B, cfg.N, device=dev)
+    args = (plan, devin.h0, devin.seed_dist, devin.ins[0], devin.rel_features, devin.rel_features_inv,
+            P["rel_linear0.weight"], P["rel_linear0.bias"], W, P["e2e_linear0.bias"], P["score_func.weight"],
+            P["score_func.bias"], mask)
+    flag = _lib.PATH_ONLY_INV if direction else _lib.PATH_ONLY_FWD
+    both = ops.reason_layer(*args, path=_lib.PATH_FUSED)
+    one = ops.reason_layer(*args, path=_lib.PATH_FUSED | flag)
+    for a, b in zip(both, one):
+        assert torch.equal(a, b)
+    import bench
+    t_both = float(np.mean(bench._events_ms(lambda: ops.reason_layer(*args, path=_lib.PATH_FUSED), 10)))
+    t_one = float(np.mean(bench._events_ms(lambda: ops.reason_layer(*args, path=_lib.PATH_FUSED | flag), 10)))
+    with capsys.disabled():
+        print("\none-direction layer (B=16, N=2000, D=200): both directions %.3f ms, one %.3f ms" % (t_both, t_one))
+    with pytest.raises(_lib.GnnragError):
+        ops.reason_layer(*args, path=_lib.PATH_FUSED | _lib.PATH_ONLY_FWD | _lib.PATH_ONLY_INV)
+
+
 @pytest.mark.parametrize("cfgname", ["tiny50", "mid"])
 def test_whole_iteration_call_and_graph_replay_are_bit_identical(dev, cfgname):
     """f-3: the L layer calls of a ReaRev iteration as ONE library call (gnnrag_reason_stack, run ahead by the module's
