@@ -58,8 +58,11 @@ def flops_update(cfg) -> float:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: the chip needs ~20 steps after an idle period before its clocks (and the step time) settle - measured
+    # series at C2: 1.13, 0.91, 0.94, 0.98, ... 0.86 after 20 steps, one 32 ms host-side stall around step 20, p50 0.845
+    # (tools/probe/spread_probe.py) - so the default warm-up covers that ramp
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",

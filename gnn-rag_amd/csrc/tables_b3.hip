@@ -80,6 +80,15 @@ __device__ __forceinline__ int tab_lds_row(int j) {
   return j;
 }
 
+// Weight rows a column part stages per plane: its CTN x 16 columns (columns past the part's last real one as zeros)
+// PLUS ONE zero row when the part does not fill the plane - the last k block of a row reads up to 32 bytes past the
+// row's end (k >= D; the A side is zero there), i.e. the head of the NEXT row, and 0 x (whatever an unwritten LDS row
+// holds) is NaN when that happens to be an Inf / NaN pattern.  With D = 200 the next row is one of the part's own zero
+// rows; with D = 208 the 6-tile part ends exactly at its last staged row (found by the D = 208 shape-sweep test:
+// column 207 came out as relu(NaN) = 0 for some rows).  A full plane (7 tiles) is followed by the next plane's row 0
+// or the zeroed slack.
+__device__ __forceinline__ constexpr int tab_stage_rows(int ctn) { return ctn < kTabNTH ? ctn * 16 + 1 : ctn * 16; }
+
 // One column part with CTN column tiles (compile time: the MFMA loop has no branches).  QLDS: the instruction rows
 // of the chunk's questions are in LDS (the usual case) - also compile time: a run-time branch around the global-memory
 // variant's loads would make every vmcnt wait of the loop conservative, i.e. wait for the prefetch just issued.
@@ -130,7 +139,7 @@ __device__ __forceinline__ void tables_b3_part(const TabArgs& a, unsigned char* 
       // ---- this instruction's weight block -> three bf16 planes in LDS ----
       {
         const int wcol = (1 + 2 * i + d) * D;               // first k column of the block inside e2e_linear.weight
-        const int total = ctn * 16 * kTabSlots * 2;         // 8-byte pieces (4 k) per plane: rows x 52
+        const int total = tab_stage_rows(ctn) * kTabSlots * 2;      // 8-byte pieces (4 k) per plane: rows x 52
         constexpr int UN = 6;                               // requests in flight per thread before the first split
         for (int base = 0; base < total; base += 512 * UN) {
           f32x4 v[UN];
@@ -350,7 +359,7 @@ __device__ __forceinline__ void vq_stage(const VqArgs& a, unsigned char* lds, co
   const int tid = threadIdx.x;
   const int D = a.D, I = a.I, KC = D >> 2;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  const int total = CTN * 16 * kTabSlots * 2;               // 8-byte pieces (4 k) per plane
+  const int total = tab_stage_rows(CTN) * kTabSlots * 2;        // 8-byte pieces (4 k) per plane
   for (int base = 0; base < total; base += 512 * UN) {
     f32x4 v[UN];
 #pragma unroll
@@ -582,7 +591,7 @@ __device__ __forceinline__ void update_b3_part(const UpdB3Args& a, unsigned char
     Sl[j] = j < ncol ? a.w_s[col0 + j] : 0.f;
   }
   {   // weight planes of this column part (self block: columns 0..D-1 of e2e_linear.weight)
-    const int total = CTN * 16 * kTabSlots * 2;
+    const int total = tab_stage_rows(CTN) * kTabSlots * 2;
     constexpr int UN = 6;
     for (int base = 0; base < total; base += 512 * UN) {
       f32x4 v[UN];
