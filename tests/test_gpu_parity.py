@@ -116,7 +116,7 @@ def test_linear_vs_fp64(dev, M, K, Nout, with_add, relu):
 
 
 @pytest.mark.parametrize("R1,D,L,pos_rows", [(602, 200, 3, 0), (602, 200, 3, 602), (12, 56, 2, 7), (1, 8, 1, 0),
-                                             (6106, 200, 4, 0), (130, 36, 9, 130)])
+                                             (6106, 200, 4, 0), (130, 36, 9, 130), (3001, 208, 2, 2500)])
 def test_rel_transform_all_layers_in_one_launch_vs_fp64(dev, R1, D, L, pos_rows):
     """gnnrag_rel_transform (k_rel_transform): rel_linear{j}(rel_features_d) (+ pos_emb{j}_d) for every layer j and
     both directions from one launch (L = 9 takes two launches), against fp64; reasongnn.py:75-79, :102-105."""
@@ -622,19 +622,19 @@ def test_query_reform_equals_reference_op_sequence_at_c2(dev, capsys):
         print("\nQueryReform at C2: reference op sequence %.3f ms, drop-in %.3f ms" % tuple(times))
 
 
-@pytest.mark.parametrize("B,R,used,I,N", [(4, 600, None, 2, 1200), (9, 1500, 260, 3, 1500), (3, 40, None, 1, 300)])
-def test_relation_tables_bf16x3_w_resident_kernel(dev, B, R, used, I, N):
+@pytest.mark.parametrize("B,R,used,I,N,D", [(4, 600, None, 2, 1200, 200), (9, 1500, 260, 3, 1500, 200),
+                                            (3, 40, None, 1, 300, 200), (5, 500, None, 2, 1000, 208)])
+def test_relation_tables_bf16x3_w_resident_kernel(dev, B, R, used, I, N, D):
     """The bf16x3 relation tables on the W-resident kernel (tables_b3.hip; D = 200, >= 1024 compact rows): against
     the exact-fp32 kernel and the float64 definition, incl. questions of very different relation counts (row chunks
     that span several questions), 1-3 instructions and a row count that is not a multiple of 16."""
     from gnnrag_amd import ops, synth
-    D = 200
     cfg = synth.GraphConfig(name="tab", B=B, N=N, E=6 * N, R=R, D=D, I=I, L=1, T=1, seed=B + R, rel_per_question=used,
                             n_real_min=N // 3)
     batch = synth.make_batch(cfg)
     et = batch.edge_tuple
     plan = ops.CsrPlan(et[0], et[1], et[2], cfg.B, cfg.N, cfg.R1, dev)
-    assert plan.rel_total >= 1024 or (B, R) == (3, 40)          # the last case stays on the k-tiled kernel
+    assert plan.rel_total >= 1024 or (B, R) == (3, 40)          # that case stays on the k-tiled kernel
     rng = np.random.default_rng(5)
     Tf = (0.3 * rng.standard_normal((cfg.R1, D))).astype(np.float32)
     Ti = (0.3 * rng.standard_normal((cfg.R1, D))).astype(np.float32)

@@ -96,3 +96,38 @@ def test_random_shape_bf16x3_math(k):
                 np.testing.assert_allclose(got["dist"][c], want["dist"][c], rtol=RTOL, atol=TOL, err_msg="%s dist %d" % (cfg, c))
     finally:
         ops.set_dense_math(old)
+
+
+@pytest.mark.parametrize("k", range(int(__import__("os").environ.get("GNNRAG_SWEEP_LARGE", "6"))))
+def test_random_large_shape(k):
+    """Random shapes LARGE enough for the W-resident bf16x3 kernels (>= 8192 node rows, >= 1024 compact relation rows,
+    hidden size 200 or 208) - ragged node counts, 1-3 instructions, normalised weights, pos_emb, Freebase-like
+    vocabularies - through both kernel paths in the default (mixed) math mode against the float64 oracle."""
+    import gnnrag_amd  # noqa: F401
+    import oracle.rearev_np64 as onp
+    from gnnrag_amd import ops, stack, synth
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(7000 + k)
+    N = int(rng.integers(900, 2300))
+    B = int(rng.integers(max(4, 8192 // N + 1), 14))
+    used = int(rng.integers(150, 500)) if rng.integers(0, 2) else None
+    cfg = synth.GraphConfig(name="large%d" % k, B=B, N=N, E=int(rng.integers(3 * N, 7 * N)),
+                            R=int(rng.choice([300, 650, 3000])) if used is None else 3000, D=int(rng.choice([200, 208])),
+                            I=int(rng.integers(1, 4)), L=2, T=1, seed=int(rng.integers(1, 10 ** 6)),
+                            zipf_heads=bool(rng.integers(0, 2)), normalized_gnn=bool(rng.integers(0, 2)),
+                            pos_emb=bool(rng.integers(0, 2)), n_real_min=N // 2, rel_per_question=used)
+    batch = synth.make_batch(cfg)
+    et = batch.edge_tuple
+    plan = ops.CsrPlan(et[0], et[1], et[2], cfg.B, cfg.N, cfg.R1, dev)
+    assert cfg.B * cfg.N >= 8192 and plan.rel_total >= 1024, cfg
+    feats = synth.make_features(cfg)
+    params = synth.make_layer_params(cfg)
+    want = onp.run_stack(batch, feats, params, use_type_layer=False)
+    for path in (2, 1):
+        got = stack.run_stack(batch, feats, params, dev, use_type_layer=False, path=path)
+        for c in range(cfg.T * cfg.L):
+            scale = max(1.0, float(np.abs(want["h"][c]).max()))
+            np.testing.assert_allclose(got["h"][c], want["h"][c], rtol=0, atol=TOL * scale,
+                                       err_msg="%s h %d path %d" % (cfg, c, path))
+            np.testing.assert_allclose(got["dist"][c], want["dist"][c], rtol=0, atol=TOL,
+                                       err_msg="%s dist %d path %d" % (cfg, c, path))
