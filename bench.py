@@ -437,8 +437,17 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
     ms = {}
     # relation projections of ALL L layers and both directions: one launch per step (rel_transform.hip)
     rel_layers = [(lp[0], lp[1], None, None) for lp in P["layers"]]
-    ms["rel_transform_all_layers"] = t(lambda: box.__setitem__("T", ops.rel_transform(relf, relf_inv, rel_layers)))
-    Tf, Ti = box["T"][0, 0], box["T"][0, 1]
+    # the V-form table kernel (k_tables_vq) is what a step runs when its shapes apply and the math mode is not fp32:
+    # then the projections also write its bf16 planes
+    vq = (ops.get_dense_math() != ops.MATH_FP32 and Dk % 8 == 0 and 193 <= Dk <= 208 and plan.rel_total >= 1024)
+    if vq:
+        ms["rel_transform_all_layers"] = t(lambda: box.__setitem__("T", ops.rel_transform(relf, relf_inv, rel_layers,
+                                                                                          planes=True)))
+        Tall, planes = box["T"]
+    else:
+        ms["rel_transform_all_layers"] = t(lambda: box.__setitem__("T", ops.rel_transform(relf, relf_inv, rel_layers)))
+        Tall, planes = box["T"], None
+    Tf, Ti = Tall[0, 0], Tall[0, 1]
     ms["aggregate_dense"] = t(lambda: box.__setitem__("agg", ops.aggregate(plan, dense, ins, Tf, Ti)))
     ms["aggregate_seed"] = t(lambda: ops.aggregate(plan, seed, ins, Tf, Ti))
     agg = box["agg"]
@@ -446,7 +455,12 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
                                                                           sf.bias, layer.local_entity_mask, I)))
     del agg
     box.pop("agg")
-    ms["relation_tables"] = t(lambda: box.__setitem__("P", ops.relation_tables(plan, Tf, Ti, ins, e2e.weight)))
+    if vq:
+        e2e0 = P["layers"][0][2]
+        ms["relation_tables"] = t(lambda: box.__setitem__("P", ops.relation_tables_planes(plan, planes[0], ins, e2e0)))
+        ms["relation_tables_without_planes"] = t(lambda: ops.relation_tables(plan, Tf, Ti, ins, e2e0))
+    else:
+        ms["relation_tables"] = t(lambda: box.__setitem__("P", ops.relation_tables(plan, Tf, Ti, ins, e2e.weight)))
     P = box["P"]
     ms["aggregate_fused_dense"] = t(lambda: box.__setitem__("nbr", ops.aggregate_fused(plan, dense, P)))
     ms["aggregate_fused_seed"] = t(lambda: ops.aggregate_fused(plan, seed, P))
@@ -531,11 +545,18 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
         "roofline": r_fused if fused else r_unf,
         "roofline_aggregate_unfused" if fused else "roofline_aggregate_fused": r_unf if fused else r_fused,
         "roofline_dense": {
-            "update_score": mfma("gnnrag_update_score (k_gemm_f32 [BN,(2I+1)D]x[(2I+1)D,D])", flops_update(cfg),
+            # flops are the fp32-equivalent ones of the reference's products ([2*rel_total, I*D]x[I*D, D] for the
+            # tables whichever form computes them); the bf16x3 kernels issue 6 bf16 MFMAs per fp32-equivalent one, so
+            # `frac` of the fp32 peak can exceed what an exact-fp32 kernel could reach
+            "update_score": mfma("gnnrag_update_score [BN,(2I+1)D]x[(2I+1)D,D] (k_gemm_f32, k-tiled)", flops_update(cfg),
                                  ms["update_score"]),
-            "relation_tables": mfma("gnnrag_relation_tables (k_gemm_f32 generated-A [2*rel_total, I*D]x[I*D, D])",
+            "relation_tables": mfma("gnnrag_relation_tables%s [2*rel_total, I*D]x[I*D, D] (%s)"
+                                    % ("_planes" if vq else "", "k_tables_vq, bf16x3 V form" if vq else
+                                       "k_tables_b3 / k_gemm_f32 generated-A"),
                                     2.0 * 2 * plan.rel_total * I * D * D, ms["relation_tables"]),
-            "update_score_fused": mfma("gnnrag_update_score_fused (k_gemm_f32 [BN,D]x[D,D] + nbr)",
+            "update_score_fused": mfma("gnnrag_update_score_fused [BN,D]x[D,D] + nbr (%s)"
+                                       % ("k_gemm_wres, exact fp32" if ops.get_dense_math() == ops.MATH_FP32
+                                          else "k_update_b3, bf16x3, where its shapes apply"),
                                        2.0 * B * N * D * D, ms["update_score_fused"]),
         },
         "kernel_ms": ms,
