@@ -26,7 +26,7 @@ def main(tag):
             shutil.copy(os.path.join(src, f), os.path.join(dst, tag + g))
     shutil.copy(os.path.join(src, "pmc_traffic_C2.json"), os.path.join(dst, "pmc_traffic.json"))
     other = {}
-    for w in ("C1", "C3", "C4", "C5", "C2fb", "C1_graph", "C3_graph"):
+    for w in ("C1", "C3", "C4", "C5", "C2fb", "C2u", "C1_graph", "C3_graph"):
         p = os.path.join(src, "bench_%s.log" % w)
         if os.path.exists(p):
             try:

@@ -23,7 +23,7 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python $R/bench.py --no-cpu-baseline --spread-steps 0 > $OUT/bench_under_rocprof.log 2>&1
 cd $R
 python tools/rocpd_stats.py $(find $OUT/trace -name 'bench_results.db' | head -1) > $OUT/kernel_stats_bench.txt 2>&1
-for W in C1 C3 C4 C5 C2fb; do
+for W in C1 C3 C4 C5 C2fb C2u; do
   cp $OUT/pmc_traffic_$W.json $R/profiles/pmc_traffic.json 2>/dev/null || cp $OUT/pmc_traffic_C2.json $R/profiles/pmc_traffic.json
   python bench.py --workload $W --no-cpu-baseline --steps 30 > $OUT/bench_$W.log 2>&1
 done
@@ -38,4 +38,4 @@ python tools/rocpd_stats.py $(find $OUT/trace_C5 -name 'bench_results.db' | head
 find $OUT -name '*.db' -delete
 tail -1 $OUT/bench_default.log | cut -c1-300
 head -12 $OUT/kernel_stats_bench.txt
-for W in C1 C3 C4 C5 C2fb C1_graph C3_graph; do echo -n "$W: "; tail -1 $OUT/bench_$W.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4), d['roofline']['kernel'][:60], round(d['roofline']['frac'],3))" 2>&1 | tail -1; done
+for W in C1 C3 C4 C5 C2fb C2u C1_graph C3_graph; do echo -n "$W: "; tail -1 $OUT/bench_$W.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4), d['roofline']['kernel'][:60], round(d['roofline']['frac'],3))" 2>&1 | tail -1; done
