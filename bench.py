@@ -59,8 +59,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: the chip needs ~20 steps after an idle period before its clocks (and the step time) settle - measured
-    # series at C2: 1.13, 0.91, 0.94, 0.98, ... 0.86 after 20 steps, one 32 ms host-side stall around step 20, p50 0.845
-    # (tools/probe/spread_probe.py) - so the default warm-up covers that ramp
+    # series at C2: 1.13, 0.91, 0.94, 0.98, ... 0.86 after 20 steps, p50 0.845 (tools/probe/spread_probe.py) - so the
+    # default warm-up covers that ramp
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="C2")
@@ -209,15 +209,22 @@ def main():
     # step-time spread: `spread_steps` further steps, each bracketed by its own HIP event pair (rank 0's device time)
     spread = None
     if args.spread_steps > 0:
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-               for _ in range(args.spread_steps)]
-        for a, b in evs:
-            a.record()
-            step()
-            b.record()
-        torch.cuda.synchronize()
+        # a pool of 16 event pairs, read back every 16 steps: hundreds of timing events outstanding at once made the
+        # HIP runtime grow its signal pool in the middle of the loop (one 30-60 ms host stall, seen as a "step")
+        pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(16)]
+        ts = []
+        done = 0
+        while done < args.spread_steps:
+            n = min(16, args.spread_steps - done)
+            for a, b in pool[:n]:
+                a.record()
+                step()
+                b.record()
+            torch.cuda.synchronize()
+            ts += [a.elapsed_time(b) for a, b in pool[:n]]
+            done += n
         drain()
-        ts = np.array([a.elapsed_time(b) for a, b in evs])
+        ts = np.array(ts)
         spread = {"n": int(len(ts)), "p05": float(np.percentile(ts, 5)), "p50": float(np.percentile(ts, 50)),
                   "p95": float(np.percentile(ts, 95)), "max": float(ts.max()), "mean": float(ts.mean()),
                   "unit": "ms per step, device time between HIP events (rank 0)"}
