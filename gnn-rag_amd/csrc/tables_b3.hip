@@ -683,8 +683,9 @@ __device__ __forceinline__ void update_b3_part(const UpdB3Args& a, unsigned char
       ap[1] = __builtin_bit_cast(bf16x8, ra[kb][1]);
       ap[2] = __builtin_bit_cast(bf16x8, ra[kb][0] + ra[kb][1]);
 #else
-      const Split3 s0 = split3(kok ? ra[kb][0] : zero4);
-      const Split3 s1 = split3(kok ? ra[kb][1] : zero4);
+      // only the LAST k block can reach past D (the launcher admits 192 < D <= 208): no select in the others
+      const Split3 s0 = split3(kb < NKB - 1 || kok ? ra[kb][0] : zero4);
+      const Split3 s1 = split3(kb < NKB - 1 || kok ? ra[kb][1] : zero4);
       ap[0] = __builtin_bit_cast(bf16x8, (u32x4){s0.hi.x, s0.hi.y, s1.hi.x, s1.hi.y});
       ap[1] = __builtin_bit_cast(bf16x8, (u32x4){s0.mid.x, s0.mid.y, s1.mid.x, s1.mid.y});
       ap[2] = __builtin_bit_cast(bf16x8, (u32x4){s0.lo.x, s0.lo.y, s1.lo.x, s1.lo.y});
