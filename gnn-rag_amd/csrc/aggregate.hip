@@ -31,6 +31,8 @@
 //  * destination nodes with more than kHeavyDeg facts (Freebase hubs) are cut into 256-fact
 //    chunks, one wave per chunk (k_heavy_partial), and reduced in chunk order (k_heavy_reduce):
 //    deterministic, no atomics, scales to hubs with 10^5 facts.
+#include <type_traits>
+
 #include "gnnrag_common.h"
 
 #ifndef GNNRAG_REASON_SLICE
@@ -432,6 +434,12 @@ __global__ __launch_bounds__(256) void k_heavy_reduce(const WalkArgs a, int na) 
 // shares them with width-4 shuffles.  Node sets are handed out by an LDS ticket so a set with a
 // hub does not hold up its wave's other sets.  All slice workgroups of a question run on one
 // XCD (workgroup b -> XCD b % 8), so their partial-line writes to out[] merge in that L2.
+#ifndef GNNRAG_SLICE_BRANCHLESS
+#define GNNRAG_SLICE_BRANCHLESS 1   // LDS walk: the 4 facts of a step are multiplied without per-fact branches
+#endif
+#ifndef GNNRAG_SLICE_BL_GROUP
+#define GNNRAG_SLICE_BL_GROUP 1
+#endif
 #ifndef GNNRAG_SLICE_ABL
 #define GNNRAG_SLICE_ABL 0      // timing-only ablations of k_walk_slice (wrong results): 1 no table staging loads,
 #endif                          // 2 no output stores, 8 no (p, rel) pair loads
@@ -491,14 +499,14 @@ __device__ __forceinline__ void set_load_rows(SetRows& s, const WalkArgs& a, int
   }
 }
 
-__device__ __forceinline__ void set_load_first(SetRows& s, const int2* const (&prd)[2], int sub) {
+__device__ __forceinline__ void set_load_first(SetRows& s, const int2* const (&prd)[2], int sub, int zr) {
 #pragma unroll
   for (int d = 0; d < 2; ++d)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
       s.first[d][h] = (s.valid && !s.big && 4 * h + sub < s.len[d])
                           ? ((GNNRAG_SLICE_ABL & 8) ? make_int2(0x3f800000, sub) : prd[d][s.beg[d] + 4 * h + sub])
-                          : make_int2(0, 0);
+                          : make_int2(0, zr);          // no fact: prior 0, the table's zero row
 }
 
 // value of lane k of this lane's quad (DPP quad_perm broadcast: VALU speed, no LDS crossbar)
@@ -523,10 +531,51 @@ template <int MODE, int NI> struct SliceAcc {
   }
 };
 
-// acc += sum over the 4 facts a lane group (one quad) holds one per lane in `pairs`
+// acc += sum over the 4 facts a lane group (one quad) holds one per lane in `pairs`.
+// Branch-free form (default): the four facts' (p, row) are broadcast, the four LDS rows are requested back to back and
+// multiplied after ONE wait - the per-fact `if (p != 0)` of the first form cost 4 of its 11 instructions per fact and
+// serialised four LDS round trips per step.  Slots without a fact carry (p = 0, row = the table's extra ZERO row), so
+// they add exactly 0; a real fact with p = 0 adds 0 * t like the reference's fact_val * fact_prior (reasongnn.py:82).
+// One wave-uniform test skips a step none of whose 64 facts has a prior (seed priors: most steps).
 template <int MODE, int NI>
 __device__ __forceinline__ void slice_fma4(SliceAcc<MODE, NI>& acc, int2 pairs, const float* __restrict__ Td,
                                            const f32x4 (&q)[SliceAcc<MODE, NI>::n]) {
+#if GNNRAG_SLICE_BRANCHLESS
+  if (__ballot(pairs.x != 0) == 0) return;               // (p >= 0: bits == 0 <=> p == 0)
+  constexpr int NT = (MODE == MODE_REASON) ? 1 : NI;     // table float4s per fact
+  // G facts' rows are in flight together (two 1024-thread workgroups per CU leave 64 VGPRs: the broadcasts are made
+  // per group, not up front)
+  auto group = [&](auto k0c) {
+    constexpr int k0 = decltype(k0c)::value;
+    constexpr int G = GNNRAG_SLICE_BL_GROUP;
+    float pk[G];
+    int rk[G];
+    f32x4 t[G][NT];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      pk[k] = __int_as_float(k0 + k == 0 ? quad_bcast<0>(pairs.x) : k0 + k == 1 ? quad_bcast<1>(pairs.x)
+                             : k0 + k == 2 ? quad_bcast<2>(pairs.x) : quad_bcast<3>(pairs.x));
+      rk[k] = k0 + k == 0 ? quad_bcast<0>(pairs.y) : k0 + k == 1 ? quad_bcast<1>(pairs.y)
+              : k0 + k == 2 ? quad_bcast<2>(pairs.y) : quad_bcast<3>(pairs.y);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+        t[k][i] = *reinterpret_cast<const f32x4*>(Td + (size_t)rk[k] * SliceAcc<MODE, NI>::width + kSliceW * i);
+    }
+#pragma unroll
+    for (int k = 0; k < G; ++k)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        if constexpr (MODE == MODE_REASON) acc.v[i] += pk[k] * vrelu(t[k][0] * q[i]);
+        else acc.v[i] += pk[k] * t[k][i];
+      }
+  };
+  group(std::integral_constant<int, 0>{});
+  if constexpr (GNNRAG_SLICE_BL_GROUP < 4) group(std::integral_constant<int, GNNRAG_SLICE_BL_GROUP>{});
+  if constexpr (GNNRAG_SLICE_BL_GROUP == 1) {
+    group(std::integral_constant<int, 2>{});
+    group(std::integral_constant<int, 3>{});
+  }
+#else
 #define GNNRAG_SLICE_STEP(K)                                                                        \
   {                                                                                                 \
     const float pk = __int_as_float(quad_bcast<K>(pairs.x));                                        \
@@ -544,6 +593,7 @@ __device__ __forceinline__ void slice_fma4(SliceAcc<MODE, NI>& acc, int2 pairs, 
   }
   GNNRAG_SLICE_STEP(0) GNNRAG_SLICE_STEP(1) GNNRAG_SLICE_STEP(2) GNNRAG_SLICE_STEP(3)
 #undef GNNRAG_SLICE_STEP
+#endif
 }
 
 // one direction of one row, walked by a whole wave: 64 facts per step (lane group k owns facts
@@ -552,7 +602,7 @@ template <int MODE, int NI>
 __device__ __forceinline__ void slice_walk_wave(SliceAcc<MODE, NI>& acc, const int2* __restrict__ prd, int beg,
                                                 int len, int first, int stride, int lane,
                                                 const float* __restrict__ Td,
-                                                const f32x4 (&q)[SliceAcc<MODE, NI>::n]) {
+                                                const f32x4 (&q)[SliceAcc<MODE, NI>::n], int zr) {
   const int nsteps = (len + 63) >> 6;
   constexpr int INF = (SliceAcc<MODE, NI>::n > 1 && MODE == MODE_FUSED) ? 4 : 8;   // steps in flight (register budget)
   for (int st = first; st < nsteps; st += stride * INF) {
@@ -560,7 +610,7 @@ __device__ __forceinline__ void slice_walk_wave(SliceAcc<MODE, NI>& acc, const i
 #pragma unroll
     for (int u = 0; u < INF; ++u) {
       const int off = (st + stride * u) * 64 + lane;
-      pairs[u] = (off < len) ? prd[beg + off] : make_int2(0, 0);
+      pairs[u] = (off < len) ? prd[beg + off] : make_int2(0, zr);
     }
 #pragma unroll
     for (int u = 0; u < INF; ++u) slice_fma4<MODE, NI>(acc, pairs[u], Td, q);
@@ -596,9 +646,9 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
   constexpr int NA = Acc::n;
   constexpr int ND = (MODE == MODE_REASON) ? 2 : 1;     // output slots per node: per direction / summed
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
-  float* Ts = s_mem;                                   // [2][Rg][16] (room for [2][R1][16])
+  float* Ts = s_mem;                                   // [2][Rg + 1][16] (room for [2][R1 + 1][16]); row Rg is zero
   constexpr int SW = Acc::width;                       // floats per staged table row
-  int* ctl = reinterpret_cast<int*>(s_mem + (size_t)2 * a.R1 * SW);   // [0] the ticket
+  int* ctl = reinterpret_cast<int*>(s_mem + (size_t)2 * (a.R1 + 1) * SW);   // [0] the ticket
   int* blist = ctl + 16;                               // [kSliceBigCap][5]: node, beg0, len0, beg1, len1
   float* red = reinterpret_cast<float*>(blist + 5 * kSliceBigCap);   // [16 waves][NA][16 floats]
   // XCD-aware order: the nslice workgroups of question g all land on XCD g % 8.  An XCD's work items
@@ -651,7 +701,11 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     const float* tab = a.T[d] + (size_t)roff * D;
     if (!(GNNRAG_SLICE_ABL & 1) && col0 + 4 * k < D) v = *reinterpret_cast<const f32x4*>(tab + (size_t)r * D + col0 + 4 * k);
-    *reinterpret_cast<f32x4*>(Ts + ((size_t)d * Rg + r) * SW + 4 * k) = v;
+    *reinterpret_cast<f32x4*>(Ts + ((size_t)d * (Rg + 1) + r) * SW + 4 * k) = v;
+  }
+  if (tid < 2 * GR) {                                  // the zero row of each direction (slots without a fact point at it)
+    const int d = tid / GR, k = tid % GR;
+    *reinterpret_cast<f32x4*>(Ts + ((size_t)d * (Rg + 1) + Rg) * SW + 4 * k) = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   __syncthreads();
 
@@ -662,7 +716,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
 #pragma unroll
   for (int i = 0; i < NA; ++i) col_ok[i] = col0 + Acc::coff(i) + 4 * sub < D;
   const int2* const prd[2] = {pr, pr + F};
-  const float* Td[2] = {Ts + 4 * sub, Ts + (size_t)Rg * SW + 4 * sub};
+  const float* Td[2] = {Ts + 4 * sub, Ts + (size_t)(Rg + 1) * SW + 4 * sub};
   f32x4 q[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
@@ -682,7 +736,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
       acc.zero();
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
-        slice_walk_wave<MODE, NI>(acc, prd[d], e[1 + 2 * d], e[2 + 2 * d], wave, 16, lane, Td[d], q);
+        slice_walk_wave<MODE, NI>(acc, prd[d], e[1 + 2 * d], e[2 + 2 * d], wave, 16, lane, Td[d], q, Rg);
         if (ND == 2 || d == 1) {
           slice_wave_reduce<MODE, NI>(acc);
           if (grp == 0) {
@@ -724,7 +778,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
       acc.zero();
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
-        slice_walk_wave<MODE, NI>(acc, prd[d], e[1 + 2 * d], e[2 + 2 * d], 0, 1, lane, Td[d], q);
+        slice_walk_wave<MODE, NI>(acc, prd[d], e[1 + 2 * d], e[2 + 2 * d], 0, 1, lane, Td[d], q, Rg);
         if (ND == 2 || d == 1) {
           slice_wave_reduce<MODE, NI>(acc);
           if (grp == 0) {
@@ -743,15 +797,15 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
   set_load_rows(s0, a, g, t0, nsets, grp);
   int t1 = t0 < nsets ? next_set() : nsets;
   set_load_rows(s1, a, g, t1, nsets, grp);
-  set_load_first(s0, prd, sub);
+  set_load_first(s0, prd, sub, Rg);
   while (t0 < nsets) {
     const int t2 = t1 < nsets ? next_set() : nsets;
     set_load_rows(s2, a, g, t2, nsets, grp);
-    set_load_first(s1, prd, sub);
+    set_load_first(s1, prd, sub, Rg);
 
     if (s0.valid && s0.big && nlist == 0) {     // no list for this question: the owner group walks it
       s0.big = false;
-      set_load_first(s0, prd, sub);
+      set_load_first(s0, prd, sub, Rg);
     }
     if (s0.valid && !s0.big) {
       Acc acc;
@@ -761,7 +815,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
         const int beg = s0.beg[d], len = s0.len[d];
         int2 c0 = s0.first[d][0], c1 = s0.first[d][1];
         for (int j = 0; j < len; j += 8) {
-          int2 n0 = make_int2(0, 0), n1 = make_int2(0, 0);
+          int2 n0 = make_int2(0, Rg), n1 = make_int2(0, Rg);
           if (!(GNNRAG_SLICE_ABL & 8) && j + 8 + sub < len) n0 = prd[d][beg + j + 8 + sub];
           if (!(GNNRAG_SLICE_ABL & 8) && j + 12 + sub < len) n1 = prd[d][beg + j + 12 + sub];
           slice_fma4<MODE, NI>(acc, c0, Td[d], q);
@@ -871,7 +925,7 @@ static size_t prior_bytes(const gnnrag_csr* csr) {
   return align_up((size_t)2 * (size_t)(csr->F > 0 ? csr->F : 1) * sizeof(int2), 256);
 }
 static size_t slice_lds_bytes(int R1, int na = 3, int width = kSliceW) {
-  return (size_t)2 * R1 * width * sizeof(float) + (16 + 5 * kSliceBigCap) * sizeof(int) +
+  return (size_t)2 * (R1 + 1) * width * sizeof(float) + (16 + 5 * kSliceBigCap) * sizeof(int) +
          (size_t)na * 16 * 16 * sizeof(float);
 }
 // the LDS variant needs the two table slices of a question in one CU's LDS (160 KB); rows = table rows
