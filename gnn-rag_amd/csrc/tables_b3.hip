@@ -1,4 +1,11 @@
-// Per-question relation tables of the fused path in the bf16x3 math mode, on a W-resident kernel.
+// The bf16x3 W-resident kernels of the fused path (gfx950):
+//   k_tables_b3   relation tables, operand relu(T * ins) generated in registers (a lone gnnrag_relation_tables call)
+//   k_tables_vq   relation tables in "V form" from pre-split relation planes (what a layer / stack call runs)
+//   k_update_b3   the self-block update h' = relu(h W^T + b + nbr) with the fused score
+// They share the LDS weight-plane layout (three bf16 planes of an exact 3-way split, 26-slot row stride), the six
+// plane products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation, and the register epilogue.
+//
+// ---- k_tables_b3: per-question relation tables of the fused path, operand generated on the fly ----------------------
 //
 //   P[d, m, :] = sum_i  W_e2e[:, (1+2i+d)D : (2+2i+d)D] . relu( T_d[r_m, :] * ins[b_m, i, :] )      m = compact row (b_m, r_m)
 //

@@ -56,6 +56,16 @@ def test_size_queries_and_struct_layout(lib):
     # T tables + the larger of {agg [BN,2I*D]} / {P [2,rel_total,D] + nbr [BN,D]} + heavy-chunk partials
     assert ws >= 2 * 602 * 200 * 4 + 128000 * 800 * 4 + 2 * c.max_chunks * 2 * 200 * 4
     assert lib.gnnrag_aggregate_workspace_bytes(ctypes.byref(c), 200, 2) >= 2 * c.max_chunks * 2 * 200 * 4
+    # the stack workspace adds all L layers' relation projections [L,2,R1,D] and, at the V-form table kernel's hidden
+    # sizes, their bf16 planes [L,2,3,R1,448]
+    planes = lib.gnnrag_rel_planes_bytes(602, 200, 3)
+    assert planes == 3 * 2 * 3 * 602 * 448 * 2
+    assert lib.gnnrag_stack_workspace_bytes(ctypes.byref(c), 3, 200, 2) >= ws + 3 * 2 * 602 * 200 * 4 + planes
+    assert lib.gnnrag_stack_workspace_bytes(ctypes.byref(c), 3, 64, 2) >= lib.gnnrag_layer_workspace_bytes(ctypes.byref(c), 64, 2) + 3 * 2 * 602 * 64 * 4
+    assert lib.gnnrag_rel_planes_bytes(602, 300, 3) == 0 and lib.gnnrag_stack_workspace_bytes(None, 3, 200, 2) == 0
+    # weight-gradient GEMM: partial blocks of [N1, N2] per row chunk
+    tn = lib.gnnrag_gemm_tn_workspace_bytes(128000, 200, 200)
+    assert tn >= 200 * 200 * 4 and tn % (200 * 200 * 4) == 0 and lib.gnnrag_gemm_tn_workspace_bytes(0, 200, 200) == 0
 
 
 def test_argument_errors_without_gpu(lib):
@@ -74,6 +84,23 @@ def test_argument_errors_without_gpu(lib):
     c.rel_max = 6001
     assert lib.gnnrag_aggregate_fused_variant(ctypes.byref(c), 200) == 0         # tables exceed a CU's LDS
     assert lib.gnnrag_aggregate_fused_variant(None, 200) == -1
+    # round-2 entry points: null pointers / bad sizes -> BADARG, shapes outside a kernel's set -> UNSUPPORTED (-2),
+    # nothing is launched either way
+    assert lib.gnnrag_rel_transform(None, None, 10, 8, 1, None, 0, None, None, None) == -1
+    lp = (_lib.LayerParams * 1)()
+    lp[0].W_rel, lp[0].b_rel = 256, 256
+    assert lib.gnnrag_rel_transform(one, one, 10, 6, 1, lp, 0, one, None, None) == -2        # D % 4 != 0
+    assert lib.gnnrag_rel_transform(one, one, 10, 300, 1, lp, 0, one, one, None) == -2      # planes need D <= 224
+    assert lib.gnnrag_relation_tables_planes(None, None, None, None, None, 200, 2, None) == -1
+    c.rel_total, c.rel_max = 100, 50
+    assert lib.gnnrag_relation_tables_planes(ctypes.byref(c), one, one, one, one, 200, 2, None) == -2   # < 1024 rows
+    assert lib.gnnrag_gemm_tn(None, None, 10, 8, 8, None, None, 0, None) == -1
+    assert lib.gnnrag_gemm_tn(one, one, 10, 6, 8, one, one, 1 << 20, None) == -2            # N1 % 4 != 0
+    assert lib.gnnrag_gemm_tn(one, one, 10, 8, 8, one, None, 0, None) == -3                 # workspace too small
+    # path flags: one direction only, not both
+    args = [ctypes.byref(c)] + [one] * 9 + [0] + [one] * 8 + [one, 1 << 30, 200, 2]
+    assert lib.gnnrag_reason_layer(*args, 2 | 0x10 | 0x20, 2, None) == -1
+    assert lib.gnnrag_reason_layer(*args, 5, 2, None) == -1
 
 
 def test_module_surface_matches_reference_state_dict():
@@ -110,6 +137,13 @@ def test_product_refuses_to_run_without_gpu():
                           query_entities=torch.zeros(cfg.B, cfg.N))
     with pytest.raises(_lib.GnnragError):
         ops.linear(torch.zeros(4, 4), torch.zeros(4, 4))
+    with pytest.raises(_lib.GnnragError):
+        ops.gemm_tn(torch.zeros(8, 4), torch.zeros(8, 4))
+    with pytest.raises(_lib.GnnragError):
+        ops.rel_transform(torch.zeros(4, 8), torch.zeros(4, 8), [(torch.zeros(8, 8), torch.zeros(8), None, None)])
+    from gnnrag_amd.autograd import linear as ag_linear
+    with pytest.raises(_lib.GnnragError):                    # the training-path projections have no CPU form either
+        ag_linear(torch.zeros(4, 8, requires_grad=True), torch.zeros(8, 8), torch.zeros(8))
 
 
 def test_no_product_module_imports_the_oracle():
