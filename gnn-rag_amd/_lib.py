@@ -30,6 +30,7 @@ class CsrStruct(C.Structure):
         ("big_deg", C.c_int32), ("reserved_", C.c_int32),
         ("edge_l", C.c_void_p * 2), ("rel_off", C.c_void_p), ("rel_rows", C.c_void_p),
         ("rel_total", C.c_int32), ("rel_max", C.c_int32),
+        ("mpos", C.c_void_p * 2),
     ]
 
 
@@ -106,7 +107,7 @@ SIGNATURES = {
     "gnnrag_error_string": (C.c_char_p, [C.c_int]),
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 PATH_AUTO, PATH_UNFUSED, PATH_FUSED = 0, 1, 2
 PATH_ONLY_FWD, PATH_ONLY_INV = 0x10, 0x20        # OR-ed into the path: one-direction layers (NSM)
 E_TUPLE = -4

@@ -109,6 +109,9 @@ struct WalkArgs {
   const int32_t* big_nodes;
   int32_t big_deg;
   int32_t skip_dir;           // LDS walk: 1 + direction to leave out (one-direction layers, NSM), 0 = walk both
+  int32_t merged;             // LDS walk (FUSED): a node's facts of both directions are ONE run of the pair stream
+                              // (gnnrag_csr::mpos); direction 1's pairs carry table rows offset by Rg + 1
+  const int32_t* mpos[2];
 };
 
 template <int MODE, int NI> struct AccN { static constexpr int n = (MODE == MODE_REASON) ? NI : 1; };
@@ -437,6 +440,9 @@ __global__ __launch_bounds__(256) void k_heavy_reduce(const WalkArgs a, int na) 
 #ifndef GNNRAG_SLICE_BRANCHLESS
 #define GNNRAG_SLICE_BRANCHLESS 1   // LDS walk: the 4 facts of a step are multiplied without per-fact branches
 #endif
+#ifndef GNNRAG_SLICE_MERGED
+#define GNNRAG_SLICE_MERGED 1      // fused LDS walk over merged rows (both directions of a node in one loop)
+#endif
 #ifndef GNNRAG_SLICE_BL_GROUP
 #define GNNRAG_SLICE_BL_GROUP 1
 #endif
@@ -459,6 +465,32 @@ __global__ __launch_bounds__(256) void k_fact_prior(const int2* __restrict__ e0,
   int r;
   load_fact<MODE_FUSED>(edge, w, dist, 0, (int)i, (int)F, p, r);
   pr[(size_t)d * F + i] = make_int2(__float_as_int(p), r);
+}
+
+// the same pairs written to their place in the MERGED stream (gnnrag_csr::mpos): a node's facts of direction 0, then
+// of direction 1, contiguous; direction 1's table rows are addressed behind direction 0's slice (row + Rg + 1, Rg =
+// relations the question uses: the LDS layout is [2][Rg + 1][16])
+__global__ __launch_bounds__(256) void k_fact_prior_merged(const int2* __restrict__ e0, const int2* __restrict__ e1,
+                                                           const float* __restrict__ w0, const float* __restrict__ w1,
+                                                           const float* __restrict__ dist,
+                                                           const int32_t* __restrict__ m0, const int32_t* __restrict__ m1,
+                                                           const int32_t* __restrict__ rel_off, int N, int64_t F,
+                                                           int2* __restrict__ pr) {
+  const int d = blockIdx.y;
+  const int2* edge = d ? e1 : e0;
+  const float* w = d ? w1 : w0;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= F) return;
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  const i32x2 e = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(edge) + i);
+  float p = dist[e.x];
+  if (w) p *= __builtin_nontemporal_load(w + i);
+  int r = e.y;
+  if (d) {
+    const int q = e.x / N;
+    r += rel_off[q + 1] - rel_off[q] + 1;
+  }
+  pr[(d ? m1 : m0)[i]] = make_int2(__float_as_int(p), r);
 }
 
 // Node classes of the LDS walk (by the larger of the two directions' fact counts):
@@ -496,6 +528,12 @@ __device__ __forceinline__ void set_load_rows(SetRows& s, const WalkArgs& a, int
       s.len[d] = a.skip_dir == d + 1 ? 0 : a.row_ptr[d][s.n + 1] - s.beg[d];
       s.big |= s.len[d] > a.big_deg;
     }
+  }
+  if (a.merged) {           // both directions as one run: [rp0[n] + rp1[n], rp0[n+1] + rp1[n+1])
+    s.beg[0] += s.beg[1];
+    s.len[0] += s.len[1];
+    s.beg[1] = 0;
+    s.len[1] = 0;
   }
 }
 
@@ -688,6 +726,12 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
       const int beg = a.row_ptr[d][n];
       e[1 + 2 * d] = beg;
       e[2 + 2 * d] = a.skip_dir == d + 1 ? 0 : a.row_ptr[d][n + 1] - beg;
+    }
+    if (a.merged) {
+      e[1] += e[3];
+      e[2] += e[4];
+      e[3] = 0;
+      e[4] = 0;
     }
   }
   // stage the two table slices (float4 granules; rows are D*4 bytes apart).  FUSED: the question's own
@@ -969,8 +1013,12 @@ static int launch_slice(const WalkArgs& a, const gnnrag_csr* csr, void* workspac
   int2* pr = (int2*)((char*)workspace + partial_bytes(csr, D, na_ws));
   const int64_t F = csr->F;
   if (F > 0 && a.i0 == 0) {     // the (p, rel) pairs do not depend on the instruction pass
-    hipLaunchKernelGGL(k_fact_prior, dim3((unsigned)((F + 255) / 256), 2), dim3(256), 0, stream, a.edge[0],
-                       a.edge[1], a.w[0], a.w[1], a.dist, F, pr);
+    if (a.merged)
+      hipLaunchKernelGGL(k_fact_prior_merged, dim3((unsigned)((F + 255) / 256), 2), dim3(256), 0, stream, a.edge[0],
+                         a.edge[1], a.w[0], a.w[1], a.dist, a.mpos[0], a.mpos[1], a.rel_off, a.N, F, pr);
+    else
+      hipLaunchKernelGGL(k_fact_prior, dim3((unsigned)((F + 255) / 256), 2), dim3(256), 0, stream, a.edge[0],
+                         a.edge[1], a.w[0], a.w[1], a.dist, F, pr);
     GNNRAG_LAUNCH_CHECK();
   }
   constexpr int SW = SliceAcc<MODE, NI>::width;
@@ -1067,6 +1115,10 @@ int gnnrag::aggregate_fused_dirs(const gnnrag_csr* csr, const float* dist, const
   a.out = out;
   a.I = 1;
   a.skip_dir = skip_dir;
+  // merged rows: whenever both directions are walked and the structure carries the merged positions
+  a.merged = (GNNRAG_SLICE_MERGED && skip_dir == 0 && csr->mpos[0] && csr->mpos[1]) ? 1 : 0;
+  a.mpos[0] = csr->mpos[0];
+  a.mpos[1] = csr->mpos[1];
   switch (gnnrag_aggregate_fused_variant(csr, D)) {
     case GNNRAG_WALK_L2_GATHER: return launch_walk<MODE_FUSED>(a, 1, stream);   // tables too big for LDS
     // 32-column slices when two of them still fit a CU's LDS (questions that use up to ~300 relations): half

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GNNRAG_ABI_VERSION 8
+#define GNNRAG_ABI_VERSION 9
 
 #define GNNRAG_E_BADARG      (-1)  /* null pointer / negative size / inconsistent sizes   */
 #define GNNRAG_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set (see DESIGN)  */
@@ -81,6 +81,11 @@ typedef struct gnnrag_csr {
   int32_t* rel_rows;    /* [rel_total][2]  (question, relation id) of every compact row        */
   int32_t  rel_total;   /* compact rows in the batch (host copy, filled by gnnrag_csr_build)   */
   int32_t  rel_max;     /* largest number of relations used by one question                    */
+  /* Merged rows (fused LDS walk): the facts arriving at node n in direction 0 followed by those of direction 1 form
+   * ONE run [row_ptr[0][n] + row_ptr[1][n], row_ptr[0][n+1] + row_ptr[1][n+1]) of a 2F-long stream; mpos[d][i] is the
+   * place of direction d's i-th sorted fact in it.  The walk then steps through a node's facts of both directions in
+   * one loop (same summation order: direction 0's facts in ascending fact id, then direction 1's). */
+  int32_t* mpos[2];     /* [F]                                                                  */
 } gnnrag_csr;
 
 /* Bytes of caller-owned device memory a gnnrag_csr needs (persistent part / build scratch). */

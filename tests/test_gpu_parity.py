@@ -71,6 +71,16 @@ def test_csr_plan_bit_exact(dev, name):
         np.testing.assert_array_equal(el[:, 0], e[:, 0])
         q = e[:, 0] // cfg.N
         np.testing.assert_array_equal(got["rel_rows"][got["rel_off"][q] + el[:, 1]], np.stack([q, e[:, 1]], 1))
+    # merged rows: node n's facts of direction 0, then of direction 1, as one run of a 2F-long stream
+    dst = {0: t, 1: h}
+    rp0, rp1 = want["row_ptr0"].astype(np.int64), want["row_ptr1"].astype(np.int64)
+    F = len(h)
+    for d in (0, 1):
+        n_of = dst[d][want["perm%d" % d]]                          # destination of every sorted position
+        pos = np.arange(F)
+        np.testing.assert_array_equal(got["mpos%d" % d], pos + (rp1[n_of] if d == 0 else rp0[n_of + 1]))
+    merged = np.concatenate([got["mpos0"], got["mpos1"]])
+    assert np.array_equal(np.sort(merged), np.arange(2 * F))        # a permutation of the stream
     if name == "mid":
         assert got["n_heavy"].sum() > 0, "the Zipf hub must exercise the heavy-row path"
 
@@ -724,7 +734,7 @@ def test_update_bf16x3_w_resident_vs_exact_fp32(dev, M, D):
 @pytest.mark.parametrize("direction", [0, 1], ids=["fwd", "inv"])
 def test_one_direction_layer_skips_the_other_direction(dev, direction, capsys):
     """NSM layers aggregate along ONE direction (nsm_gnn.py:87-112 / :118-142): with GNNRAG_PATH_ONLY_FWD / _INV only
-    that direction's relation tables are built (V form) and walked (LDS walk).  Bit-identical to the both-direction
+    that direction's relation tables are built (V form) and walked (LDS walk).  Same results as the both-direction
     call with a zero weight block for the other direction, which is what small / odd shapes still run."""
     from gnnrag_amd import _lib, ops, stack, synth
     cfg = synth.GraphConfig(name="nsm1d", B=16, N=2000, E=10000, R=600, D=200, I=1, L=1, T=1, seed=31 + direction)
@@ -746,8 +756,11 @@ def test_one_direction_layer_skips_the_other_direction(dev, direction, capsys):
     flag = _lib.PATH_ONLY_INV if direction else _lib.PATH_ONLY_FWD
     both = ops.reason_layer(*args, path=_lib.PATH_FUSED)
     one = ops.reason_layer(*args, path=_lib.PATH_FUSED | flag)
+    # equal up to the summation order in hub rows: the both-direction call walks a node's facts of both directions as one
+    # merged run (the zero block's facts add exact zeros, but the wave-per-hub partial sums group differently)
     for a, b in zip(both, one):
-        assert torch.equal(a, b)
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
+    assert torch.equal(both[2].argmax(1), one[2].argmax(1))
     import bench
     t_both = float(np.mean(bench._events_ms(lambda: ops.reason_layer(*args, path=_lib.PATH_FUSED), 10)))
     t_one = float(np.mean(bench._events_ms(lambda: ops.reason_layer(*args, path=_lib.PATH_FUSED | flag), 10)))

@@ -37,6 +37,7 @@ VARIANTS = {
     # merges them (4x fewer MFMAs): they bound nothing.  upd_halfmfma (3 of 6 plane products) is the honest MFMA probe.
     # k_walk_slice (aggregate.hip): 1 no table staging loads, 2 no output stores, 8 no pair loads; GNNRAG_TUNE_WORKLOAD=C2u
     # runs the same on uniformly drawn heads (what the degree skew costs)
+    "sl_unmerged": {"GNNRAG_SLICE_MERGED": 0},
     "sl_branchy": {"GNNRAG_SLICE_BRANCHLESS": 0}, "sl_g1": {"GNNRAG_SLICE_BL_GROUP": 1}, "sl_g2": {"GNNRAG_SLICE_BL_GROUP": 2},
     "sl_g4": {"GNNRAG_SLICE_BL_GROUP": 4},
     "sl_nostage": {"GNNRAG_SLICE_ABL": 1}, "sl_nostore": {"GNNRAG_SLICE_ABL": 2},
