@@ -110,8 +110,9 @@ struct WalkArgs {
   int32_t big_deg;
   int32_t skip_dir;           // LDS walk: 1 + direction to leave out (one-direction layers, NSM), 0 = walk both
   int32_t merged;             // LDS walk (FUSED): a node's facts of both directions are ONE run of the pair stream
-                              // (gnnrag_csr::mpos); direction 1's pairs carry table rows offset by Rg + 1
-  const int32_t* mpos[2];
+                              // (gnnrag_csr::edge_m); direction 1's pairs carry table rows offset by Rg + 1
+  const int2* edge_m;
+  const int32_t* m_from;
 };
 
 template <int MODE, int NI> struct AccN { static constexpr int n = (MODE == MODE_REASON) ? NI : 1; };
@@ -467,30 +468,22 @@ __global__ __launch_bounds__(256) void k_fact_prior(const int2* __restrict__ e0,
   pr[(size_t)d * F + i] = make_int2(__float_as_int(p), r);
 }
 
-// the same pairs written to their place in the MERGED stream (gnnrag_csr::mpos): a node's facts of direction 0, then
-// of direction 1, contiguous; direction 1's table rows are addressed behind direction 0's slice (row + Rg + 1, Rg =
-// relations the question uses: the LDS layout is [2][Rg + 1][16])
-__global__ __launch_bounds__(256) void k_fact_prior_merged(const int2* __restrict__ e0, const int2* __restrict__ e1,
+// the pairs of the MERGED stream (gnnrag_csr::edge_m: a node's facts of direction 0, then of direction 1, contiguous;
+// direction 1's relation index already points behind direction 0's table slice): one coalesced pass over 2F records
+__global__ __launch_bounds__(256) void k_fact_prior_merged(const int2* __restrict__ em, const int32_t* __restrict__ from,
                                                            const float* __restrict__ w0, const float* __restrict__ w1,
-                                                           const float* __restrict__ dist,
-                                                           const int32_t* __restrict__ m0, const int32_t* __restrict__ m1,
-                                                           const int32_t* __restrict__ rel_off, int N, int64_t F,
+                                                           const float* __restrict__ dist, int64_t F,
                                                            int2* __restrict__ pr) {
-  const int d = blockIdx.y;
-  const int2* edge = d ? e1 : e0;
-  const float* w = d ? w1 : w0;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= F) return;
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= 2 * F) return;
   typedef int i32x2 __attribute__((ext_vector_type(2)));
-  const i32x2 e = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(edge) + i);
+  const i32x2 e = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(em) + j);
   float p = dist[e.x];
-  if (w) p *= __builtin_nontemporal_load(w + i);
-  int r = e.y;
-  if (d) {
-    const int q = e.x / N;
-    r += rel_off[q + 1] - rel_off[q] + 1;
+  if (w0) {
+    const int f = from[j];
+    p *= f < F ? w0[f] : w1[f - F];
   }
-  pr[(d ? m1 : m0)[i]] = make_int2(__float_as_int(p), r);
+  pr[j] = make_int2(__float_as_int(p), e.y);
 }
 
 // Node classes of the LDS walk (by the larger of the two directions' fact counts):
@@ -1014,8 +1007,8 @@ static int launch_slice(const WalkArgs& a, const gnnrag_csr* csr, void* workspac
   const int64_t F = csr->F;
   if (F > 0 && a.i0 == 0) {     // the (p, rel) pairs do not depend on the instruction pass
     if (a.merged)
-      hipLaunchKernelGGL(k_fact_prior_merged, dim3((unsigned)((F + 255) / 256), 2), dim3(256), 0, stream, a.edge[0],
-                         a.edge[1], a.w[0], a.w[1], a.dist, a.mpos[0], a.mpos[1], a.rel_off, a.N, F, pr);
+      hipLaunchKernelGGL(k_fact_prior_merged, dim3((unsigned)((2 * F + 255) / 256)), dim3(256), 0, stream, a.edge_m,
+                         a.m_from, a.w[0], a.w[1], a.dist, F, pr);
     else
       hipLaunchKernelGGL(k_fact_prior, dim3((unsigned)((F + 255) / 256), 2), dim3(256), 0, stream, a.edge[0],
                          a.edge[1], a.w[0], a.w[1], a.dist, F, pr);
@@ -1116,9 +1109,9 @@ int gnnrag::aggregate_fused_dirs(const gnnrag_csr* csr, const float* dist, const
   a.I = 1;
   a.skip_dir = skip_dir;
   // merged rows: whenever both directions are walked and the structure carries the merged positions
-  a.merged = (GNNRAG_SLICE_MERGED && skip_dir == 0 && csr->mpos[0] && csr->mpos[1]) ? 1 : 0;
-  a.mpos[0] = csr->mpos[0];
-  a.mpos[1] = csr->mpos[1];
+  a.merged = (GNNRAG_SLICE_MERGED && skip_dir == 0 && csr->edge_m && csr->m_from) ? 1 : 0;
+  a.edge_m = (const int2*)csr->edge_m;
+  a.m_from = csr->m_from;
   switch (gnnrag_aggregate_fused_variant(csr, D)) {
     case GNNRAG_WALK_L2_GATHER: return launch_walk<MODE_FUSED>(a, 1, stream);   // tables too big for LDS
     // 32-column slices when two of them still fit a CU's LDS (questions that use up to ~300 relations): half

@@ -23,7 +23,7 @@ namespace gnnrag {
 
 struct CsrLayout {
   size_t row_ptr[2], edge[2], perm[2], w_gnn[2], w_rel[2], heavy[2], chunk_off[2], n_heavy, big_cnt, big_nodes;
-  size_t edge_l[2], rel_off, rel_rows, mpos[2], total;
+  size_t edge_l[2], rel_off, rel_rows, edge_m, m_from, total;
   int32_t heavy_cap;
 };
 
@@ -52,7 +52,8 @@ static CsrLayout csr_layout(int64_t F, int32_t B, int32_t N, int32_t R1, int has
   L.rel_off = take(((size_t)B + 1) * sizeof(int32_t));
   const size_t BR = (size_t)B * (size_t)R1;
   L.rel_rows = take((BR < Fp ? BR : Fp) * 2 * sizeof(int32_t));   // every compact row has >= 1 fact
-  for (int d = 0; d < 2; ++d) L.mpos[d] = take(Fp * sizeof(int32_t));
+  L.edge_m = take(2 * Fp * 2 * sizeof(int32_t));
+  L.m_from = take(2 * Fp * sizeof(int32_t));
   L.total = off;
   return L;
 }
@@ -132,23 +133,32 @@ __global__ __launch_bounds__(256) void k_csr_heavy(const int32_t* __restrict__ r
   }
 }
 
-// merged position of every sorted fact (see gnnrag.h: mpos): direction 0's facts of node n come first in the node's
-// merged run, then direction 1's
-__global__ __launch_bounds__(256) void k_csr_mpos(const int32_t* __restrict__ perm0, const int32_t* __restrict__ perm1,
-                                                  const int32_t* __restrict__ heads, const int32_t* __restrict__ tails,
-                                                  const int32_t* __restrict__ rp0, const int32_t* __restrict__ rp1,
-                                                  int64_t F, int32_t* __restrict__ mpos0, int32_t* __restrict__ mpos1) {
+// the merged record stream (see gnnrag.h: edge_m / m_from): node n's facts of direction 0 come first in the node's run
+// [rp0[n] + rp1[n], rp0[n+1] + rp1[n+1]), then direction 1's, whose compact relation index is moved behind the first
+// table slice (+ the question's relation count + 1)
+__global__ __launch_bounds__(256) void k_csr_merge(const int32_t* __restrict__ perm0, const int32_t* __restrict__ perm1,
+                                                   const int32_t* __restrict__ heads, const int32_t* __restrict__ tails,
+                                                   const int32_t* __restrict__ rp0, const int32_t* __restrict__ rp1,
+                                                   const int2* __restrict__ el0, const int2* __restrict__ el1,
+                                                   const int32_t* __restrict__ rel_off, int32_t N, int64_t F,
+                                                   int2* __restrict__ edge_m, int32_t* __restrict__ m_from) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= F) return;
   if (blockIdx.y == 0) {
     const int n = tails[perm0[i]];                // destination in direction 0
-    mpos0[i] = (int32_t)i + rp1[n];
+    const int64_t m = i + rp1[n];
+    edge_m[m] = el0[i];
+    m_from[m] = (int32_t)i;
   } else {
     const int n = heads[perm1[i]];                // destination in direction 1
-    mpos1[i] = (int32_t)i + rp0[n + 1];
+    const int64_t m = i + rp0[n + 1];
+    int2 e = el1[i];
+    const int q = n / N;
+    e.y += rel_off[q + 1] - rel_off[q] + 1;
+    edge_m[m] = e;
+    m_from[m] = (int32_t)(F + i);
   }
 }
-
 
 // Per-question list of "big" nodes (more than kBigDeg facts in a direction): the LDS walk hands them
 // to whole waves / the whole workgroup instead of a 4-lane group.  Order inside a question's list is
@@ -556,9 +566,10 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
     out->heavy[d] = (int32_t*)(base + L.heavy[d]);
     out->chunk_off[d] = (int32_t*)(base + L.chunk_off[d]);
     out->edge_l[d] = (int32_t*)(base + L.edge_l[d]);
-    out->mpos[d] = (int32_t*)(base + L.mpos[d]);
   }
   out->rel_off = (int32_t*)(base + L.rel_off);
+  out->edge_m = (int32_t*)(base + L.edge_m);
+  out->m_from = (int32_t*)(base + L.m_from);
   out->rel_rows = (int32_t*)(base + L.rel_rows);
   out->n_heavy = (int32_t*)(base + L.n_heavy);
   out->n_chunks = out->n_heavy + 2;
@@ -627,8 +638,9 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
                      out->chunk_off[1], out->n_chunks);
   GNNRAG_LAUNCH_CHECK();
   if (F > 0) {
-    hipLaunchKernelGGL(k_csr_mpos, dim3((unsigned)((F + 255) / 256), 2), dim3(256), 0, stream, out->perm[0],
-                       out->perm[1], heads, tails, out->row_ptr[0], out->row_ptr[1], F, out->mpos[0], out->mpos[1]);
+    hipLaunchKernelGGL(k_csr_merge, dim3((unsigned)((F + 255) / 256), 2), dim3(256), 0, stream, out->perm[0],
+                       out->perm[1], heads, tails, out->row_ptr[0], out->row_ptr[1], (const int2*)out->edge_l[0],
+                       (const int2*)out->edge_l[1], out->rel_off, N, F, (int2*)out->edge_m, out->m_from);
     GNNRAG_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(k_csr_big, dim3((int)((BN + 255) / 256)), dim3(256), 0, stream, out->row_ptr[0],

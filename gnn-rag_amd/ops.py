@@ -274,8 +274,8 @@ class CsrPlan:
             out["edge_l%d" % d] = self._view(self.c.edge_l[d], 2 * self.F, torch.int32).numpy().reshape(-1, 2)
         out["rel_off"] = self._view(self.c.rel_off, self.B + 1, torch.int32).numpy()
         out["rel_rows"] = self._view(self.c.rel_rows, 2 * self.rel_total, torch.int32).numpy().reshape(-1, 2)
-        for d in (0, 1):
-            out["mpos%d" % d] = self._view(self.c.mpos[d], self.F, torch.int32).numpy()
+        out["edge_m"] = self._view(self.c.edge_m, 4 * self.F, torch.int32).numpy().reshape(-1, 2)
+        out["m_from"] = self._view(self.c.m_from, 2 * self.F, torch.int32).numpy()
         return out
 
     def rel_rows(self) -> np.ndarray:

@@ -82,10 +82,14 @@ typedef struct gnnrag_csr {
   int32_t  rel_total;   /* compact rows in the batch (host copy, filled by gnnrag_csr_build)   */
   int32_t  rel_max;     /* largest number of relations used by one question                    */
   /* Merged rows (fused LDS walk): the facts arriving at node n in direction 0 followed by those of direction 1 form
-   * ONE run [row_ptr[0][n] + row_ptr[1][n], row_ptr[0][n+1] + row_ptr[1][n+1]) of a 2F-long stream; mpos[d][i] is the
-   * place of direction d's i-th sorted fact in it.  The walk then steps through a node's facts of both directions in
-   * one loop (same summation order: direction 0's facts in ascending fact id, then direction 1's). */
-  int32_t* mpos[2];     /* [F]                                                                  */
+   * ONE run [row_ptr[0][n] + row_ptr[1][n], row_ptr[0][n+1] + row_ptr[1][n+1]) of a 2F-long stream.  edge_m holds the
+   * (source node, compact relation) records in that order - direction 1's relation index offset by the question's
+   * relation count + 1, so that it addresses the second table slice behind the first one's zero row - and m_from
+   * where each record came from (d * F + sorted position in direction d: the per-fact weights are read through it).
+   * The walk then steps through a node's facts of both directions in one loop (same summation order: direction 0's
+   * facts in ascending fact id, then direction 1's). */
+  int32_t* edge_m;      /* [2F][2]                                                              */
+  int32_t* m_from;      /* [2F]                                                                 */
 } gnnrag_csr;
 
 /* Bytes of caller-owned device memory a gnnrag_csr needs (persistent part / build scratch). */

@@ -71,16 +71,25 @@ def test_csr_plan_bit_exact(dev, name):
         np.testing.assert_array_equal(el[:, 0], e[:, 0])
         q = e[:, 0] // cfg.N
         np.testing.assert_array_equal(got["rel_rows"][got["rel_off"][q] + el[:, 1]], np.stack([q, e[:, 1]], 1))
-    # merged rows: node n's facts of direction 0, then of direction 1, as one run of a 2F-long stream
+    # merged rows: node n's facts of direction 0, then of direction 1, as one run of a 2F-long record stream; direction
+    # 1's compact relation index is moved behind direction 0's table slice (+ relations of the question + 1)
     dst = {0: t, 1: h}
     rp0, rp1 = want["row_ptr0"].astype(np.int64), want["row_ptr1"].astype(np.int64)
     F = len(h)
+    nrel = np.diff(got["rel_off"])
+    em = np.zeros((2 * F, 2), np.int64)
+    frm = np.zeros(2 * F, np.int64)
     for d in (0, 1):
         n_of = dst[d][want["perm%d" % d]]                          # destination of every sorted position
-        pos = np.arange(F)
-        np.testing.assert_array_equal(got["mpos%d" % d], pos + (rp1[n_of] if d == 0 else rp0[n_of + 1]))
-    merged = np.concatenate([got["mpos0"], got["mpos1"]])
-    assert np.array_equal(np.sort(merged), np.arange(2 * F))        # a permutation of the stream
+        m = np.arange(F) + (rp1[n_of] if d == 0 else rp0[n_of + 1])
+        rec = got["edge_l%d" % d].astype(np.int64).copy()
+        if d == 1:
+            rec[:, 1] += nrel[n_of // cfg.N] + 1
+        em[m] = rec
+        frm[m] = d * F + np.arange(F)
+    np.testing.assert_array_equal(got["edge_m"], em)
+    np.testing.assert_array_equal(got["m_from"], frm)
+    assert np.array_equal(np.sort(frm), np.arange(2 * F))           # every fact of both directions exactly once
     if name == "mid":
         assert got["n_heavy"].sum() > 0, "the Zipf hub must exercise the heavy-row path"
 
