@@ -672,7 +672,7 @@ __device__ __forceinline__ float* slice_out(const WalkArgs& a, int n, int i, int
 // accumulators allow (one float4 per lane in FUSED mode).
 template <int MODE, int NI>
 __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k_walk_slice(const WalkArgs a, const int2* __restrict__ pr,
-                                                              int64_t F, int nslice, int nfull) {
+                                                              int64_t F, int nslice, int nfull, int pl) {
   typedef SliceAcc<MODE, NI> Acc;
   constexpr int NA = Acc::n;
   constexpr int ND = (MODE == MODE_REASON) ? 2 : 1;     // output slots per node: per direction / summed
@@ -688,7 +688,11 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
   // launch is made of half-length workgroups.
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   int item = slot, part = 0, nparts = 1;
-  if (slot >= nfull) {
+  if (pl > 0) {               // few questions: EVERY item is cut into 2^pl parts of the question's nodes (B = 1: 13
+    item = slot >> pl;        // slices x 4 parts fill the XCD's 64 workgroup slots instead of 26 of them)
+    part = slot & ((1 << pl) - 1);
+    nparts = 1 << pl;
+  } else if (slot >= nfull) {
     const int hslot = slot - nfull;
     item = nfull + (hslot >> 1);
     part = hslot & 1;
@@ -1032,9 +1036,17 @@ static int launch_slice(const WalkArgs& a, const gnnrag_csr* csr, void* workspac
   const int items_x = ((csr->B + 7) / 8) * nslice;
   const int rem = items_x % slots_per_xcd;
   const int nfull = (GNNRAG_SLICE_SPLIT_TAIL && rem != 0) ? items_x - rem : items_x;
-  const int nblk = 8 * (nfull + 2 * (items_x - nfull));
+  int nblk = 8 * (nfull + 2 * (items_x - nfull));
+  // at most 8 questions (one per XCD): cut every (question, slice) item into as many node ranges as still fit the XCD's
+  // slots in one round (each part stages its own table slice; >= 16 node sets per part)
+  int pl = 0;
+  if (csr->B <= 8) {
+    while (pl < 3 && (items_x << (pl + 1)) <= slots_per_xcd && ((a.N / 16) >> (pl + 1)) >= 16) ++pl;
+    if (pl < 2) pl = 0;       // halves are what the tail split above already gives
+    if (pl) nblk = 8 * (items_x << pl);
+  }
   hipLaunchKernelGGL((k_walk_slice<MODE, NI>), dim3(nblk), dim3(kSliceThreads), lds, stream, a, (const int2*)pr, F,
-                     nslice, nfull);
+                     nslice, nfull, pl);
   GNNRAG_LAUNCH_CHECK();
   return 0;   // hubs were walked inside the kernel, nothing to add afterwards
 }
