@@ -22,6 +22,7 @@
 // the k order inside the tile that A and W share, which the sum does not see.  Global loads of
 // tile t+1 are issued before the MFMAs of tile t (register prefetch), two workgroups per CU.
 #include "gnnrag_common.h"
+#include "dense_internal.h"
 
 // Variants that were A/B-tested on MI355X and did NOT pay (removed; see DESIGN.md section 3.5 and git history):
 // branch-free clamped tile loads (-8 %), source-level fragment double buffering / sched_group_barrier
@@ -936,14 +937,15 @@ extern "C" int gnnrag_linear(const float* A, int64_t M, int32_t K, const float* 
 }
 
 // shared by the two update entry points: h' = relu(A.W^T + b (+ add)), score = score_func(h') + mask term
-static int update_common(GemmArgs g, int64_t BN, int32_t D, hipStream_t stream, int math) {
+static int update_common(GemmArgs g, int64_t BN, int32_t D, hipStream_t stream, int math, bool score_zeroed = false) {
   if (D <= 208) {
     g.n0 = 0;
     // short K, exact fp32, aligned operands: the W-resident kernel (whole weight block in LDS)
     const bool al = aligned16(g.A0) && aligned16(g.W) && aligned16(g.C) && (!g.add || aligned16(g.add)) &&
                     g.ldw % 4 == 0 && g.wc0 % 4 == 0 && (!g.add || g.add_rows >= g.M);
     if (GNNRAG_UPDATE_B3 && math != GNNRAG_MATH_FP32 && al && g.add && !g.A1 && g.K == D) {
-      const int rc = update_b3_launch(g.A0, g.add, g.W, g.bias, g.w_s, g.b_s, g.mask, g.C, g.score, BN, D, g.ldw, stream);
+      const int rc = update_b3_launch_z(g.A0, g.add, g.W, g.bias, g.w_s, g.b_s, g.mask, g.C, g.score, BN, D, g.ldw, stream,
+                                        score_zeroed);
       if (rc != GNNRAG_E_UNSUPPORTED) return rc;
     }
     const int S = (GNNRAG_GEMM_WRES && math != GNNRAG_MATH_BF16X3 && al && g.M >= 4096) ? wres_stride(g) : 0;
@@ -1004,6 +1006,13 @@ extern "C" int gnnrag_update_score_fused(const float* h, const float* nbr, const
                                          const float* w_s, const float* b_s, const float* mask, float* h_out,
                                          float* score, int64_t BN, int32_t D, int32_t I, int32_t math,
                                          gnnrag_stream_t stream) {
+  return gnnrag::update_score_fused_z(h, nbr, W, b, w_s, b_s, mask, h_out, score, BN, D, I, math, (hipStream_t)stream,
+                                      false);
+}
+
+int gnnrag::update_score_fused_z(const float* h, const float* nbr, const float* W, const float* b, const float* w_s,
+                                 const float* b_s, const float* mask, float* h_out, float* score, int64_t BN, int32_t D,
+                                 int32_t I, int32_t math, hipStream_t stream, bool score_zeroed) {
   if (!h || !nbr || !W || !b || !w_s || !b_s || !mask || !h_out || !score || BN < 0 || D <= 0 || I <= 0 ||
       !math_ok(math))
     return GNNRAG_E_BADARG;
@@ -1016,7 +1025,7 @@ extern "C" int gnnrag_update_score_fused(const float* h, const float* nbr, const
   g.w_s = w_s; g.b_s = b_s; g.mask = mask; g.score = score;
   g.M = (int32_t)BN; g.K = D; g.K0 = D; g.Nout = D; g.ldw = (2 * I + 1) * D; g.wc0 = 0;
   g.relu = 1;
-  return update_common(g, BN, D, (hipStream_t)stream, math);
+  return update_common(g, BN, D, stream, math, score_zeroed);
 }
 
 extern "C" int gnnrag_relation_tables(const gnnrag_csr* csr, const float* T_fwd, const float* T_inv,

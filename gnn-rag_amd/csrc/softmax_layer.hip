@@ -1,5 +1,6 @@
 // Per-question masked softmax, the one-call layer driver and small utilities.
 #include "gnnrag_common.h"
+#include "dense_internal.h"
 
 namespace gnnrag {
 
@@ -169,15 +170,19 @@ static int layer_body(const gnnrag_csr* csr, const LayerWs& w, char* base, const
     float* nbr = (float*)(base + w.nbr);
     const bool one_dir = only >= 0 && gnnrag_aggregate_fused_variant(csr, D) != GNNRAG_WALK_L2_GATHER;
     rc = GNNRAG_E_UNSUPPORTED;
-    if (planes && math != GNNRAG_MATH_FP32 && csr->rel_total > 0)
-      rc = tables_vq_launch(csr, planes, ins, W_e2e, P, D, I, one_dir ? only : -1, (hipStream_t)stream);
+    bool score_zeroed = false;    // the V-form table kernel also zeroes the score the update accumulates onto
+    if (planes && math != GNNRAG_MATH_FP32 && csr->rel_total > 0) {
+      rc = tables_vq_launch_z(csr, planes, ins, W_e2e, P, D, I, one_dir ? only : -1, score_out, BN,
+                              (hipStream_t)stream);
+      score_zeroed = rc == 0;
+    }
     if (rc == GNNRAG_E_UNSUPPORTED) rc = gnnrag_relation_tables(csr, T_fwd, T_inv, ins, W_e2e, P, D, I, math, stream);
     if (rc) return rc;
     rc = aggregate_fused_dirs(csr, dist, P, nbr, D, one_dir ? 2 - only : 0, base + w.partial, w.partial_bytes,
                               (hipStream_t)stream);
     if (rc) return rc;
-    rc = gnnrag_update_score_fused(h, nbr, W_e2e, b_e2e, w_score, b_score, mask, h_out, score_out, BN, D, I,
-                                   math, stream);
+    rc = update_score_fused_z(h, nbr, W_e2e, b_e2e, w_score, b_score, mask, h_out, score_out, BN, D, I, math,
+                              (hipStream_t)stream, score_zeroed);
     if (rc) return rc;
   } else {
     float* agg = (float*)(base + w.agg);

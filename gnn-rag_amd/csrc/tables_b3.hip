@@ -27,6 +27,7 @@
 //     tile, k block): hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid, smallest terms first, fp32 accumulation.
 // Two barriers per instruction and workgroup instead of two per 32 k.
 #include "gnnrag_common.h"
+#include "dense_internal.h"
 
 namespace gnnrag {
 
@@ -354,6 +355,8 @@ struct VqArgs {
   int32_t ct0;                   // column tiles of part 0
   int32_t nchunk;                // row chunks per question (> 1 only when the batch has few questions)
   int32_t dir0;                  // first direction of the launch (grid y counts on from it)
+  float* zero;                   // null or a buffer the launch also zeroes (the layer's score, see dense_internal.h)
+  int64_t zero_n;
 };
 
 // V planes of one half and one column part -> LDS:  V[n, k] = sum_i W[col0 + n, (1 + 2 i + d) D + k] * max(+-ins[g, i, k], 0)
@@ -543,6 +546,11 @@ __device__ __forceinline__ void tables_vq_part(const VqArgs& a, unsigned char* l
 
 __global__ __launch_bounds__(512, 2) void k_tables_vq(VqArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  if (a.zero) {               // every workgroup zeroes its share (a few floats per thread)
+    const int64_t nb = (int64_t)gridDim.x * gridDim.y * gridDim.z;
+    const int64_t lin = blockIdx.x + (int64_t)gridDim.x * (blockIdx.y + (int64_t)gridDim.y * blockIdx.z);
+    for (int64_t i = lin * 512 + threadIdx.x; i < a.zero_n; i += nb * 512) a.zero[i] = 0.f;
+  }
   const int NT = (a.D + 15) >> 4;
   const int h = blockIdx.z;
   const int ctn = h == 0 ? a.ct0 : NT - a.ct0;
@@ -778,6 +786,12 @@ __global__ __launch_bounds__(512, 2) void k_update_b3(UpdB3Args a, int nchunks) 
 int update_b3_launch(const float* h, const float* nbr, const float* W, const float* b, const float* w_s, const float* b_s,
                      const float* mask, float* h_out, float* score, int64_t BN, int32_t D, int32_t ldw,
                      hipStream_t stream) {
+  return update_b3_launch_z(h, nbr, W, b, w_s, b_s, mask, h_out, score, BN, D, ldw, stream, false);
+}
+
+int update_b3_launch_z(const float* h, const float* nbr, const float* W, const float* b, const float* w_s,
+                       const float* b_s, const float* mask, float* h_out, float* score, int64_t BN, int32_t D,
+                       int32_t ldw, hipStream_t stream, bool score_zeroed) {
   if (D % 8 || (D + 31) / 32 != kTabNKB || (D + 15) / 16 != 13 || BN < 8192 || BN * D >= ((int64_t)1 << 31) || ldw % 4)
     return GNNRAG_E_UNSUPPORTED;
   if ((((uintptr_t)h | (uintptr_t)nbr | (uintptr_t)W | (uintptr_t)h_out) & 15) != 0) return GNNRAG_E_UNSUPPORTED;
@@ -794,7 +808,7 @@ int update_b3_launch(const float* h, const float* nbr, const float* W, const flo
   int chunks = cus / 2;
   if (chunks < 1) chunks = 1;
   if ((long long)chunks * 8 > U) chunks = (int)((U + 7) / 8);
-  GNNRAG_HIP(hipMemsetAsync(score, 0, (size_t)BN * sizeof(float), stream));
+  if (!score_zeroed) GNNRAG_HIP(hipMemsetAsync(score, 0, (size_t)BN * sizeof(float), stream));
   static DeviceMask cap;
   {
     const int rc = raise_lds_cap(k_update_b3, cap);
@@ -815,6 +829,11 @@ bool tables_vq_shape_ok(int32_t D, int32_t I) {
 
 int tables_vq_launch(const gnnrag_csr* csr, const void* planes, const float* ins, const float* W, float* P, int32_t D,
                      int32_t I, int32_t only_dir, hipStream_t stream) {
+  return tables_vq_launch_z(csr, planes, ins, W, P, D, I, only_dir, nullptr, 0, stream);
+}
+
+int tables_vq_launch_z(const gnnrag_csr* csr, const void* planes, const float* ins, const float* W, float* P, int32_t D,
+                       int32_t I, int32_t only_dir, float* zero, int64_t zero_n, hipStream_t stream) {
   if (!tables_vq_shape_ok(D, I) || csr->rel_total < 1024 || only_dir > 1) return GNNRAG_E_UNSUPPORTED;
   if ((((uintptr_t)planes | (uintptr_t)ins | (uintptr_t)W | (uintptr_t)P) & 15) != 0) return GNNRAG_E_UNSUPPORTED;
   VqArgs a;
@@ -838,6 +857,8 @@ int tables_vq_launch(const gnnrag_csr* csr, const void* planes, const float* ins
   if (nchunk > tiles_max / 8) nchunk = tiles_max / 8;
   if (nchunk < 1) nchunk = 1;
   a.nchunk = nchunk;
+  a.zero = zero;
+  a.zero_n = zero ? zero_n : 0;
   static DeviceMask cap;
   {
     const int rc = raise_lds_cap(k_tables_vq, cap);
