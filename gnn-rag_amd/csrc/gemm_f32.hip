@@ -494,7 +494,7 @@ template <int NT> struct ColMap {
   static constexpr int NFULL = NT / 4;
   static constexpr int NGRP = (NT + 3) / 4;
   // LDS row of W row j (0 <= j < NT*16)
-  static __device__ __forceinline__ int lds_row(int j) {
+  static __host__ __device__ __forceinline__ int lds_row(int j) {
     if (j < NFULL * 64) {
       const int a = j >> 6, w = j & 63;
       return ((a << 2) + (w & 3)) * 16 + (w >> 2);
@@ -527,8 +527,12 @@ __device__ __forceinline__ int opaque(int x) {
 //    tile.  256 VGPRs per lane (2 waves per SIMD) hold accumulators (52), fragments (52) and add rows (52);
 //  * the two waves of a SIMD are independent, so one's epilogue overlaps the other's MFMAs by itself.
 // Exact fp32 (v_mfma_f32_16x16x4_f32), alternating accumulators.
-template <int NT, int NC, int EPI, bool HAS_ADD>
-__global__ __launch_bounds__(512, 2) void k_gemm_wres(GemmArgs g, int S) {
+// KGUARD: K <= 16 * (NC - 1), i.e. k groups in front of the last one reach beyond K as well (hidden sizes between the
+// compiled NC values: 32, 100, 160 ...): every group then clamps its A / W addresses and zeroes the A values beyond K.
+// LR = LDS rows of the W block: the ColMap order scatters the W rows of a partly filled 64-column group over up to 64
+// LDS rows (Nout = 56: rows up to 61), so the block is sized by the largest row in use, not by Nout.
+template <int NT, int NC, int EPI, bool HAS_ADD, bool KGUARD>
+__global__ __launch_bounds__(512, 2) void k_gemm_wres(GemmArgs g, int S, int LR) {
   typedef ColMap<NT> CM;
   extern __shared__ __attribute__((aligned(16))) float Wl[];     // [Nout rows in ColMap order][S float4 chunks]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_wres(GemmArgs g, int S) {
   }
   // bias and score weights behind W (read with ds_read in the epilogue: global loads there would have to wait for
   // the fragment refills issued just before them)
-  float* Bl = Wl + (size_t)Nout * S * 4;
+  float* Bl = Wl + (size_t)LR * S * 4;
   float* Sl = Bl + Nout;
   for (int j = tid; j < Nout; j += 512) {
     Bl[j] = g.bias ? g.bias[j] : 0.f;
@@ -578,11 +582,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_wres(GemmArgs g, int S) {
   // per k group c: this lane's float4 offset inside a row of A / of W (zero beyond K: the A value is zeroed, the W
   // address is clamped to a valid chunk so that 0 * finite = 0)
   // (raw load: the k >= K zeroing happens where the fragment is USED, so that a refill does not wait for its data)
-  // Only the last k group can reach beyond K (K > 16 * (NC - 1)).
+  // Without KGUARD only the last k group can reach beyond K (K > 16 * (NC - 1)).
   auto a_frag = [&](int tile, int c) -> f32x4 {
     const int row = min(tile * 16 + fr, g.M - 1);                 // rows beyond M: valid memory, results discarded
     const float* rowp = g.A0 + (size_t)row * g.K0 + 4 * fg;
-    if (c < NC - 1) return *reinterpret_cast<const f32x4*>(rowp + 16 * c);
+    if (!KGUARD && c < NC - 1) return *reinterpret_cast<const f32x4*>(rowp + 16 * c);
     return *reinterpret_cast<const f32x4*>(rowp + (min(16 * c + 4 * fg, K - 4) - 4 * fg));
   };
   f32x4 ra[NC];
@@ -655,7 +659,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_wres(GemmArgs g, int S) {
     for (int c = 0; c < NC; ++c) {
       f32x4 a = ra[c];
       int kc = 4 * c + fg_t;
-      if (c == NC - 1) {
+      if (KGUARD || c == NC - 1) {
         if (16 * c + 4 * fg_t >= K) a = zero4;
         kc = min(kc, KC - 1);
       }
@@ -733,11 +737,24 @@ __global__ __launch_bounds__(512, 2) void k_gemm_wres(GemmArgs g, int S) {
 
 // applicability of k_gemm_wres and its LDS row stride (float4 chunks): S >= K/4 with S % 4 == 2 keeps the
 // ds_read_b128 fragment reads bank-conflict free; the whole block must fit one CU's LDS
+// LDS rows the W block of an Nout-column problem occupies in ColMap order (largest row in use + 1)
+template <int NT> static int wres_rows_nt(int Nout) {
+  int rows = 0;
+  for (int j = Nout > 64 ? Nout - 64 : 0; j < Nout; ++j) {
+    const int r = ColMap<NT>::lds_row(j) + 1;
+    rows = r > rows ? r : rows;
+  }
+  return rows;
+}
+static int wres_rows(int Nout, int K) {      // same (NT, NC) classes as launch_wres
+  const int nt = (Nout + 15) / 16, nc = (K + 15) / 16, m = nt > nc ? nt : nc;
+  return m <= 4 ? wres_rows_nt<4>(Nout) : m <= 8 ? wres_rows_nt<8>(Nout) : wres_rows_nt<13>(Nout);
+}
 static int wres_stride(const GemmArgs& g) {
-  if (g.K % 4 || g.Nout % 4 || g.K0 != g.K || g.A1 || g.n0 || g.K < 16) return 0;
+  if (g.K % 4 || g.Nout % 4 || g.K0 != g.K || g.A1 || g.n0 || g.K < 16 || g.Nout > 208 || g.K > 208) return 0;
   int S = g.K / 4;
   while (S % 4 != 2) ++S;
-  if ((size_t)g.Nout * S * 16 + (size_t)g.Nout * 8 > 160 * 1024) return 0;
+  if ((size_t)wres_rows(g.Nout, g.K) * S * 16 + (size_t)g.Nout * 8 > 160 * 1024) return 0;
   return S;
 }
 
@@ -751,19 +768,23 @@ static int launch_wres(const GemmArgs& g, int S, hipStream_t stream) {
   const int tiles = (g.M + 15) / 16;
   int grid = cus > 0 ? cus : 1;
   if (grid * 8 > tiles) grid = (tiles + 7) / 8;
-  const size_t lds = (size_t)g.Nout * S * 16 + (size_t)g.Nout * 8 ;      // W, bias, score weights
+  const int LR = wres_rows(g.Nout, g.K);
+  const size_t lds = (size_t)LR * S * 16 + (size_t)g.Nout * 8;           // W (ColMap rows), bias, score weights
   const int nc = (g.K + 15) / 16, nt = (g.Nout + 15) / 16;
-#define GNNRAG_WRES1(NTT, NCC, HA)                                                                              \
+#define GNNRAG_WRES1(NTT, NCC, HA, KG)                                                                          \
   do {                                                                                                          \
     static DeviceMask cap;                                                                                      \
-    const int rc_ = raise_lds_cap(k_gemm_wres<NTT, NCC, EPI, HA>, cap);                                         \
+    const int rc_ = raise_lds_cap(k_gemm_wres<NTT, NCC, EPI, HA, KG>, cap);                                     \
     if (rc_) return rc_;                                                                                        \
-    hipLaunchKernelGGL((k_gemm_wres<NTT, NCC, EPI, HA>), dim3(grid), dim3(512), lds, stream, g, S);             \
+    hipLaunchKernelGGL((k_gemm_wres<NTT, NCC, EPI, HA, KG>), dim3(grid), dim3(512), lds, stream, g, S, LR);     \
   } while (0)
 #define GNNRAG_WRES(NTT, NCC)                                                                                   \
   do {                                                                                                          \
-    if (g.add) GNNRAG_WRES1(NTT, NCC, true);                                                                    \
-    else GNNRAG_WRES1(NTT, NCC, false);                                                                         \
+    const bool kg = g.K <= 16 * (NCC - 1);                                                                      \
+    if (g.add && kg) GNNRAG_WRES1(NTT, NCC, true, true);                                                        \
+    else if (g.add) GNNRAG_WRES1(NTT, NCC, true, false);                                                        \
+    else if (kg) GNNRAG_WRES1(NTT, NCC, false, true);                                                           \
+    else GNNRAG_WRES1(NTT, NCC, false, false);                                                                  \
   } while (0)
   if (nt <= 4 && nc <= 4) GNNRAG_WRES(4, 4);
   else if (nt <= 8 && nc <= 8) GNNRAG_WRES(8, 8);

@@ -199,11 +199,14 @@ static int layer_body(const gnnrag_csr* csr, const LayerWs& w, char* base, const
 // row, not once per fact; all layers in one launch when the float4 kernel applies (rel_transform.hip)
 static int rel_projections(const gnnrag_csr* csr, int32_t n, const gnnrag_layer_params* layers,
                            const float* relfeat_fwd, const float* relfeat_inv, int32_t pos_rows, float* T,
-                           void* planes, int32_t D, int32_t math, gnnrag_stream_t stream) {
+                           void* planes, bool* planes_written, int32_t D, int32_t math, gnnrag_stream_t stream) {
+  *planes_written = false;
   if ((D & 3) == 0) {
     const int rc = gnnrag_rel_transform(relfeat_fwd, relfeat_inv, csr->R1, D, n, layers, pos_rows, T, planes, stream);
-    // (unaligned operands: the k-tiled kernel below; the caller's planes stay unwritten, so it must not use them)
-    if (rc != GNNRAG_E_UNSUPPORTED || planes) return rc;
+    if (rc == 0) *planes_written = planes != nullptr;
+    // unaligned operands: the k-tiled kernel below (its scalar loaders take any address); the planes stay unwritten,
+    // which the caller learns through *planes_written and then builds the tables from T (gnnrag_relation_tables)
+    if (rc != GNNRAG_E_UNSUPPORTED) return rc;
   }
   const size_t RD = (size_t)csr->R1 * D;
   for (int j = 0; j < n; ++j) {
@@ -246,8 +249,11 @@ extern "C" int gnnrag_reason_layer(const gnnrag_csr* csr, const float* h, const 
                      ((path & 0xf) == GNNRAG_PATH_AUTO && fused_is_cheaper(csr->B, csr->N, csr->rel_total, D, I));
   void* planes = fused && math != GNNRAG_MATH_FP32 && tables_vq_shape_ok(D, I) && csr->rel_total >= 1024
                      ? (void*)(base + w.planes) : nullptr;
-  const int rc = rel_projections(csr, 1, &p, relfeat_fwd, relfeat_inv, pos_rows, T_fwd, planes, D, math, stream);
+  bool planes_written = false;
+  const int rc = rel_projections(csr, 1, &p, relfeat_fwd, relfeat_inv, pos_rows, T_fwd, planes, &planes_written, D, math,
+                                 stream);
   if (rc) return rc;
+  if (!planes_written) planes = nullptr;
   return layer_body(csr, w, base, h, dist, ins, T_fwd, T_inv, planes, W_e2e, b_e2e, w_score, b_score, mask, h_out, score_out,
                     dist_out, D, I, path, math, stream);
 }
@@ -280,9 +286,10 @@ extern "C" int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnra
   const bool want_planes = fused && math != GNNRAG_MATH_FP32 && tables_vq_shape_ok(D, I) && csr->rel_total >= 1024;
   const size_t plane_bytes = tables_vq_planes_bytes(csr->R1);
   char* planes_all = base + w.total + align_up((size_t)L * 2 * RD * sizeof(float), 256);
+  bool planes_written = false;
   if (upfront) {
     const int rc = rel_projections(csr, L, layers, relfeat_fwd, relfeat_inv, pos_rows, Tall,
-                                   want_planes ? planes_all : nullptr, D, math, stream);
+                                   want_planes ? planes_all : nullptr, &planes_written, D, math, stream);
     if (rc) return rc;
   }
   const float* h = h0;
@@ -295,9 +302,11 @@ extern "C" int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnra
     float* T = upfront ? Tall + (size_t)j * 2 * RD : T0;
     void* planes = !want_planes ? nullptr : upfront ? (void*)(planes_all + (size_t)j * plane_bytes) : (void*)(base + w.planes);
     if (!upfront) {
-      const int rc = rel_projections(csr, 1, &p, relfeat_fwd, relfeat_inv, pos_rows, T, planes, D, math, stream);
+      const int rc = rel_projections(csr, 1, &p, relfeat_fwd, relfeat_inv, pos_rows, T, planes, &planes_written, D, math,
+                                     stream);
       if (rc) return rc;
     }
+    if (!planes_written) planes = nullptr;
     const int rc = layer_body(csr, w, base, h, dist, ins, T, T + RD, planes, p.W_e2e, p.b_e2e, w_score, b_score, mask, hj, sj,
                               dj, D, I, path, math, stream);
     if (rc) return rc;

@@ -167,6 +167,16 @@ class BatchFacts:
     def __iter__(self):
         return (self[i] for i in range(7))
 
+    def shard(self, lo: int, hi: int) -> "BatchFacts":
+        """Facts of questions [lo, hi) as a self-contained batch (node ids re-based by ``lo * N``), sliced ON THE
+        DEVICE - what ``shard.shard_edge_tuple`` hands a rank when the loader serves device-resident tuples."""
+        a, b = int(self._sizes[:lo].sum()), int(self._sizes[:hi].sum())
+        hrt = self.hrt_device[:, a:b].clone()
+        if lo:
+            hrt[0] -= lo * self._N
+            hrt[2] -= lo * self._N
+        return BatchFacts(hrt, self._sizes[lo:hi], self._parts[lo:hi], self._N)
+
 
 class DeviceFactCache(FactCache):
     """:class:`FactCache` whose per-question id blocks live ON THE GPU ("cached per-question

@@ -376,8 +376,9 @@ def gemm_tn(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     M, N1 = A.shape
     N2 = B.shape[1]
     out = torch.empty((N1, N2), dtype=torch.float32, device=A.device)
-    ws = torch.empty(max(lib.gnnrag_gemm_tn_workspace_bytes(M, N1, N2), 16), dtype=torch.uint8, device=A.device)
     with torch.cuda.device(A.device):
+        # the chunk count behind the workspace size depends on the CURRENT device's CU count: query it on A's device
+        ws = torch.empty(max(lib.gnnrag_gemm_tn_workspace_bytes(M, N1, N2), 16), dtype=torch.uint8, device=A.device)
         _lib.check(lib.gnnrag_gemm_tn(A.data_ptr(), B.data_ptr(), M, N1, N2, out.data_ptr(), ws.data_ptr(), ws.numel(),
                                       _stream()), "gnnrag_gemm_tn")
     return out

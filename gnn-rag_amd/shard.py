@@ -63,6 +63,8 @@ def shard_edge_tuple(edge_tuple, N: int, lo: int, hi: int):
     """Facts of questions [lo, hi), re-based so the shard is a self-contained batch.
     Facts of one question are contiguous and ``batch_ids`` is non-decreasing
     (``_build_fact_mat``, dataset_load.py:481-506)."""
+    if hasattr(edge_tuple, "hrt_device"):          # data/fact_mat.BatchFacts: the id arrays live on the GPU
+        return edge_tuple.shard(lo, hi)
     heads, rels, tails, bids, _, wl, wrl = edge_tuple
     bids = np.asarray(bids)
     if len(bids) and (np.diff(bids) < 0).any():
@@ -183,7 +185,11 @@ def sharded_training_step(model, batch: tuple, group: Optional[dist.ProcessGroup
     the parameter gradients of all ranks are summed with ONE all-reduce of a flat buffer (~2.5 MB at D = 200: latency
     bound on xGMI, so one bucket) - afterwards every rank holds the gradient of the whole-batch loss and the caller's
     optimizer step keeps the replicas identical.  Dropout / fact dropout draw from each rank's own RNG streams, as in
-    any data-parallel run.  Returns (batch-mean loss, local model outputs).  Single process: the plain step."""
+    any data-parallel run.  Returns (batch-mean loss, local model outputs).  Single process: the plain step.
+
+    Gradient accumulation: whatever a parameter's ``.grad`` held on entry is kept as it is and only THIS step's
+    contribution is all-reduced and added to it (the step back-propagates into cleared ``.grad`` fields and restores
+    the earlier content afterwards) - summing stale contributions over the ranks would inflate them world-size times."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         out = model(batch, training=True)
         out[0].backward()
@@ -193,6 +199,9 @@ def sharded_training_step(model, batch: tuple, group: Optional[dist.ProcessGroup
     ranges = shard_ranges(batch, world, balance)
     lo, hi = ranges[rank]
     params = [p for p in model.parameters() if p.requires_grad]
+    earlier = [p.grad for p in params]                      # accumulated by the caller before this step
+    for p in params:
+        p.grad = None
     if hi > lo:
         out = model(shard_batch(batch, rank, world, balance), training=True)
         local = out[0] * (float(hi - lo) / B)
@@ -203,12 +212,12 @@ def sharded_training_step(model, batch: tuple, group: Optional[dist.ProcessGroup
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params] + [loss_part])
     dist.all_reduce(flat, group=group)
     off = 0
-    for p in params:
+    for p, old in zip(params, earlier):
         n = p.numel()
         g = flat[off: off + n].view_as(p)
-        if p.grad is None:
+        if old is None:
             p.grad = g.clone()
         else:
-            p.grad.copy_(g)
+            p.grad = old.add_(g)
         off += n
     return flat[off], out

@@ -1,0 +1,80 @@
+"""The device-resident per-question fact cache (reference: gnn/dataset_load.py:473-527,
+gnn/modules/kg_reasoning/base_gnn.py:19-51).  Needs no reference checkout: the loader is a stub holding the attributes
+the caches read, so the ``-m gpu`` test below runs on the GPU box (where /root/reference does not exist)."""
+import numpy as np
+import pytest
+
+
+class _StubLoader:
+    """The attributes of the reference's BasicDataLoader that the fact caches read (dataset_load.py:473-527)."""
+
+    def __init__(self, rng, n_q=9, N=40, num_rel=13):
+        self.max_local_entity, self.num_kb_relation = N, num_rel + 1
+        self.data_eff, self.use_self_loop = False, True
+        self.kb_adj_mats, self.global2local_entity_maps = {}, {}
+        for q in range(n_q):
+            n = int(rng.integers(3, N + 1))
+            e = int(rng.integers(0, 4 * n))
+            self.kb_adj_mats[q] = (rng.integers(0, n, e), rng.integers(0, num_rel, e), rng.integers(0, n, e))
+            self.global2local_entity_maps[q] = {i: i for i in range(n)}
+
+
+def test_device_cache_tuple_matches_host_cache_on_cpu_tensors():
+    """BatchFacts (the lazily filled tuple of the device-resident cache) holds what FactCache.batch returns - checked
+    with the cache's blocks kept as CPU tensors, which exercises the same code without a GPU."""
+    import torch
+    from gnnrag_amd.data.fact_mat import DeviceFactCache, FactCache
+    ld = _StubLoader(np.random.default_rng(4))
+    host, devc = FactCache(ld), DeviceFactCache(ld, torch.device("cpu"))
+    for ids in ([0, 3, 4], [8, 1], [], [2]):
+        a, b = host.batch(ids), devc.batch(ids)
+        assert len(b) == 7 and tuple(b.hrt_device.shape) == (3, len(a[0]))
+        for k in range(3):
+            np.testing.assert_array_equal(b[k].numpy(), a[k])
+        for k in range(3, 7):
+            np.testing.assert_array_equal(np.asarray(b[k]), np.asarray(a[k]))
+        assert len(b[4]) == len(a[4]) and len(list(b)) == 7 and len(b[:3]) == 3
+
+
+def test_device_resident_tuple_shards_like_the_host_tuple():
+    """shard.shard_edge_tuple on a BatchFacts (ids on the device) gives the questions' facts re-based exactly as it
+    does for the host tuple (advisor finding, round 2: it used to call np.asarray on CUDA tensors)."""
+    import torch
+    from gnnrag_amd import shard
+    from gnnrag_amd.data.fact_mat import DeviceFactCache, FactCache
+    ld = _StubLoader(np.random.default_rng(5))
+    host, devc = FactCache(ld), DeviceFactCache(ld, torch.device("cpu"))
+    ids = [0, 3, 4, 8, 1]
+    a, b = host.batch(ids), devc.batch(ids)
+    for lo, hi in ((0, 5), (0, 2), (2, 5), (3, 3), (4, 5)):
+        sa, sb = shard.shard_edge_tuple(a, ld.max_local_entity, lo, hi), shard.shard_edge_tuple(b, ld.max_local_entity, lo, hi)
+        for k in range(3):
+            np.testing.assert_array_equal(sb[k].numpy(), sa[k])
+        for k in range(3, 7):
+            np.testing.assert_array_equal(np.asarray(sb[k]), np.asarray(sa[k]))
+    np.testing.assert_array_equal(shard.facts_per_question(b, len(ids)), shard.facts_per_question(a, len(ids)))
+
+
+@pytest.mark.gpu
+def test_structure_from_the_device_resident_cache_is_bit_identical():
+    """f-1 (rest): per-question id blocks cached on the GPU, batch = device-side concatenation with node offsets;
+    the structure built from it equals the one built from the host tuple bit for bit, and the batch is rebuilt from the
+    cache without touching the questions' arrays again."""
+    import torch
+    import gnnrag_amd  # noqa: F401
+    from gnnrag_amd import ops
+    from gnnrag_amd.data.fact_mat import DeviceFactCache, FactCache
+    dev = torch.device("cuda", 0)
+    ld = _StubLoader(np.random.default_rng(7), n_q=12, N=300, num_rel=25)
+    host, devc = FactCache(ld), DeviceFactCache(ld, dev)
+    for ids in ([0, 5, 7, 11], [3, 3, 1], [9]):
+        a, b = host.batch(ids), devc.batch(ids)
+        B, N, R1 = len(ids), ld.max_local_entity, ld.num_kb_relation + 1
+        pa = ops.CsrPlan(a[0], a[1], a[2], B, N, R1, dev).to_host()
+        pb = ops.CsrPlan(None, None, None, B, N, R1, dev, hrt_device=b.hrt_device).to_host()
+        for k in pa:
+            if k == "big":
+                assert all(np.array_equal(x, y) for x, y in zip(pa[k], pb[k]))
+            else:
+                np.testing.assert_array_equal(pa[k], pb[k], err_msg=k)
+    assert sorted(devc._dev) == [0, 1, 3, 5, 7, 9, 11]      # every question uploaded once

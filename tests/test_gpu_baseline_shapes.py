@@ -132,9 +132,10 @@ def test_more_big_nodes_than_the_list_holds(dev):
 
 def test_c1_shape_single_question(dev):
     """C1: one WebQSP-shaped question (B = 1, N = 2000 padded, released-checkpoint dims D = 50, 2 instructions,
-    3 layers, 3 iterations) incl. TypeLayer.  D = 50 is not a multiple of 4, so the fused aggregation is the
-    table-row gather kernel with float2 lanes (k_walk_light<FUSED, VEC 2, 32-lane groups>), the GEMMs run their
-    scalar-loader NT = 4 variants."""
+    3 layers, 3 iterations) incl. TypeLayer.  D = 50 is not a multiple of 4: the drop-in module zero-pads it to 56
+    (reasongnn.py drop-in, `_inference_params`), so what runs is the LDS walk at width 56 (k_walk_slice) and the
+    float4 GEMM variants - asserted below on the PADDED width.  (The unpadded scalar path, GNNRAG_PAD_DIM=0, is
+    covered by tests/test_gpu_round3_shapes.py::test_c1_kernel_variants_padded_and_unpadded.)"""
     import oracle.rearev_np64 as onp
     import oracle.rearev_torch_cpu as otorch
     from gnnrag_amd import ops, stack, synth
@@ -144,7 +145,7 @@ def test_c1_shape_single_question(dev):
         feats = synth.make_features(cfg, seed=seed)
         params = synth.make_layer_params(cfg)
         plan = _plan_of(batch, dev)
-        assert ops.aggregate_fused_variant(plan, cfg.D) == ops.WALK_L2_GATHER and cfg.D % 4 == 2
+        assert cfg.D % 4 == 2 and ops.aggregate_fused_variant(plan, 56) in (ops.WALK_LDS_16, ops.WALK_LDS_32)
         want64 = onp.run_stack(batch, feats, params, use_type_layer=True)
         want = otorch.run_stack(batch, feats, params, use_type_layer=True)
         for path in (0, 1, 2):

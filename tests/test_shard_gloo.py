@@ -223,6 +223,14 @@ def _train_worker(rank, world, port, q):
                 continue
             worst = max(worst, float((p.grad - pr.grad).abs().max()) / scale)
         ok = worst <= 1e-4 and abs(float(loss) - float(loss_ref)) <= 1e-5 * max(1.0, abs(float(loss_ref)))
+        # gradient accumulation: a second step without zeroing adds ONE more whole-batch gradient (what .grad held
+        # on entry is not summed over the ranks again)
+        shard.sharded_training_step(model, batch)
+        for (n, p), (_, pr) in zip(model.named_parameters(), ref.named_parameters()):
+            if pr.grad is None:
+                continue
+            worst = max(worst, float((p.grad - 2 * pr.grad).abs().max()) / scale)
+        ok = ok and worst <= 2e-4
         q.put((rank, bool(ok), worst))
     finally:
         dist.destroy_process_group()
