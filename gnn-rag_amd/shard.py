@@ -13,6 +13,8 @@ rank owns the question, the gathered result is bit-identical to the single-GPU r
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional, Tuple
 
 import numpy as np
@@ -163,7 +165,9 @@ def shard_model(model, group: Optional[dist.ProcessGroup] = None, balance: str =
             return inner(batch, training=training)
         world = dist.get_world_size(group)
         B = batch[0].shape[0]
-        if world == 1 or B < world:
+        # (GNNRAG_FORCE_DIST=1: a single rank still shards - trivially - and runs both collectives, so that a
+        # 1-GPU box exercises the RCCL path)
+        if (world == 1 and os.environ.get("GNNRAG_FORCE_DIST") != "1") or B < world:
             return inner(batch, training=training)
         rank = dist.get_rank(group)
         ranges = shard_ranges(batch, world, balance)

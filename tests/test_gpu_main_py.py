@@ -1,0 +1,90 @@
+"""The UNMODIFIED reference entry point on the MI355X ("Next round" item 2; north_star: "drops into
+main.py/evaluate.py unchanged ... Hits@1 identical"):
+
+    python tools/run_reference.py oracle/_ref/gnn ReaRev --is_eval --load_experiment synth-final.ckpt ...
+
+i.e. gnn/main.py -> Trainer_KBQA -> load_data -> ReaRev (built from the reference's own models/ReaRev/rearev.py, whose
+imports resolve to this package's modules) -> load_ckpt of a checkpoint the reference's trainer wrote on CPU ->
+Evaluator.evaluate over the valid and test splits -> .info file, with the device-resident fact cache
+(GNNRAG_DEVICE_FACTS=1) and the device-side candidate selection - compared with what the PURE reference produced on CPU
+for the same checkpoint and data (oracle/stage_ref.py: expected_test.info, expected.json):
+
+  * per question the same candidates in the same order, their probabilities within 1e-4 (north_star's bar),
+  * identical per-question precision / recall / F1 / hit / EM and identical logged F1 / H@1 / EM of both splits;
+
+and once more with GNNRAG_FORCE_DIST=1, which puts shard_model and RCCL (all-gather of the scored nodes, all-reduce of
+the loss) on the path with world size 1.
+
+oracle/_ref (staged reference sources + synthetic dataset + checkpoint + CPU expectations) is git-ignored and built by
+``python oracle/stage_ref.py`` / ``__graft_entry__.build()`` in the build container; it travels to the GPU box with the
+snapshot.  Without it the test skips.  Reference: gnn/main.py:30-44, gnn/train_model.py:193-198, gnn/evaluate.py:147-240.
+"""
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(REPO, "oracle", "_ref")
+GNN = os.path.join(REF, "gnn")
+CKPT = os.path.join(REF, "ckpt")
+DATA = os.path.join(REF, "data", "synth") + "/"
+STAGED = all(os.path.exists(p) for p in (os.path.join(GNN, "main.py"), os.path.join(CKPT, "synth-final.ckpt"),
+                                          os.path.join(CKPT, "expected_test.info"), os.path.join(CKPT, "expected.json")))
+
+TOL = 1e-4
+
+
+def _run_main_py(tmp_path, extra_env):
+    ck = str(tmp_path) + "/"
+    shutil.copyfile(os.path.join(CKPT, "synth-final.ckpt"), os.path.join(ck, "synth-final.ckpt"))
+    argv = [sys.executable, os.path.join(REPO, "tools", "run_reference.py"), GNN,
+            "ReaRev", "--data_folder", DATA, "--lm", "lstm", "--relation_word_emb", "False",
+            "--entity_dim", "50", "--kg_dim", "25", "--num_iter", "3", "--num_ins", "2", "--num_gnn", "3",
+            "--batch_size", "16", "--test_batch_size", "16", "--name", "synth",
+            "--is_eval", "--load_experiment", "synth-final.ckpt", "--checkpoint_dir", ck, "--experiment_name", "gpu"]
+    env = dict(os.environ, GNNRAG_DEVICE_FACTS="1", **extra_env)
+    r = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=600)
+    log = r.stdout + r.stderr
+    assert r.returncode == 0, log[-4000:]
+    metrics = {}
+    for key in ("EVAL", "TEST"):
+        hit = re.findall(key + r" F1: ([0-9.]+), H1: ([0-9.]+), EM ([0-9.]+)", log)
+        assert hit, log[-2000:]
+        metrics[key.lower()] = [float(x) for x in hit[-1]]
+    lines = open(os.path.join(ck, "gpu_test.info")).read().splitlines()
+    out_dir = os.path.join(REPO, "gpurun_out", "main_py")
+    os.makedirs(out_dir, exist_ok=True)
+    tag = "dist" if extra_env else "single"
+    with open(os.path.join(out_dir, "run_%s.log" % tag), "w") as f:
+        f.write(log[-20000:])
+    shutil.copyfile(os.path.join(ck, "gpu_test.info"), os.path.join(out_dir, "gpu_test_%s.info" % tag))
+    return metrics, [json.loads(l) for l in lines], log
+
+
+@pytest.mark.skipif(not STAGED, reason="oracle/_ref not staged (python oracle/stage_ref.py in the build container)")
+@pytest.mark.parametrize("mode", ["single", "force_dist"])
+def test_unmodified_main_py_eval_matches_cpu_reference(tmp_path, mode):
+    want_metrics = json.load(open(os.path.join(CKPT, "expected.json")))
+    want = [json.loads(l) for l in open(os.path.join(CKPT, "expected_test.info")).read().splitlines()]
+    metrics, got, log = _run_main_py(tmp_path, {"GNNRAG_FORCE_DIST": "1"} if mode == "force_dist" else {})
+    assert "gnnrag_amd: native library mapped" in log, log[-2000:]        # the child ran on libgnnrag_hip.so
+    assert metrics == want_metrics, (metrics, want_metrics)               # logged with 4 decimals by the reference
+    assert len(got) == len(want) and len(got) > 0
+    worst = 0.0
+    for g, w in zip(got, want):
+        assert g["question"] == w["question"] and g["answers"] == w["answers"]
+        for key in ("precison", "recall", "f1", "hit", "em"):
+            assert g[key] == w[key], (key, g["question"])
+        assert [c[0] for c in g["cand"]] == [c[0] for c in w["cand"]], g["question"]     # same entities, same order
+        for (_, pg), (_, pw) in zip(g["cand"], w["cand"]):
+            worst = max(worst, abs(pg - pw))
+    assert worst <= TOL, worst
+    print("main.py on the MI355X (%s): %d questions, metrics %s, max |candidate probability - CPU reference| = %.3g"
+          % (mode, len(got), metrics, worst))

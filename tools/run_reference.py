@@ -36,7 +36,16 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     is_eval = "--is_eval" in sys.argv
-    if world > 1:                                        # one process per GPU (torchrun), RCCL over xGMI
+    # GNNRAG_FORCE_DIST=1 on a single GPU: the question-sharded path (process group, shard_model, RCCL all-gather and
+    # all-reduce) runs with world size 1 - what a 1-GPU box can prove of the multi-GPU path
+    force_dist = os.environ.get("GNNRAG_FORCE_DIST") == "1" and world == 1 and is_eval
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("LOCAL_RANK", "0")
+        os.environ["WORLD_SIZE"] = "1"
+    if world > 1 or force_dist:                          # one process per GPU (torchrun), RCCL over xGMI
         if not is_eval:
             # only evaluation is question-sharded: a training run under torchrun would train one full replica per
             # rank without gradient sync, and every rank would write the same checkpoint / .info file
@@ -75,7 +84,7 @@ def main():
                     # evaluation-only runs use it as it is, training runs keep the reference's RNG stream
                     # GNNRAG_DEVICE_FACTS=1 (single-rank evaluation): per-question id blocks stay on the GPU
                     dev = None
-                    if os.environ.get("GNNRAG_DEVICE_FACTS") and is_eval and world == 1 and split != "train":
+                    if os.environ.get("GNNRAG_DEVICE_FACTS") and is_eval and split != "train":
                         import torch
                         dev = torch.device("cuda", torch.cuda.current_device())
                     patch_loader(dataset[split], cache=(split != "train"), keep_rng_stream=not is_eval, device=dev)
@@ -87,7 +96,7 @@ def main():
     if not os.environ.get("GNNRAG_NO_EVAL_PATCH"):
         from gnnrag_amd import eval_tail
         evaluate.Evaluator.evaluate = eval_tail.evaluate
-    if world > 1:
+    if world > 1 or force_dist:
         from gnnrag_amd import shard
         _ev_init = evaluate.Evaluator.__init__
 
@@ -98,7 +107,11 @@ def main():
         evaluate.Evaluator.__init__ = _init_sharded
 
     sys.argv = [os.path.join(ref, "main.py")] + sys.argv[2:]
-    runpy.run_path(os.path.join(ref, "main.py"), run_name="__main__")
+    try:
+        runpy.run_path(os.path.join(ref, "main.py"), run_name="__main__")
+    finally:
+        mapped = [l.split()[-1] for l in open("/proc/self/maps") if "libgnnrag_hip" in l]
+        print("gnnrag_amd: native library %s" % ("mapped: " + mapped[0] if mapped else "NOT loaded"))
 
 
 if __name__ == "__main__":
