@@ -102,14 +102,22 @@ SIGNATURES = {
                                                                C.c_int32, _VP, C.POINTER(C.c_void_p)]),
     "gnnrag_graph_launch": (C.c_int, [_VP, _VP]),
     "gnnrag_graph_destroy": (C.c_int, [_VP]),
+    "gnnrag_frontier_workspace_bytes": (C.c_size_t, [C.POINTER(CsrStruct)]),
+    "gnnrag_frontier_supported": (C.c_int, [C.POINTER(CsrStruct), C.c_int32]),
+    "gnnrag_frontier_build": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, C.c_size_t, _VP]),
+    "gnnrag_relation_tables_frontier": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, _VP, _VP, C.c_int32,
+                                                  C.c_int32, _VP]),
+    "gnnrag_aggregate_fused_frontier": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, C.c_int32, _VP]),
+    "gnnrag_frontier_read": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP]),
     "gnnrag_stream_copy": (C.c_int, [_VP, _VP, C.c_int64, _VP]),
     "gnnrag_abi_version": (C.c_int, []),
     "gnnrag_error_string": (C.c_char_p, [C.c_int]),
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 PATH_AUTO, PATH_UNFUSED, PATH_FUSED = 0, 1, 2
 PATH_ONLY_FWD, PATH_ONLY_INV = 0x10, 0x20        # OR-ed into the path: one-direction layers (NSM)
+PATH_SEED_PRIOR = 0x40                           # OR-ed into the path: the (first layer's) prior is a seed distribution
 E_TUPLE = -4
 _lib = None
 

@@ -141,16 +141,20 @@ __global__ __launch_bounds__(256) void k_csr_merge(const int32_t* __restrict__ p
                                                    const int32_t* __restrict__ rp0, const int32_t* __restrict__ rp1,
                                                    const int2* __restrict__ el0, const int2* __restrict__ el1,
                                                    const int32_t* __restrict__ rel_off, int32_t N, int64_t F,
-                                                   int2* __restrict__ edge_m, int32_t* __restrict__ m_from) {
+                                                   int64_t BN, int2* __restrict__ edge_m, int32_t* __restrict__ m_from) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= F) return;
+  // (an invalid tuple - node id outside [0, B*N) - is rejected by the build AFTER these kernels have run: such a fact
+  // must not index the row pointers.  Round 2's version did, and a negative id wrote edge_m far out of bounds.)
+  const int nd = blockIdx.y == 0 ? tails[perm0[i]] : heads[perm1[i]];
+  if (nd < 0 || nd >= BN) return;
   if (blockIdx.y == 0) {
-    const int n = tails[perm0[i]];                // destination in direction 0
+    const int n = nd;                             // destination in direction 0
     const int64_t m = i + rp1[n];
     edge_m[m] = el0[i];
     m_from[m] = (int32_t)i;
   } else {
-    const int n = heads[perm1[i]];                // destination in direction 1
+    const int n = nd;                             // destination in direction 1
     const int64_t m = i + rp0[n + 1];
     int2 e = el1[i];
     const int q = n / N;
@@ -640,7 +644,7 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
   if (F > 0) {
     hipLaunchKernelGGL(k_csr_merge, dim3((unsigned)((F + 255) / 256), 2), dim3(256), 0, stream, out->perm[0],
                        out->perm[1], heads, tails, out->row_ptr[0], out->row_ptr[1], (const int2*)out->edge_l[0],
-                       (const int2*)out->edge_l[1], out->rel_off, N, F, (int2*)out->edge_m, out->m_from);
+                       (const int2*)out->edge_l[1], out->rel_off, N, F, BN, (int2*)out->edge_m, out->m_from);
     GNNRAG_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(k_csr_big, dim3((int)((BN + 255) / 256)), dim3(256), 0, stream, out->row_ptr[0],

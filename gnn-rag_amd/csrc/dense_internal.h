@@ -14,6 +14,27 @@ int update_b3_launch_z(const float* h, const float* nbr, const float* W, const f
                        const float* b_s, const float* mask, float* h_out, float* score, int64_t BN, int32_t D,
                        int32_t ldw, hipStream_t stream, bool score_zeroed);
 
+// Row-gated form of the self-block update: `nbr` holds valid data only in the rows whose byte in add_flag is non-zero,
+// every other row reads the ZERO ROW behind the buffer (row index BN), so the unflagged rows of nbr are never
+// touched (frontier layers: frontier.hip).  add_flag: [BN + 4 bytes of padding], 4-byte aligned.
+// Returns GNNRAG_E_UNSUPPORTED (nothing launched) when the kernel the shape would take has no gated form.
+int update_score_fused_rows(const float* h, const float* nbr, const uint8_t* add_flag, const float* W, const float* b,
+                            const float* w_s, const float* b_s, const float* mask, float* h_out, float* score,
+                            int64_t BN, int32_t D, int32_t I, int32_t math, hipStream_t stream, bool score_zeroed);
+int update_b3_launch_f(const float* h, const float* nbr, const uint8_t* add_flag, const float* W, const float* b,
+                       const float* w_s, const float* b_s, const float* mask, float* h_out, float* score, int64_t BN,
+                       int32_t D, int32_t ldw, hipStream_t stream, bool score_zeroed);
+
+// true when update_score_fused_rows has a row-gated kernel for this shape / alignment / math mode (gemm_f32.hip)
+bool update_rows_supported(const float* h, const float* nbr, const float* W, const float* h_out, int64_t BN, int32_t D,
+                           int32_t I, int32_t math);
+bool update_b3_shape_ok(int64_t BN, int32_t D, int32_t ldw);
+
+// frontier.hip: the frontier of a (sparse) prior; also zeroes two float ranges on the way (score buffer, zero row)
+int frontier_build_z(const gnnrag_csr* csr, const float* dist, void* fws, size_t fws_bytes, float* zero_a,
+                     int64_t zero_na, float* zero_b, int64_t zero_nb, hipStream_t stream);
+const uint8_t* frontier_row_flags(const gnnrag_csr* csr, const void* fws);
+
 // gnnrag_update_score_fused with the promise that `score` already holds zeros
 int update_score_fused_z(const float* h, const float* nbr, const float* W, const float* b, const float* w_s,
                          const float* b_s, const float* mask, float* h_out, float* score, int64_t BN, int32_t D,

@@ -82,6 +82,8 @@ struct GemmArgs {
   const int2* gen_rows;
   int32_t gen_D, gen_I, gen_dir;
   int32_t v4out;        // rows of C/add are 16-byte aligned and Nout % 4 == 0: float4 epilogue
+  const uint8_t* add_flag;   // k_gemm_wres<.., AFL>: row gates of `add` [M + 4]; a row whose byte is 0 reads the zero row
+                             // `add + M * Nout` behind the buffer (frontier layers, frontier.hip)
 };
 
 enum { AMODE_PLAIN = 0, AMODE_GEN = 1 };
@@ -531,7 +533,7 @@ __device__ __forceinline__ int opaque(int x) {
 // compiled NC values: 32, 100, 160 ...): every group then clamps its A / W addresses and zeroes the A values beyond K.
 // LR = LDS rows of the W block: the ColMap order scatters the W rows of a partly filled 64-column group over up to 64
 // LDS rows (Nout = 56: rows up to 61), so the block is sized by the largest row in use, not by Nout.
-template <int NT, int NC, int EPI, bool HAS_ADD, bool KGUARD>
+template <int NT, int NC, int EPI, bool HAS_ADD, bool KGUARD, bool AFL>
 __global__ __launch_bounds__(512, 2) void k_gemm_wres(GemmArgs g, int S, int LR) {
   typedef ColMap<NT> CM;
   extern __shared__ __attribute__((aligned(16))) float Wl[];     // [Nout rows in ColMap order][S float4 chunks]
@@ -605,6 +607,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_wres(GemmArgs g, int S, int LR)
   auto col_of = [&](int a) { return a < CM::NFULL ? 64 * a + 4 * fr : 64 * CM::NFULL + fr; };
   const float bs = (EPI == EPI_UPDATE) ? g.b_s[0] : 0.f;
   int tnext_c = 0;
+  // AFL: the four row gates of a lane's `add` rows (one dword), requested a tile ahead like the A fragments
+  unsigned fl_next = 0x01010101u;
+  if (AFL && t < tend) fl_next = *reinterpret_cast<const unsigned*>(g.add_flag + (size_t)t * 16 + 4 * fg);
 #if GNNRAG_GEMM_TIMING
   long long* tb = g_tbuf ? g_tbuf + ((size_t)blockIdx.x * 8 + wave) * 32 : nullptr;
   int stamp = 0;
@@ -623,6 +628,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_wres(GemmArgs g, int S, int LR)
     ++stamp;
 #endif
     const int rbase = t * 16 + 4 * fg;                             // C layout: this lane's rows rbase + q
+    const unsigned fl = fl_next;
+    if (AFL) fl_next = *reinterpret_cast<const unsigned*>(g.add_flag + (size_t)(t + 1 < tend ? t + 1 : t) * 16 + 4 * fg);
     // the epilogue's addend rows, in the MFMA / ColMap layout
     f32x4 addv[CM::NGRP][4];
 #pragma unroll
@@ -635,7 +642,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_wres(GemmArgs g, int S, int LR)
         const int col = col_of(a);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int row = min(rbase + q, g.M - 1);
+          int row = min(rbase + q, g.M - 1);
+          if (AFL && ((fl >> (8 * q)) & 0xffu) == 0u) row = g.M;      // not a frontier row: the zero row
           const float* arow = g.add + (size_t)row * Nout;
           if (a < CM::NFULL) addv[a][q] = *reinterpret_cast<const f32x4*>(arow + min(col, Nout - 4));
           else addv[a][q][0] = arow[min(col, Nout - 1)];
@@ -771,20 +779,22 @@ static int launch_wres(const GemmArgs& g, int S, hipStream_t stream) {
   const int LR = wres_rows(g.Nout, g.K);
   const size_t lds = (size_t)LR * S * 16 + (size_t)g.Nout * 8;           // W (ColMap rows), bias, score weights
   const int nc = (g.K + 15) / 16, nt = (g.Nout + 15) / 16;
-#define GNNRAG_WRES1(NTT, NCC, HA, KG)                                                                          \
+#define GNNRAG_WRES1(NTT, NCC, HA, KG, FL)                                                                      \
   do {                                                                                                          \
     static DeviceMask cap;                                                                                      \
-    const int rc_ = raise_lds_cap(k_gemm_wres<NTT, NCC, EPI, HA, KG>, cap);                                     \
+    const int rc_ = raise_lds_cap(k_gemm_wres<NTT, NCC, EPI, HA, KG, FL>, cap);                                 \
     if (rc_) return rc_;                                                                                        \
-    hipLaunchKernelGGL((k_gemm_wres<NTT, NCC, EPI, HA, KG>), dim3(grid), dim3(512), lds, stream, g, S, LR);     \
+    hipLaunchKernelGGL((k_gemm_wres<NTT, NCC, EPI, HA, KG, FL>), dim3(grid), dim3(512), lds, stream, g, S, LR); \
   } while (0)
 #define GNNRAG_WRES(NTT, NCC)                                                                                   \
   do {                                                                                                          \
     const bool kg = g.K <= 16 * (NCC - 1);                                                                      \
-    if (g.add && kg) GNNRAG_WRES1(NTT, NCC, true, true);                                                        \
-    else if (g.add) GNNRAG_WRES1(NTT, NCC, true, false);                                                        \
-    else if (kg) GNNRAG_WRES1(NTT, NCC, false, true);                                                           \
-    else GNNRAG_WRES1(NTT, NCC, false, false);                                                                  \
+    if (g.add && g.add_flag && kg) GNNRAG_WRES1(NTT, NCC, true, true, true);                                    \
+    else if (g.add && g.add_flag) GNNRAG_WRES1(NTT, NCC, true, false, true);                                    \
+    else if (g.add && kg) GNNRAG_WRES1(NTT, NCC, true, true, false);                                            \
+    else if (g.add) GNNRAG_WRES1(NTT, NCC, true, false, false);                                                 \
+    else if (kg) GNNRAG_WRES1(NTT, NCC, false, true, false);                                                    \
+    else GNNRAG_WRES1(NTT, NCC, false, false, false);                                                           \
   } while (0)
   if (nt <= 4 && nc <= 4) GNNRAG_WRES(4, 4);
   else if (nt <= 8 && nc <= 8) GNNRAG_WRES(8, 8);
@@ -964,15 +974,19 @@ static int update_common(GemmArgs g, int64_t BN, int32_t D, hipStream_t stream, 
     // short K, exact fp32, aligned operands: the W-resident kernel (whole weight block in LDS)
     const bool al = aligned16(g.A0) && aligned16(g.W) && aligned16(g.C) && (!g.add || aligned16(g.add)) &&
                     g.ldw % 4 == 0 && g.wc0 % 4 == 0 && (!g.add || g.add_rows >= g.M);
-    if (GNNRAG_UPDATE_B3 && math != GNNRAG_MATH_FP32 && al && g.add && !g.A1 && g.K == D) {
-      const int rc = update_b3_launch_z(g.A0, g.add, g.W, g.bias, g.w_s, g.b_s, g.mask, g.C, g.score, BN, D, g.ldw, stream,
-                                        score_zeroed);
+    if (GNNRAG_UPDATE_B3 && math != GNNRAG_MATH_FP32 && al && g.add && !g.A1 && g.K == D &&
+        (!g.add_flag || ((uintptr_t)g.add_flag & 3) == 0)) {
+      const int rc = update_b3_launch_f(g.A0, g.add, g.add_flag, g.W, g.bias, g.w_s, g.b_s, g.mask, g.C, g.score, BN, D,
+                                        g.ldw, stream, score_zeroed);
       if (rc != GNNRAG_E_UNSUPPORTED) return rc;
     }
-    const int S = (GNNRAG_GEMM_WRES && math != GNNRAG_MATH_BF16X3 && al && g.M >= 4096) ? wres_stride(g) : 0;
+    const int S = (GNNRAG_GEMM_WRES && math != GNNRAG_MATH_BF16X3 && al && g.M >= 4096 &&
+                   (!g.add_flag || ((uintptr_t)g.add_flag & 3) == 0)) ? wres_stride(g) : 0;
     if (S) return launch_wres<EPI_UPDATE>(g, S, stream);
+    if (g.add_flag) return GNNRAG_E_UNSUPPORTED;      // the k-tiled kernel has no row-gated form: nothing launched
     return launch_gemm<EPI_UPDATE, AMODE_PLAIN>(g, stream, math);
   }
+  if (g.add_flag) return GNNRAG_E_UNSUPPORTED;
   // wide hidden sizes: column blocks of 208 with bias(+add)+ReLU epilogue, then a row-dot for the score
   g.relu = 1;
   for (int n0 = 0; n0 < D; n0 += 208) {
@@ -1031,9 +1045,30 @@ extern "C" int gnnrag_update_score_fused(const float* h, const float* nbr, const
                                       false);
 }
 
+bool gnnrag::update_rows_supported(const float* h, const float* nbr, const float* W, const float* h_out, int64_t BN,
+                                   int32_t D, int32_t I, int32_t math) {
+  if (D > 208 || BN >= ((int64_t)1 << 31)) return false;
+  const int ldw = (2 * I + 1) * D;
+  const bool al = aligned16(h) && aligned16(W) && aligned16(h_out) && aligned16(nbr) && ldw % 4 == 0;
+  if (!al) return false;
+  if (GNNRAG_UPDATE_B3 && math != GNNRAG_MATH_FP32 && update_b3_shape_ok(BN, D, ldw)) return true;
+  if (!(GNNRAG_GEMM_WRES && math != GNNRAG_MATH_BF16X3 && BN >= 4096)) return false;
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.M = (int32_t)BN; g.K = D; g.K0 = D; g.Nout = D; g.ldw = ldw;
+  return wres_stride(g) != 0;
+}
+
 int gnnrag::update_score_fused_z(const float* h, const float* nbr, const float* W, const float* b, const float* w_s,
                                  const float* b_s, const float* mask, float* h_out, float* score, int64_t BN, int32_t D,
                                  int32_t I, int32_t math, hipStream_t stream, bool score_zeroed) {
+  return update_score_fused_rows(h, nbr, nullptr, W, b, w_s, b_s, mask, h_out, score, BN, D, I, math, stream, score_zeroed);
+}
+
+int gnnrag::update_score_fused_rows(const float* h, const float* nbr, const uint8_t* add_flag, const float* W,
+                                    const float* b, const float* w_s, const float* b_s, const float* mask, float* h_out,
+                                    float* score, int64_t BN, int32_t D, int32_t I, int32_t math, hipStream_t stream,
+                                    bool score_zeroed) {
   if (!h || !nbr || !W || !b || !w_s || !b_s || !mask || !h_out || !score || BN < 0 || D <= 0 || I <= 0 ||
       !math_ok(math))
     return GNNRAG_E_BADARG;
@@ -1046,6 +1081,7 @@ int gnnrag::update_score_fused_z(const float* h, const float* nbr, const float* 
   g.w_s = w_s; g.b_s = b_s; g.mask = mask; g.score = score;
   g.M = (int32_t)BN; g.K = D; g.K0 = D; g.Nout = D; g.ldw = (2 * I + 1) * D; g.wc0 = 0;
   g.relu = 1;
+  g.add_flag = add_flag;
   return update_common(g, BN, D, stream, math, score_zeroed);
 }
 

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_stream_copy(const f32x4* __restrict__ s
   for (; i < n4; i += stride) dst[i] = src[i];
 }
 
-struct LayerWs { size_t T_fwd, T_inv, planes, agg, P, nbr, partial, partial_bytes, total; };
+struct LayerWs { size_t T_fwd, T_inv, planes, agg, P, nbr, partial, partial_bytes, fws, fws_bytes, total; };
 
 // flops of the dense part per layer call: unfused = one [BN,(2I+1)D]x[(2I+1)D,D] GEMM; fused = the
 // per-question relation tables [2*rel_total, I*D]x[I*D, D] (rel_total = sum over questions of the
@@ -94,7 +94,7 @@ static bool fused_is_cheaper(int64_t B, int64_t N, int64_t rel_total, int64_t D,
 }
 
 static bool path_ok(int32_t path) {
-  const int base = path & 0xf, flags = path & ~0xf;
+  const int base = path & 0xf, flags = path & ~0xf & ~GNNRAG_PATH_SEED_PRIOR;
   if (base < GNNRAG_PATH_AUTO || base > GNNRAG_PATH_FUSED) return false;
   return flags == 0 || flags == GNNRAG_PATH_ONLY_FWD || flags == GNNRAG_PATH_ONLY_INV;
 }
@@ -111,13 +111,15 @@ static LayerWs layer_ws(const gnnrag_csr* csr, int32_t D, int32_t I) {
   // the two paths never run in the same call: their big buffers share one region
   const size_t a_bytes = BN * 2 * I * D * sizeof(float);
   const size_t p_bytes = align_up((size_t)2 * (csr->rel_total > 0 ? csr->rel_total : 1) * D * sizeof(float), 256);
-  const size_t n_bytes = BN * D * sizeof(float);
+  const size_t n_bytes = (BN + 1) * D * sizeof(float);              // + the zero row frontier layers read for rows off the frontier
   const size_t big = take(a_bytes > p_bytes + n_bytes ? a_bytes : p_bytes + n_bytes);
   w.agg = big;
   w.P = big;
   w.nbr = big + p_bytes;
   w.partial_bytes = gnnrag_aggregate_workspace_bytes(csr, D, I);
   w.partial = take(w.partial_bytes);
+  w.fws_bytes = gnnrag_frontier_workspace_bytes(csr);
+  w.fws = take(w.fws_bytes);
   w.total = off;
   return w;
 }
@@ -162,6 +164,7 @@ static int layer_body(const gnnrag_csr* csr, const LayerWs& w, char* base, const
   // leave a direction out (V-form tables + LDS walk); otherwise both directions run and the caller's zero weight
   // block makes the other one contribute exactly 0
   const int only = (path & GNNRAG_PATH_ONLY_FWD) ? 0 : (path & GNNRAG_PATH_ONLY_INV) ? 1 : -1;
+  const bool seed_prior = (path & GNNRAG_PATH_SEED_PRIOR) != 0;
   path &= 0xf;
   if (path == GNNRAG_PATH_AUTO)
     path = fused_is_cheaper(csr->B, csr->N, csr->rel_total, D, I) ? GNNRAG_PATH_FUSED : GNNRAG_PATH_UNFUSED;
@@ -169,6 +172,25 @@ static int layer_body(const gnnrag_csr* csr, const LayerWs& w, char* base, const
     float* P = (float*)(base + w.P);
     float* nbr = (float*)(base + w.nbr);
     const bool one_dir = only >= 0 && gnnrag_aggregate_fused_variant(csr, D) != GNNRAG_WALK_L2_GATHER;
+    if (seed_prior && only < 0 && gnnrag_frontier_supported(csr, D) && csr->rel_total > 0) {
+      // The caller says `dist` is a seed distribution (first layer of a ReaRev iteration, rearev.py:208): only the
+      // seeds' facts have a prior, so only the relation-table rows those facts use and the neighbour sums of the nodes
+      // they reach are computed (frontier.hip; the frontier itself is derived from `dist` on the device, so a prior
+      // that is NOT sparse still gives the right result, slowly); the update reads `nbr` through the row gates.
+      void* fws = base + w.fws;
+      const bool gated = update_rows_supported(h, nbr, W_e2e, h_out, BN, D, I, math);
+      if (!gated) GNNRAG_HIP(hipMemsetAsync(nbr, 0, (size_t)BN * D * sizeof(float), (hipStream_t)stream));
+      rc = frontier_build_z(csr, dist, fws, w.fws_bytes, score_out, BN, nbr + (size_t)BN * D, D, (hipStream_t)stream);
+      if (rc) return rc;
+      rc = gnnrag_relation_tables_frontier(csr, fws, T_fwd, T_inv, ins, W_e2e, P, D, I, stream);
+      if (rc) return rc;
+      rc = gnnrag_aggregate_fused_frontier(csr, fws, dist, P, nbr, D, stream);
+      if (rc) return rc;
+      rc = update_score_fused_rows(h, nbr, gated ? frontier_row_flags(csr, fws) : nullptr, W_e2e, b_e2e, w_score, b_score,
+                                   mask, h_out, score_out, BN, D, I, math, (hipStream_t)stream, true);
+      if (rc) return rc;
+      return gnnrag_masked_softmax(score_out, dist_out, csr->B, csr->N, stream);
+    }
     rc = GNNRAG_E_UNSUPPORTED;
     bool score_zeroed = false;    // the V-form table kernel also zeroes the score the update accumulates onto
     if (planes && math != GNNRAG_MATH_FP32 && csr->rel_total > 0) {
@@ -307,8 +329,9 @@ extern "C" int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnra
       if (rc) return rc;
     }
     if (!planes_written) planes = nullptr;
+    // GNNRAG_PATH_SEED_PRIOR describes dist0, i.e. layer 0 only (every later layer starts from a softmax output)
     const int rc = layer_body(csr, w, base, h, dist, ins, T, T + RD, planes, p.W_e2e, p.b_e2e, w_score, b_score, mask, hj, sj,
-                              dj, D, I, path, math, stream);
+                              dj, D, I, j == 0 ? path : (path & ~GNNRAG_PATH_SEED_PRIOR), math, stream);
     if (rc) return rc;
     h = hj;
     dist = dj;

@@ -582,10 +582,11 @@ struct UpdB3Args {
   const float* mask;     // [M]
   float* C;              // [M, D]
   float* score;          // [M], zeroed before the launch
+  const uint8_t* add_flag;   // FL: [M + 4] row gates of `add`; a row whose byte is 0 reads the zero row `add + M * D`
   int32_t M, D, ldw, ct0;
 };
 
-template <int CTN>
+template <int CTN, bool FL>
 __device__ __forceinline__ void update_b3_part(const UpdB3Args& a, unsigned char* lds, int col0, bool first_part,
                                                int chunk, int nchunks) {
   constexpr int RB = kTabSlots * 16;
@@ -654,16 +655,22 @@ __device__ __forceinline__ void update_b3_part(const UpdB3Args& a, unsigned char
     }
   }
   const float bs = a.b_s[0];
+  // FL: the four row gates of a lane's rows (one dword), requested a tile ahead like the A pieces
+  unsigned fl_next = 0x01010101u;
+  if (FL && t < tend) fl_next = *reinterpret_cast<const unsigned*>(a.add_flag + (size_t)t * 16 + 4 * fg);
   __syncthreads();
 
   for (; t < tend; ++t) {
     const int rbase = t * 16 + 4 * fg;                       // C layout: rows rbase + q, column slot fr
+    const unsigned fl = fl_next;
+    if (FL) fl_next = *reinterpret_cast<const unsigned*>(a.add_flag + (size_t)(t + 1 < tend ? t + 1 : t) * 16 + 4 * fg);
     // the epilogue's operands: nbr in the register layout (interleaved group: 4 consecutive columns per lane)
     f32x4 addg[4];                                           // group 0 (column tiles 0..3), per row q
     float addt[CTN > 4 ? CTN - 4 : 1][4];                    // plain tiles 4.., per row q
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int row = min(rbase + q, a.M - 1);
+      int row = min(rbase + q, a.M - 1);
+      if (FL && ((fl >> (8 * q)) & 0xffu) == 0u) row = a.M;      // not a frontier row: the zero row behind the buffer
       const float* arow = a.add + (size_t)row * D + col0;
 #if GNNRAG_UPD_ABL & 4
       addg[q] = zero4;
@@ -771,6 +778,7 @@ __device__ __forceinline__ void update_b3_part(const UpdB3Args& a, unsigned char
   }
 }
 
+template <bool FL>
 __global__ __launch_bounds__(512, 2) void k_update_b3(UpdB3Args a, int nchunks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   // the two parts of a row chunk are neighbours in the grid AND on one XCD (blocks b and b + 8): block = 16*(c/8) + 8*h + c%8
@@ -779,8 +787,8 @@ __global__ __launch_bounds__(512, 2) void k_update_b3(UpdB3Args a, int nchunks) 
   const int chunk = (blk >> 4) * 8 + (blk & 7);
   if (chunk >= nchunks) return;
   const int NT = (a.D + 15) >> 4;
-  if (h == 0) update_b3_part<kTabNTH>(a, lds, 0, true, chunk, nchunks);
-  else if (NT - a.ct0 == 6) update_b3_part<6>(a, lds, a.ct0 * 16, false, chunk, nchunks);
+  if (h == 0) update_b3_part<kTabNTH, FL>(a, lds, 0, true, chunk, nchunks);
+  else if (NT - a.ct0 == 6) update_b3_part<6, FL>(a, lds, a.ct0 * 16, false, chunk, nchunks);
 }
 
 int update_b3_launch(const float* h, const float* nbr, const float* W, const float* b, const float* w_s, const float* b_s,
@@ -792,13 +800,24 @@ int update_b3_launch(const float* h, const float* nbr, const float* W, const flo
 int update_b3_launch_z(const float* h, const float* nbr, const float* W, const float* b, const float* w_s,
                        const float* b_s, const float* mask, float* h_out, float* score, int64_t BN, int32_t D,
                        int32_t ldw, hipStream_t stream, bool score_zeroed) {
-  if (D % 8 || (D + 31) / 32 != kTabNKB || (D + 15) / 16 != 13 || BN < 8192 || BN * D >= ((int64_t)1 << 31) || ldw % 4)
-    return GNNRAG_E_UNSUPPORTED;
+  return update_b3_launch_f(h, nbr, nullptr, W, b, w_s, b_s, mask, h_out, score, BN, D, ldw, stream, score_zeroed);
+}
+
+bool update_b3_shape_ok(int64_t BN, int32_t D, int32_t ldw) {
+  return !(D % 8 || (D + 31) / 32 != kTabNKB || (D + 15) / 16 != 13 || BN < 8192 || BN * D >= ((int64_t)1 << 31) || ldw % 4);
+}
+
+int update_b3_launch_f(const float* h, const float* nbr, const uint8_t* add_flag, const float* W, const float* b,
+                       const float* w_s, const float* b_s, const float* mask, float* h_out, float* score, int64_t BN,
+                       int32_t D, int32_t ldw, hipStream_t stream, bool score_zeroed) {
+  if (!update_b3_shape_ok(BN, D, ldw)) return GNNRAG_E_UNSUPPORTED;
   if ((((uintptr_t)h | (uintptr_t)nbr | (uintptr_t)W | (uintptr_t)h_out) & 15) != 0) return GNNRAG_E_UNSUPPORTED;
   UpdB3Args a;
   memset(&a, 0, sizeof(a));
   a.A = h; a.W = W; a.bias = b; a.add = nbr; a.w_s = w_s; a.b_s = b_s; a.mask = mask; a.C = h_out; a.score = score;
   a.M = (int32_t)BN; a.D = D; a.ldw = ldw; a.ct0 = kTabNTH;
+  a.add_flag = add_flag;
+  if (add_flag && ((uintptr_t)add_flag & 3)) return GNNRAG_E_UNSUPPORTED;
   int cus = 0;
   {
     const int rc = device_cu_count(&cus);
@@ -809,13 +828,14 @@ int update_b3_launch_z(const float* h, const float* nbr, const float* W, const f
   if (chunks < 1) chunks = 1;
   if ((long long)chunks * 8 > U) chunks = (int)((U + 7) / 8);
   if (!score_zeroed) GNNRAG_HIP(hipMemsetAsync(score, 0, (size_t)BN * sizeof(float), stream));
-  static DeviceMask cap;
+  static DeviceMask cap, cap_f;
   {
-    const int rc = raise_lds_cap(k_update_b3, cap);
+    const int rc = add_flag ? raise_lds_cap(k_update_b3<true>, cap_f) : raise_lds_cap(k_update_b3<false>, cap);
     if (rc) return rc;
   }
   const int nblk = ((chunks + 7) / 8) * 16;
-  hipLaunchKernelGGL(k_update_b3, dim3(nblk), dim3(512), 160 * 1024, stream, a, chunks);
+  if (add_flag) hipLaunchKernelGGL(k_update_b3<true>, dim3(nblk), dim3(512), 160 * 1024, stream, a, chunks);
+  else hipLaunchKernelGGL(k_update_b3<false>, dim3(nblk), dim3(512), 160 * 1024, stream, a, chunks);
   GNNRAG_LAUNCH_CHECK();
   return 0;
 }

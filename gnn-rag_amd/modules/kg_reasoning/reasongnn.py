@@ -43,6 +43,11 @@ class ReasonGNNLayer(BaseGNNLayer):
         self._ws = ops.LayerWorkspace()
         # kernel path of the library (0 auto / 1 unfused / 2 fused); GNNRAG_PATH overrides for A/B runs
         self.path = int(os.environ.get("GNNRAG_PATH", "0"))
+        # The step-0 call of every ReaRev iteration starts from the seed distribution (rearev.py:208), whose support is
+        # the question's seeds: the library then computes relation tables and neighbour sums for the seeds' frontier
+        # only (GNNRAG_PATH_SEED_PRIOR; derived from the distribution on the device, so ANY prior gives the same
+        # result - a dense one just slowly).  GNNRAG_SEED_PRIOR=0 switches the hint off.
+        self.seed_prior = os.environ.get("GNNRAG_SEED_PRIOR", "1") != "0"
         # One library call per ReaRev iteration instead of one per layer (ops.LayerStack): the step-0 call runs all
         # num_gnn layers, the calls for steps 1.. hand out what it computed - provided the caller passes back the
         # distribution it was given and the same instructions, as ReaRev.forward does (rearev.py:208-210).
@@ -113,12 +118,16 @@ class ReasonGNNLayer(BaseGNNLayer):
         h_out, score_tp, new_dist = ops.reason_layer(
             self.plan, self._state_in(P), current_dist.detach().float(), self._pad_last(relational_ins.detach().float(), P),
             P["relfeat"], P["relfeat_inv"], W_rel, b_rel, W_e2e, b_e2e, P["w_score"], P["b_score"],
-            self.local_entity_mask, pos=pos, pos_inv=pos_inv, ws=self._ws, path=self.path)
+            self.local_entity_mask, pos=pos, pos_inv=pos_inv, ws=self._ws, path=self._path_of(step))
         self.local_entity_emb = self._state_out(h_out, P)
         self.possible_cand.append(self.local_entity_mask)
         if return_score:
             return score_tp, new_dist
         return new_dist, self.local_entity_emb
+
+    def _path_of(self, step):
+        from ..._lib import PATH_SEED_PRIOR
+        return self.path | (PATH_SEED_PRIOR if (self.seed_prior and step == 0) else 0)
 
     # ---- zero-padded inference copies (hidden size not a multiple of 4) ------------------------------------
     def _inference_params(self):
@@ -191,7 +200,7 @@ class ReasonGNNLayer(BaseGNNLayer):
             P = self._inference_params()
             if self._stack is None or self._stack_key != P["key"]:
                 self._stack = ops.LayerStack(self.plan, P["relfeat"], P["relfeat_inv"], P["layers"], P["w_score"],
-                                             P["b_score"], self.local_entity_mask, self.num_ins, path=self.path)
+                                             P["b_score"], self.local_entity_mask, self.num_ins, path=self._path_of(0))
                 self._stack_key = P["key"]
             h, score, dist = self._stack.run(self._state_in(P), current_dist.detach().float(),
                                              self._pad_last(relational_ins.detach().float(), P))

@@ -456,6 +456,62 @@ def aggregate_fused(plan: CsrPlan, dist: torch.Tensor, P: torch.Tensor) -> torch
     return out
 
 
+class Frontier:
+    """The frontier of a sparse prior (``gnnrag_frontier_build``): the nodes reached by the facts that start at a node
+    with ``dist != 0`` and the compact relation rows those facts use.  Test-side view of what
+    ``GNNRAG_PATH_SEED_PRIOR`` does inside ``gnnrag_reason_layer`` / ``gnnrag_reason_stack``."""
+
+    def __init__(self, plan: CsrPlan, dist: torch.Tensor):
+        lib = _lib.load()
+        self.plan = plan
+        dist = _chk(dist, "dist").reshape(-1)
+        _on_plan_device(plan, dist, "dist")
+        if dist.numel() != plan.B * plan.N:
+            raise ValueError("dist does not match the plan")
+        self.dist = dist
+        nbytes = max(lib.gnnrag_frontier_workspace_bytes(C.byref(plan.c)), 256)
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dist.device)
+        with torch.cuda.device(dist.device):
+            _lib.check(lib.gnnrag_frontier_build(C.byref(plan.c), dist.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
+                                                 _stream()), "gnnrag_frontier_build")
+
+    def read(self):
+        """(number of listed nodes, number of listed relation rows, row gates uint8 [B*N]) - synchronises."""
+        counts = (C.c_int32 * 2)()
+        flags = np.zeros(self.plan.B * self.plan.N, dtype=np.uint8)
+        with torch.cuda.device(self.dist.device):
+            _lib.check(_lib.load().gnnrag_frontier_read(C.byref(self.plan.c), self.ws.data_ptr(), counts,
+                                                        flags.ctypes.data, _stream()), "gnnrag_frontier_read")
+        return int(counts[0]), int(counts[1]), flags
+
+    def relation_tables(self, T_fwd, T_inv, ins, W_e2e, P: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The listed rows of P [2, rel_total, D] (the rest keeps what ``P`` held; NaN-filled when allocated here)."""
+        ins = _chk(ins, "ins")
+        B, I, D = ins.shape
+        T_fwd = _chk(T_fwd, "T_fwd", shape=(self.plan.R1, D))
+        T_inv = _chk(T_inv, "T_inv", shape=(self.plan.R1, D))
+        W_e2e = _chk(W_e2e, "e2e_linear.weight", shape=(D, (2 * I + 1) * D))
+        if P is None:
+            P = torch.full((2, max(self.plan.rel_total, 1), D), float("nan"), dtype=torch.float32, device=ins.device)
+        with torch.cuda.device(ins.device):
+            _lib.check(_lib.load().gnnrag_relation_tables_frontier(
+                C.byref(self.plan.c), self.ws.data_ptr(), T_fwd.data_ptr(), T_inv.data_ptr(), ins.data_ptr(),
+                W_e2e.data_ptr(), P.data_ptr(), D, I, _stream()), "gnnrag_relation_tables_frontier")
+        return P
+
+    def aggregate(self, P: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """nbr rows of the listed nodes ([B*N, D]; unlisted rows keep what ``out`` held, zeros when allocated here)."""
+        P = _chk(P, "P")
+        D = P.shape[-1]
+        if out is None:
+            out = torch.zeros((self.plan.B * self.plan.N, D), dtype=torch.float32, device=P.device)
+        with torch.cuda.device(P.device):
+            _lib.check(_lib.load().gnnrag_aggregate_fused_frontier(
+                C.byref(self.plan.c), self.ws.data_ptr(), self.dist.data_ptr(), P.data_ptr(), out.data_ptr(), D,
+                _stream()), "gnnrag_aggregate_fused_frontier")
+        return out
+
+
 def update_score_fused(h, nbr, W, b, w_s, b_s, mask, I: int, math: Optional[int] = None):
     lib = _lib.load()
     h = _chk(h, "h")

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GNNRAG_ABI_VERSION 9
+#define GNNRAG_ABI_VERSION 10
 
 #define GNNRAG_E_BADARG      (-1)  /* null pointer / negative size / inconsistent sizes   */
 #define GNNRAG_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set (see DESIGN)  */
@@ -287,6 +287,14 @@ int gnnrag_update_score_fused(const float* h, const float* nbr, const float* W_e
  * the zero block makes the other contribute exactly 0 - results are identical either way. */
 #define GNNRAG_PATH_ONLY_FWD 0x10
 #define GNNRAG_PATH_ONLY_INV 0x20
+/* OR-ed into `path`: the caller states that `dist` (gnnrag_reason_stack: dist0, i.e. layer 0 only) is a SEED
+ * distribution - the first layer of every ReaRev iteration (rearev.py:208 resets curr_dist to seed_dist).  fact_prior
+ * (reasongnn.py:80,106) is then zero for every fact that does not start at a seed, so the fused path computes only the
+ * relation-table rows the seeds' facts use and the neighbour sums of the nodes they reach (the frontier, derived from
+ * `dist` on the device: gnnrag_frontier_build).  A hint, not a promise: any prior gives the same results as without
+ * the flag (to rounding of the relation-table products), a dense one slowly.  Needs D % 4 == 0, D <= 256, both
+ * directions, the fused path; ignored otherwise. */
+#define GNNRAG_PATH_SEED_PRIOR 0x40
 size_t gnnrag_layer_workspace_bytes(const gnnrag_csr* csr, int32_t D, int32_t I);
 int gnnrag_reason_layer(const gnnrag_csr* csr,
                         const float* h, const float* dist, const float* ins,
@@ -366,6 +374,25 @@ int gnnrag_reason_stack_capture(const gnnrag_csr* csr, int32_t L, const gnnrag_l
                                 gnnrag_graph** out);
 int gnnrag_graph_launch(gnnrag_graph* graph, gnnrag_stream_t stream);
 int gnnrag_graph_destroy(gnnrag_graph* graph);
+
+/* The frontier form of the fused layer for a sparse prior (see GNNRAG_PATH_SEED_PRIOR), exposed piecewise for tests:
+ *   gnnrag_frontier_build: nodes with dist != 0 are the sources; marks the nodes their facts reach (row gates: one
+ *     byte per node at workspace offset ...) and the compact relation rows those facts use, and lists both;
+ *   gnnrag_relation_tables_frontier: the listed rows of P [2, rel_total, D], written in place (exact fp32 MFMA);
+ *   gnnrag_aggregate_fused_frontier: out[n, :] = sum_d sum_f p_f P[d, row(b, rel_f), :] for the listed nodes n ONLY
+ *     (facts with p_f = 0 are skipped: they add exact zeros); every other row of `out` is left untouched.
+ * fws: gnnrag_frontier_workspace_bytes(csr) bytes of device scratch shared by the three calls.
+ * gnnrag_frontier_read copies (rows listed, relation rows listed) to the host (synchronises the stream; tests). */
+size_t gnnrag_frontier_workspace_bytes(const gnnrag_csr* csr);
+int gnnrag_frontier_supported(const gnnrag_csr* csr, int32_t D);
+int gnnrag_frontier_build(const gnnrag_csr* csr, const float* dist, void* fws, size_t fws_bytes, gnnrag_stream_t stream);
+int gnnrag_relation_tables_frontier(const gnnrag_csr* csr, const void* fws, const float* T_fwd, const float* T_inv,
+                                    const float* ins, const float* W_e2e, float* P, int32_t D, int32_t I,
+                                    gnnrag_stream_t stream);
+int gnnrag_aggregate_fused_frontier(const gnnrag_csr* csr, const void* fws, const float* dist, const float* P,
+                                    float* out, int32_t D, gnnrag_stream_t stream);
+int gnnrag_frontier_read(const gnnrag_csr* csr, const void* fws, int32_t* counts2, uint8_t* row_flag_host,
+                         gnnrag_stream_t stream);
 
 /* Candidate selection of Evaluator.evaluate (evaluate.py:188-207) + the sort and top-p cut of
  * f1_and_hits (evaluate.py:34-51), one workgroup per question:

@@ -814,8 +814,9 @@ def test_whole_iteration_call_and_graph_replay_are_bit_identical(dev, cfgname):
         P = layer._inference_params()
         D, Dp = P["D"], P["Dp"]
         pad = (lambda t: t if Dp == D else F.pad(t, (0, Dp - D)))
+        # (same path word as the module's own stack: layer 0 takes the seed-prior form, csrc/frontier.hip)
         st = ops.LayerStack(layer.plan, P["relfeat"], P["relfeat_inv"], P["layers"], P["w_score"], P["b_score"],
-                            layer.local_entity_mask, cfg.I)
+                            layer.local_entity_mask, cfg.I, path=layer._path_of(0))
         st.run(pad(devin.h0), devin.seed_dist, pad(devin.ins[0]))                 # eager once (launch attributes)
         ins_buf = pad(devin.ins[0]).clone()
         st.capture(pad(devin.h0), devin.seed_dist, ins_buf)

@@ -60,6 +60,13 @@ def main():
                 if "updf" in which:
                     ops.update_score_fused(h, nbr, e2e.weight, e2e.bias, layer.score_func.weight,
                                            layer.score_func.bias, layer.local_entity_mask, I)
+            if "fr" in which:                                                   # seed-prior (frontier) form, piece by piece
+                fr = ops.Frontier(layer.plan, devin.seed_dist)
+                Pf = fr.relation_tables(Tf, Ti, devin.ins[0], e2e.weight)
+                fr.aggregate(Pf)
+            if "layer0" in which:                                               # a whole layer from the seed prior
+                layer.local_entity_emb = devin.h0
+                layer(devin.seed_dist, devin.ins[0], step=0)
             if "layer" in which:
                 layer.local_entity_emb = devin.h0
                 layer(dist1, devin.ins[0], step=1)
