@@ -39,6 +39,8 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
 FP32_MFMA_PEAK_TFLOPS = 157.3
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 (MI355X_MICROARCH.md); a bf16x3 kernel issues 6 bf16 MFMAs per fp32-equivalent
+                                 # product, so its ceiling in fp32-equivalent flops is 2500 / 6 = 417 TFLOP/s
 
 
 def bytes_agg(cfg, F_g: int) -> float:
@@ -76,6 +78,8 @@ def main():
                     help="eager: one gnnrag_reason_stack call per step; graph: the step captured once as a hipGraph "
                          "(gnnrag_reason_stack_capture) and replayed")
     ap.add_argument("--cpu-sample-b", type=int, default=8)
+    ap.add_argument("--fp32-steps", type=int, default=20,
+                    help="steps of the additional exact-fp32 timed loop (ms_per_step_fp32); 0 = off")
     ap.add_argument("--math", choices=["default", "fp32", "bf16x3", "mixed"], default="default",
                     help="math mode of the dense projections (default = the library's default)")
     args = ap.parse_args()
@@ -139,7 +143,7 @@ def main():
         ops.CsrPlan(et[0], et[1], et[2], cfg.B, cfg.N, cfg.R1, dev, validate=False)
     torch.cuda.synchronize()
     csr_build_ms = (time.perf_counter() - t0) * 1e3 / 3
-    csr_cached_ms = cached_structure_ms(batch, dev, ops) if rank == 0 else None
+    csr_cached_ms, csr_concat_ms = cached_structure_ms(batch, dev, ops) if rank == 0 else (None, None)
 
     graph = None
     if args.launch == "graph":
@@ -229,6 +233,29 @@ def main():
                   "p95": float(np.percentile(ts, 95)), "max": float(ts.max()), "mean": float(ts.mean()),
                   "unit": "ms per step, device time between HIP events (rank 0)"}
 
+    # the same step in EXACT fp32 (v_mfma_f32_16x16x4_f32 everywhere; the default 'mixed' mode runs the two large
+    # products as bf16x3): a second, shorter timed loop on a layer object bound to that math mode
+    ms_per_step_fp32 = None
+    if rank == 0 and graph is None and ops.get_dense_math() != ops.MATH_FP32 and args.fp32_steps > 0:
+        old_math = ops.set_dense_math(ops.MATH_FP32)
+        try:
+            layer32 = stack.build_layer(cfg, batch, params, dev)
+            stack.init_reason(layer32, batch, devin, devin.h0)
+            with torch.no_grad():
+                for _ in range(10):
+                    layer32.local_entity_emb = devin.h0
+                    stack.run_layers(layer32, cfg, devin)
+                torch.cuda.synchronize()
+                t32 = time.perf_counter()
+                for _ in range(args.fp32_steps):
+                    layer32.local_entity_emb = devin.h0
+                    stack.run_layers(layer32, cfg, devin)
+                torch.cuda.synchronize()
+                ms_per_step_fp32 = (time.perf_counter() - t32) * 1e3 / args.fp32_steps
+            del layer32
+        finally:
+            ops.set_dense_math(old_math)
+
     ms_per_step = elapsed * 1e3 / args.steps
     typed_edges = global_B * cfg.E * cfg.L * cfg.T
     facts = (F * world if not strong else sum(int(x) for x in strong_facts(ranges, gbatch))) * cfg.L * cfg.T
@@ -248,10 +275,17 @@ def main():
         "csr_build_ms": csr_build_ms, "csr_first_call_ms": csr_first_ms,
         # f-1: per-question id blocks resident on the GPU (data/fact_mat.DeviceFactCache), batch = device concatenation
         "csr_build_from_device_cache_ms": csr_cached_ms,
+        # f-1 as SURVEY 8f words it: per-question sorted structures cached on the GPU, batch = concatenation with offsets
+        # (gnnrag_csr_concat: no upload, no sort, no stream wait) - what an evaluation run pays per batch from its
+        # second pass over a split on (GNNRAG_DEVICE_STRUCTURES=1)
+        "csr_concat_from_structure_cache_ms": csr_concat_ms,
+        "value_incl_structure_concat": (typed_edges / (elapsed / args.steps + csr_concat_ms["wall_ms_incl_device"] * 1e-3)
+                                        if csr_concat_ms else None),
         # host-buffer boundary: int64 tuple -> int32 upload over PCIe + device structure build, once per batch,
         # amortised over ONE step (a ReaRev forward runs num_iter steps on the same structure); never `value`
         "value_incl_upload_and_build": typed_edges / (elapsed / args.steps + csr_build_ms * 1e-3),
         "dense_math": math_name,
+        "ms_per_step_fp32": ms_per_step_fp32,      # the same step with every product in exact fp32 MFMA (rank 0, 20 steps)
         "step_ms_spread": spread,
         "launch": ("hipGraph replay of the captured L-layer sequence (+ one D2D copy of h0 per step)"
                    if graph is not None else "eager: one gnnrag_reason_stack call per step"),
@@ -298,7 +332,20 @@ def cached_structure_ms(batch, dev, ops):
         bf = fc.batch(ids)
         ops.CsrPlan(bf[0], bf[1], bf[2], cfg.B, cfg.N, cfg.R1, dev, validate=False, hrt_device=bf.hrt_device)
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) * 1e3 / 3
+    cached_ms = (time.perf_counter() - t0) * 1e3 / 3
+    # per-question sorted STRUCTURES on the GPU, batch = concatenation with offsets (gnnrag_csr_concat)
+    sc = fact_mat.DeviceStructureCache(_Loader(), dev)
+    sc.loader.num_kb_relation = cfg.R1 - 1
+    sc.batch(ids)                                   # first use sorts every question once
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        bf = sc.batch(ids)
+        ops.CsrPlan.concat(bf.plans, cfg.N, cfg.R1, dev)
+    host_ms = (time.perf_counter() - t0) * 1e3 / 5      # the call does not wait for the stream: host time to enqueue
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3 / 5
+    return cached_ms, {"host_enqueue_ms": host_ms, "wall_ms_incl_device": wall_ms}
 
 
 def strong_shard(gbatch, gfeats, rank, world):
@@ -403,6 +450,12 @@ def _events_ms(fn, reps):
     return [a.elapsed_time(b) for a, b in evs]
 
 
+def _lib_frontier_ok(plan, D):
+    import ctypes as C
+    from gnnrag_amd import _lib
+    return bool(_lib.load().gnnrag_frontier_supported(C.byref(plan.c), int(D)))
+
+
 def roofline_leg(cfg, layer, devin, ops, F_g, steps):
     """Per-kernel device times with HIP events (torch.cuda.Event on the stream the library
     launches on), op by op, same kernels and arguments as the one-call gnnrag_reason_layer:
@@ -471,6 +524,20 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
     P = box["P"]
     ms["aggregate_fused_dense"] = t(lambda: box.__setitem__("nbr", ops.aggregate_fused(plan, dense, P)))
     ms["aggregate_fused_seed"] = t(lambda: ops.aggregate_fused(plan, seed, P))
+    # the seed-prior launch as the timed steps run it (layer 0 of every iteration): frontier of the prior, the table
+    # rows and neighbour sums of the frontier only (csrc/frontier.hip)
+    seed_form_ms = None
+    if getattr(layer, "seed_prior", False) and _lib_frontier_ok(plan, Dk):
+        ms["frontier_build"] = t(lambda: box.__setitem__("fr", ops.Frontier(plan, seed)))
+        fr = box["fr"]
+        e2e_0 = layer._inference_params()["layers"][0][2]
+        ms["relation_tables_frontier"] = t(lambda: box.__setitem__("Pf", fr.relation_tables(Tf, Ti, ins, e2e_0, P=box.get("Pf"))))
+        nbr_f = torch.zeros((B * N, Dk), dtype=torch.float32, device=h.device)
+        ms["aggregate_fused_frontier"] = t(lambda: fr.aggregate(box["Pf"], out=nbr_f))
+        seed_form_ms = ms["frontier_build"] + ms["relation_tables_frontier"] + ms["aggregate_fused_frontier"]
+        del nbr_f
+        box.pop("Pf")
+        box.pop("fr")
     nbr = box["nbr"]
     ms["update_score_fused"] = t(lambda: ops.update_score_fused(h, nbr, e2e.weight, e2e.bias, sf.weight, sf.bias,
                                                                 layer.local_entity_mask, I))
@@ -489,17 +556,31 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
                                 < 0.8 * B * N * (2 * I + 1) * Dk * Dk)
     ba = bytes_agg(cfg, F_g)
 
-    def hbm(kernel, dense_ms, seed_ms, extra=None):
-        # a step's T iterations each run 1 layer call on the (sparse) seed prior and L - 1 on dense priors
-        avg = (seed_ms + (L - 1) * dense_ms) / L
+    def hbm(kernel, dense_ms, seed_ms, extra=None, seed_form=None):
+        # `achieved` / `frac`: the NAMED kernel on the launches it really runs in a step.  Since round 3 the fused path's
+        # seed-prior launch (layer 0 of every iteration) is a different, much shorter kernel sequence (frontier form), so
+        # the LDS walk only runs the L - 1 dense-prior launches: its figure is the dense-prior one.  The mix over all L
+        # aggregation launches of an iteration (same pinned byte count per launch) is reported next to it.
+        avg = dense_ms if seed_form is not None else (seed_ms + (L - 1) * dense_ms) / L
         ach = ba / (avg * 1e-3) / 1e9
+        mix = ((seed_form if seed_form is not None else seed_ms) + (L - 1) * dense_ms) / L
         o = {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
              "frac": ach / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": ba,
-             "avg_launch_ms": avg, "launches_timed": 2 * reps,
+             "avg_launch_ms": avg, "launches_timed": reps if seed_form is not None else 2 * reps,
              "dense_prior": {"avg_launch_ms": dense_ms, "achieved": ba / (dense_ms * 1e-3) / 1e9,
                              "frac": ba / (dense_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
-             "seed_prior": {"avg_launch_ms": seed_ms},
+             "seed_prior": {"avg_launch_ms": seed_ms, "note": "the same kernel on the seed prior (not what a step runs "
+                                                              "when the frontier form applies)"},
+             "all_aggregation_launches_of_an_iteration": {
+                 "avg_launch_ms": mix, "equivalent_work_frac": ba / (mix * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                 "note": "1 seed-prior launch + (L-1) dense-prior launches, each priced at the pinned byte count"},
              "measured_copy_ceiling_GBps": copy_gbps}
+        if seed_form is not None:
+            o["seed_prior_frontier_form"] = {
+                "kernels": "k_frontier_build + k_tables_frontier + k_walk_frontier (csrc/frontier.hip)",
+                "avg_ms": seed_form, "replaces_ms": seed_ms + ms["relation_tables"],
+                "note": "layer 0 of every iteration: frontier of the seed prior, relation-table rows and neighbour sums of "
+                        "the frontier only; replaces the full table launch + the walk on the seed prior"}
         if extra:
             o.update(extra)
         o["traffic_source"] = pmc_note
@@ -531,7 +612,7 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
             pmc, pmc_note = {}, "unreadable: %r" % (e,)
     r_fused = hbm("gnnrag_aggregate_fused: " + ops.WALK_KERNEL_NAMES[ops.aggregate_fused_variant(plan, Dk)] +
                   ("" if Dk == D else " [hidden size %d zero-padded to %d]" % (D, Dk)), ms["aggregate_fused_dense"],
-                  ms["aggregate_fused_seed"],
+                  ms["aggregate_fused_seed"], seed_form=seed_form_ms, extra=
                   {"note": "fused walk: e2e_linear is pushed into per-question relation tables, so agg [BN,2I*D] is "
                            "never written; `achieved` still uses the pinned unfused byte count (SURVEY 8d), i.e. it "
                            "is an equivalent-work rate and may exceed what an unfused kernel can reach; real HBM "
@@ -541,11 +622,23 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
                 {"note": "the unfused walk the byte formula literally describes (writes agg [BN,2I*D])",
                  "traffic": pmc.get("aggregate_hbm_bytes_per_launch")})
 
-    def mfma(kernel, flops, t_ms):
+    b3_mode = ops.get_dense_math() != ops.MATH_FP32
+
+    def mfma(kernel, flops, t_ms, b3=False):
+        # a bf16x3 kernel runs on the bf16 pipe (6 plane products per fp32-equivalent one): its peak in fp32-equivalent
+        # flops is 2500 / 6 = 417 TFLOP/s; `frac` is against the pipe the kernel really uses, the fraction of the fp32
+        # pipe's peak (a pipe it does not use; can exceed what an exact-fp32 kernel could reach) is kept beside it
         ach = flops / (t_ms * 1e-3) / 1e12
-        return {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "avg_launch_ms": t_ms,
-                "flops_per_launch": flops}
+        peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if b3 else FP32_MFMA_PEAK_TFLOPS
+        o = {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": peak,
+             "unit": "TFLOP/s (fp32-equivalent)", "frac": ach / peak, "avg_launch_ms": t_ms,
+             "flops_per_launch": flops, "pipe": "bf16 MFMA, 6 plane products per product (peak 2500 / 6)" if b3 else
+             "fp32 MFMA"}
+        if b3:
+            o["bf16_flops_per_launch"] = 6.0 * flops
+            o["achieved_bf16_TFLOPs"] = 6.0 * ach
+            o["frac_of_fp32_mfma_peak"] = ach / FP32_MFMA_PEAK_TFLOPS
+        return o
 
     out = {
         "path": "fused" if fused else "unfused",
@@ -556,15 +649,16 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
             # tables whichever form computes them); the bf16x3 kernels issue 6 bf16 MFMAs per fp32-equivalent one, so
             # `frac` of the fp32 peak can exceed what an exact-fp32 kernel could reach
             "update_score": mfma("gnnrag_update_score [BN,(2I+1)D]x[(2I+1)D,D] (k_gemm_f32, k-tiled)", flops_update(cfg),
-                                 ms["update_score"]),
+                                 ms["update_score"], b3=b3_mode),
             "relation_tables": mfma("gnnrag_relation_tables%s [2*rel_total, I*D]x[I*D, D] (%s)"
                                     % ("_planes" if vq else "", "k_tables_vq, bf16x3 V form" if vq else
                                        "k_tables_b3 / k_gemm_f32 generated-A"),
-                                    2.0 * 2 * plan.rel_total * I * D * D, ms["relation_tables"]),
+                                    2.0 * 2 * plan.rel_total * I * D * D, ms["relation_tables"], b3=b3_mode),
             "update_score_fused": mfma("gnnrag_update_score_fused [BN,D]x[D,D] + nbr (%s)"
                                        % ("k_gemm_wres, exact fp32" if ops.get_dense_math() == ops.MATH_FP32
                                           else "k_update_b3, bf16x3, where its shapes apply"),
-                                       2.0 * B * N * D * D, ms["update_score_fused"]),
+                                       2.0 * B * N * D * D, ms["update_score_fused"],
+                                       b3=b3_mode and 193 <= Dk <= 208 and B * N >= 8192),
         },
         "kernel_ms": ms,
     }

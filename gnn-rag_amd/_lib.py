@@ -54,6 +54,8 @@ SIGNATURES = {
     "gnnrag_csr_scratch_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "gnnrag_csr_build": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                    _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(CsrStruct), _VP]),
+    "gnnrag_csr_concat": (C.c_int, [C.POINTER(C.POINTER(CsrStruct)), C.c_int32, C.c_int32, C.c_int32, _VP, C.c_size_t,
+                                    C.POINTER(CsrStruct), _VP]),
     "gnnrag_narrow_tuple": (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, C.c_int32]),
     "gnnrag_csr_permute_weight": (C.c_int, [C.POINTER(CsrStruct), _VP, C.c_int, _VP, _VP, _VP]),
     "gnnrag_linear": (C.c_int, [_VP, C.c_int64, C.c_int32, _VP, _VP, _VP, C.c_int64, C.c_int, _VP,

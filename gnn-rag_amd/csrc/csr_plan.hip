@@ -388,6 +388,82 @@ __global__ __launch_bounds__(256) void k_csr_permute_weight(const int32_t* __res
   out[i] = square ? v * v : v;
 }
 
+
+// ---- batch structure = concatenation of cached per-question structures --------------------
+// Questions are disjoint node ranges (heads / tails are offset by i * N, dataset_load.py:483) and the structure is
+// sorted by destination node, so the batch's sorted order IS the questions' sorted orders one after the other: no sort,
+// no search - every array is a copy with the question's node / fact / relation-row offset added.
+constexpr int kConcatChunk = 24;          // questions per launch: their table travels as a kernel argument (< 4 KB)
+struct ConcatPart {
+  const int32_t* row_ptr[2];
+  const int2* edge[2];
+  const int2* edge_l[2];
+  const int32_t* perm[2];
+  const int2* edge_m;
+  const int32_t* m_from;
+  const int2* rel_rows;
+  int64_t foff;      // first fact of the question in the batch
+  int32_t roff;      // first compact relation row of the question
+  int32_t Fq, Rq, b;
+};
+struct ConcatArgs {
+  ConcatPart part[kConcatChunk];
+  int32_t n;         // questions in this launch
+  int32_t N;
+  int64_t F;         // facts of the whole batch
+  int32_t* row_ptr[2];
+  int2* edge[2];
+  int2* edge_l[2];
+  int32_t* perm[2];
+  int2* edge_m;
+  int32_t* m_from;
+  int2* rel_rows;
+  int32_t* rel_off;
+};
+
+// blockIdx.y = question of the chunk; blockIdx.x strides over the question's items; blockIdx.z: 0 / 1 = the per-
+// direction arrays, 2 = the merged stream (2 Fq records), 3 = row pointers + relation rows
+__global__ __launch_bounds__(256) void k_csr_concat(const ConcatArgs a) {
+  const ConcatPart& q = a.part[blockIdx.y];
+  const int what = blockIdx.z;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int node0 = q.b * a.N;
+  if (what < 2) {
+    const int d = what;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < q.Fq; i += stride) {
+      int2 e = q.edge[d][i], el = q.edge_l[d][i];
+      e.x += node0;
+      el.x += node0;
+      a.edge[d][q.foff + i] = e;
+      a.edge_l[d][q.foff + i] = el;
+      a.perm[d][q.foff + i] = q.perm[d][i] + (int32_t)q.foff;
+    }
+  } else if (what == 2) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < 2 * (int64_t)q.Fq; i += stride) {
+      int2 e = q.edge_m[i];
+      e.x += node0;
+      const int f = q.m_from[i];                       // d * Fq + position in direction d
+      a.edge_m[2 * q.foff + i] = e;
+      a.m_from[2 * q.foff + i] = f < q.Fq ? f + (int32_t)q.foff : (int32_t)(a.F + (f - q.Fq) + q.foff);
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.N; i += stride) {
+      a.row_ptr[0][node0 + i] = q.row_ptr[0][i] + (int32_t)q.foff;
+      a.row_ptr[1][node0 + i] = q.row_ptr[1][i] + (int32_t)q.foff;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < q.Rq; i += stride)
+      a.rel_rows[q.roff + i] = make_int2(q.b, q.rel_rows[i].y);
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.rel_off[q.b] = q.roff;
+  }
+}
+
+__global__ void k_csr_concat_tail(int32_t* rp0, int32_t* rp1, int32_t* rel_off, int64_t BN, int32_t B, int32_t F,
+                                  int32_t rel_total) {
+  rp0[BN] = F;
+  rp1[BN] = F;
+  rel_off[B] = rel_total;
+}
+
 }  // namespace gnnrag
 
 using namespace gnnrag;
@@ -660,5 +736,110 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
   }
   out->rel_total = stats[0];
   out->rel_max = stats[1];
+  return 0;
+}
+
+// Pointers of a gnnrag_csr inside the caller's memory block (shared by gnnrag_csr_build and gnnrag_csr_concat).
+static void csr_bind(gnnrag_csr* out, char* base, const CsrLayout& L, int64_t F, int32_t B, int32_t N, int32_t R1,
+                     bool has_w_gnn, bool has_w_rel) {
+  memset(out, 0, sizeof(*out));
+  out->B = B; out->N = N; out->R1 = R1; out->F = F;
+  out->heavy_deg = kHeavyDeg;
+  out->heavy_cap = L.heavy_cap;
+  for (int d = 0; d < 2; ++d) {
+    out->row_ptr[d] = (int32_t*)(base + L.row_ptr[d]);
+    out->edge[d] = (int32_t*)(base + L.edge[d]);
+    out->perm[d] = (int32_t*)(base + L.perm[d]);
+    out->w_gnn[d] = has_w_gnn ? (float*)(base + L.w_gnn[d]) : nullptr;
+    out->w_rel[d] = has_w_rel ? (float*)(base + L.w_rel[d]) : nullptr;
+    out->heavy[d] = (int32_t*)(base + L.heavy[d]);
+    out->chunk_off[d] = (int32_t*)(base + L.chunk_off[d]);
+    out->edge_l[d] = (int32_t*)(base + L.edge_l[d]);
+  }
+  out->rel_off = (int32_t*)(base + L.rel_off);
+  out->edge_m = (int32_t*)(base + L.edge_m);
+  out->m_from = (int32_t*)(base + L.m_from);
+  out->rel_rows = (int32_t*)(base + L.rel_rows);
+  out->n_heavy = (int32_t*)(base + L.n_heavy);
+  out->n_chunks = out->n_heavy + 2;
+  out->big_cnt = (int32_t*)(base + L.big_cnt);
+  out->big_nodes = (int32_t*)(base + L.big_nodes);
+  out->big_deg = kBigDeg;
+  out->max_chunks = 2 * L.heavy_cap;   // sum ceil(deg/256) over rows with deg > 256 < F/256 + F/257
+}
+
+extern "C" int gnnrag_csr_concat(const gnnrag_csr* const* parts, int32_t B, int32_t N, int32_t R1, void* csr_mem,
+                                 size_t csr_bytes, gnnrag_csr* out, gnnrag_stream_t stream_) {
+  if (!parts || !out || !csr_mem || B <= 0 || N <= 0 || R1 <= 0) return GNNRAG_E_BADARG;
+  int64_t F = 0, RT = 0;
+  int32_t rmax = 0;
+  for (int b = 0; b < B; ++b) {
+    const gnnrag_csr* p = parts[b];
+    if (!p || p->B != 1 || p->N != N || p->R1 != R1 || p->rel_total < 0 || p->F < 0 || !p->edge_m) return GNNRAG_E_BADARG;
+    F += p->F;
+    RT += p->rel_total;
+    rmax = p->rel_total > rmax ? p->rel_total : rmax;
+  }
+  const int64_t BN = (int64_t)B * N;
+  if (BN >= ((int64_t)1 << 31) || F >= ((int64_t)1 << 31) || RT >= ((int64_t)1 << 31)) return GNNRAG_E_UNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_;
+  const CsrLayout L = csr_layout(F, B, N, R1, false, false);
+  if (csr_bytes < L.total) return GNNRAG_E_WORKSPACE;
+  csr_bind(out, (char*)csr_mem, L, F, B, N, R1, false, false);
+  GNNRAG_HIP(hipMemsetAsync(out->big_cnt, 0, (size_t)B * sizeof(int32_t), stream));
+  GNNRAG_HIP(hipMemsetAsync(out->n_heavy, 0, 8 * sizeof(int32_t), stream));
+  ConcatArgs a;
+  memset(&a, 0, sizeof(a));
+  a.N = N; a.F = F;
+  for (int d = 0; d < 2; ++d) {
+    a.row_ptr[d] = out->row_ptr[d];
+    a.edge[d] = (int2*)out->edge[d];
+    a.edge_l[d] = (int2*)out->edge_l[d];
+    a.perm[d] = out->perm[d];
+  }
+  a.edge_m = (int2*)out->edge_m; a.m_from = out->m_from; a.rel_rows = (int2*)out->rel_rows; a.rel_off = out->rel_off;
+  int64_t foff = 0;
+  int32_t roff = 0;
+  for (int b0 = 0; b0 < B; b0 += kConcatChunk) {
+    const int n = B - b0 < kConcatChunk ? B - b0 : kConcatChunk;
+    int64_t fmax = N;
+    for (int k = 0; k < n; ++k) {
+      const gnnrag_csr* p = parts[b0 + k];
+      ConcatPart& q = a.part[k];
+      for (int d = 0; d < 2; ++d) {
+        q.row_ptr[d] = p->row_ptr[d];
+        q.edge[d] = (const int2*)p->edge[d];
+        q.edge_l[d] = (const int2*)p->edge_l[d];
+        q.perm[d] = p->perm[d];
+      }
+      q.edge_m = (const int2*)p->edge_m; q.m_from = p->m_from; q.rel_rows = (const int2*)p->rel_rows;
+      q.foff = foff; q.roff = roff; q.Fq = (int32_t)p->F; q.Rq = p->rel_total; q.b = b0 + k;
+      foff += p->F;
+      roff += p->rel_total;
+      fmax = 2 * p->F > fmax ? 2 * p->F : fmax;
+    }
+    a.n = n;
+    int gx = (int)((fmax + 255) / 256);
+    gx = gx < 1 ? 1 : gx > 64 ? 64 : gx;
+    hipLaunchKernelGGL(k_csr_concat, dim3(gx, n, 4), dim3(256), 0, stream, a);
+    GNNRAG_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_csr_concat_tail, dim3(1), dim3(1), 0, stream, out->row_ptr[0], out->row_ptr[1], out->rel_off, BN, B,
+                     (int32_t)F, (int32_t)RT);
+  GNNRAG_LAUNCH_CHECK();
+  for (int d = 0; d < 2; ++d) {
+    hipLaunchKernelGGL(k_csr_heavy, dim3((int)((BN + 255) / 256)), dim3(256), 0, stream, out->row_ptr[d], BN,
+                       (int32_t)kHeavyDeg, out->heavy[d], out->heavy_cap, out->n_heavy + d);
+    GNNRAG_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_csr_heavy_chunks, dim3(2), dim3(1024), 0, stream, out->row_ptr[0], out->row_ptr[1],
+                     out->heavy[0], out->heavy[1], out->n_heavy, out->heavy_cap, out->chunk_off[0],
+                     out->chunk_off[1], out->n_chunks);
+  GNNRAG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_csr_big, dim3((int)((BN + 255) / 256)), dim3(256), 0, stream, out->row_ptr[0],
+                     out->row_ptr[1], BN, N, (int32_t)kBigDeg, out->big_cnt, out->big_nodes);
+  GNNRAG_LAUNCH_CHECK();
+  out->rel_total = (int32_t)RT;      // known on the host: this call does not wait for the stream
+  out->rel_max = rmax;
   return 0;
 }

@@ -133,10 +133,20 @@ class BatchFacts:
     ``norm_rel``).  The reference's own modules cannot consume it (they build ``torch.LongTensor`` from numpy arrays):
     it is handed out only by ``patch_loader(..., device=...)``, i.e. next to ``install.swap``-ed modules."""
 
-    def __init__(self, hrt_device, sizes, parts, N):
-        self.hrt_device = hrt_device
+    def __init__(self, hrt_device, sizes, parts, N, plans=None, make_hrt=None):
+        self._hrt, self._make_hrt = hrt_device, make_hrt
         self._sizes, self._parts, self._N = sizes, parts, N
         self._lazy = {}
+        # DeviceStructureCache: the questions' cached single-question structures (ops.CsrPlan, B = 1), in batch order -
+        # the modules then assemble the batch structure by concatenation (ops.CsrPlan.concat) instead of sorting
+        self.plans = plans
+
+    @property
+    def hrt_device(self):
+        """[3, F] int32 id block on the GPU; built on first access when the batch came from cached structures."""
+        if self._hrt is None:
+            self._hrt = self._make_hrt()
+        return self._hrt
 
     def __len__(self):
         return 7
@@ -171,11 +181,29 @@ class BatchFacts:
         """Facts of questions [lo, hi) as a self-contained batch (node ids re-based by ``lo * N``), sliced ON THE
         DEVICE - what ``shard.shard_edge_tuple`` hands a rank when the loader serves device-resident tuples."""
         a, b = int(self._sizes[:lo].sum()), int(self._sizes[:hi].sum())
+        if self.plans is not None:               # cached structures shard by slicing the list
+            parts, sizes, N, plans = self._parts[lo:hi], self._sizes[lo:hi], self._N, self.plans[lo:hi]
+            return BatchFacts(None, sizes, parts, N, plans=plans, make_hrt=lambda: _cat_blocks([p._hrt[:, : p.F] for p in plans], sizes, N))
         hrt = self.hrt_device[:, a:b].clone()
         if lo:
             hrt[0] -= lo * self._N
             hrt[2] -= lo * self._N
         return BatchFacts(hrt, self._sizes[lo:hi], self._parts[lo:hi], self._N)
+
+
+def _cat_blocks(blocks, sizes, N):
+    """Per-question [3, F_g] int32 blocks (question-local node ids) -> the batch's [3, F] block with node offsets."""
+    import torch
+    if not blocks:
+        return torch.zeros((3, 0), dtype=torch.int32)
+    dev = blocks[0].device
+    hrt = torch.cat(blocks, dim=1)
+    off = torch.repeat_interleave(torch.arange(len(blocks), device=dev, dtype=torch.int32) * N,
+                                  torch.from_numpy(np.asarray(sizes, dtype=np.int64)).to(dev, non_blocking=True),
+                                  output_size=int(np.sum(sizes)))        # size given: no device->host sync
+    hrt[0] += off
+    hrt[2] += off
+    return hrt
 
 
 class DeviceFactCache(FactCache):
@@ -206,18 +234,47 @@ class DeviceFactCache(FactCache):
             blocks.append(d)
         sizes = np.array([p[0].shape[1] for p in parts], dtype=np.int64)
         if blocks:
-            hrt = torch.cat(blocks, dim=1)
-            off = torch.repeat_interleave(torch.arange(len(blocks), device=self.device, dtype=torch.int32) * N,
-                                          torch.from_numpy(sizes).to(self.device, non_blocking=True),
-                                          output_size=int(sizes.sum()))    # size given: no device->host sync
-            hrt[0] += off
-            hrt[2] += off
+            hrt = _cat_blocks(blocks, sizes, N)
         else:
             hrt = torch.zeros((3, 0), dtype=torch.int32, device=self.device)
         return BatchFacts(hrt, sizes, parts, N)
 
 
-def patch_loader(loader, cache: bool = False, keep_rng_stream: bool = False, device=None):
+class DeviceStructureCache(DeviceFactCache):
+    """:class:`DeviceFactCache` that also keeps every question's destination-sorted STRUCTURE on the GPU (a
+    single-question ``ops.CsrPlan``: built the first time the question is used, ~64 B per fact): a batch is then the
+    concatenation of its questions' structures (``ops.CsrPlan.concat`` -> ``gnnrag_csr_concat``: copies with offsets, no
+    upload, no sort, no wait for the stream) - SURVEY.md section 8 f-1 as written ("cached per-question int32 CSR built
+    once at load time, batch = concatenation with offsets")."""
+
+    def __init__(self, loader, device, max_questions: int = 200000):
+        super().__init__(loader, device, max_questions)
+        self._plans = {}
+
+    def batch(self, sample_ids):
+        import torch
+        from .. import ops
+        N = self.loader.max_local_entity
+        R1 = self.loader.num_kb_relation + 1                  # rows of the relation feature tables (dataset_load.py:413)
+        parts, plans = [], []
+        for s_ in sample_ids:
+            s_ = int(s_)
+            q = self._question(s_)
+            pl = self._plans.get(s_)
+            if pl is None:
+                blk = torch.from_numpy(np.ascontiguousarray(q[0])).to(self.device)
+                pl = ops.CsrPlan(None, None, None, 1, N, R1, self.device, hrt_device=blk)
+                if len(self._plans) < self.max_questions:
+                    self._plans[s_] = pl
+                self._dev[s_] = blk
+            parts.append(q)
+            plans.append(pl)
+        sizes = np.array([p[0].shape[1] for p in parts], dtype=np.int64)
+        return BatchFacts(None, sizes, parts, N, plans=plans,
+                          make_hrt=lambda: _cat_blocks([p._hrt[:, : p.F] for p in plans], sizes, N).to(self.device))
+
+
+def patch_loader(loader, cache: bool = False, keep_rng_stream: bool = False, device=None, structures: bool = False):
     """Rebinds ``loader._build_fact_mat`` to the vectorised builder (the reference file is untouched).
     ``cache=True`` additionally serves ``fact_dropout == 0`` batches from a :class:`FactCache`.  The cached
     path does not draw the per-question ``np.random.permutation`` the reference draws even without dropout
@@ -226,10 +283,14 @@ def patch_loader(loader, cache: bool = False, keep_rng_stream: bool = False, dev
     reference; ``keep_rng_stream=True`` draws and discards those permutations (same stream as the reference,
     at the cost of most of the caching gain).  Use the plain cache for evaluation-only runs.  ``device``: keep the
     per-question id blocks on that GPU (:class:`DeviceFactCache`; the tuple is then a :class:`BatchFacts`, readable by
-    the MI355X modules only)."""
+    the MI355X modules only).  ``structures`` (with ``device``): also cache every question's sorted structure on the GPU,
+    so that a batch's structure is a concatenation (:class:`DeviceStructureCache`)."""
     fc = None
     if cache:
-        fc = DeviceFactCache(loader, device) if device is not None else FactCache(loader)
+        if device is not None and structures:
+            fc = DeviceStructureCache(loader, device)
+        else:
+            fc = DeviceFactCache(loader, device) if device is not None else FactCache(loader)
 
     def build(self, sample_ids, fact_dropout):
         if fc is not None and fact_dropout == 0:

@@ -23,8 +23,14 @@ def plan_for(edge_list, B: int, N: int, R1: int, device) -> "ops.CsrPlan":
     key = (id(edge_list), B, N, R1, str(device))
     if _last_plan["key"] == key and _last_plan["tuple"] is edge_list:
         return _last_plan["plan"]
-    hrt = getattr(edge_list, "hrt_device", None)          # data/fact_mat.BatchFacts: the id block is already on the GPU
-    if hrt is not None:
+    plans = getattr(edge_list, "plans", None)             # data/fact_mat.DeviceStructureCache: per-question structures
+    hrt = None if plans is not None else getattr(edge_list, "hrt_device", None)   # BatchFacts: the id block is on the GPU
+    if plans is not None and len(plans) == B and all(p.N == N and p.R1 == R1 for p in plans):
+        plan = ops.CsrPlan.concat(plans, N, R1, plans[0].device)          # copies with offsets: no sort, no sync
+    elif plans is not None:
+        hrt = edge_list.hrt_device
+        plan = ops.CsrPlan(None, None, None, B, N, R1, hrt.device, hrt_device=hrt)
+    elif hrt is not None:
         plan = ops.CsrPlan(None, None, None, B, N, R1, hrt.device, hrt_device=hrt)
     else:
         plan = ops.CsrPlan(edge_list[0], edge_list[1], edge_list[2], B, N, R1, device)

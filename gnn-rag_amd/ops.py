@@ -171,6 +171,57 @@ class CsrPlan:
         # compact relation rows: question b's tables are rows rel_off[b] : rel_off[b+1] of P[d]
         self.rel_total, self.rel_max = int(self.c.rel_total), int(self.c.rel_max)
 
+    @classmethod
+    def concat(cls, parts, N: int, R1: int, device) -> "CsrPlan":
+        """The structure of a batch as the concatenation of per-question structures already on the device
+        (``gnnrag_csr_concat``; ``parts`` = one ``CsrPlan(..., B=1, N, R1)`` per question, in batch order): a copy with
+        offsets - no upload, no sort, no wait for the stream; bit-identical to building the batch tuple from scratch."""
+        lib = _lib.load()
+        B = len(parts)
+        if B == 0:
+            raise ValueError("a batch needs at least one question")
+        self = cls.__new__(cls)
+        self.B, self.N, self.R1 = B, int(N), int(R1)
+        self.F = int(sum(p.F for p in parts))
+        self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        for p in parts:
+            if p.B != 1 or p.N != self.N or p.R1 != self.R1 or p.device != self.device:
+                raise ValueError("parts must be single-question structures of the same N / R1 on %s" % self.device)
+        if B * self.N >= 2 ** 31 or self.F >= 2 ** 31:
+            raise ValueError("batch too large for int32 indices")
+        arr = (C.POINTER(_lib.CsrStruct) * B)(*[C.pointer(p.c) for p in parts])
+        with torch.cuda.device(self.device):
+            nbytes = lib.gnnrag_csr_bytes(self.F, B, self.N, self.R1, 0, 0)
+            self._mem = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+            self.c = _lib.CsrStruct()
+            _lib.check(lib.gnnrag_csr_concat(arr, B, self.N, self.R1, self._mem.data_ptr(), self._mem.numel(),
+                                             C.byref(self.c), _stream()), "gnnrag_csr_concat")
+        self._parts = list(parts)            # the per-question blocks stay alive as long as the batch may read them
+        self._hrt_lazy = None
+        self._w = {}
+        self.rel_total, self.rel_max = int(self.c.rel_total), int(self.c.rel_max)
+        return self
+
+    @property
+    def _hrt(self):
+        """[3, F] int32 id block of the batch tuple on the device (the backward's (question, relation) ordering reads
+        it).  A concatenated structure builds it from its parts on first use."""
+        if getattr(self, "_hrt_lazy", None) is None:
+            blocks = []
+            for b, p in enumerate(self._parts):
+                h = p._hrt[:, : p.F].clone()
+                h[0] += b * self.N
+                h[2] += b * self.N
+                blocks.append(h)
+            self._hrt_lazy = torch.cat(blocks, dim=1) if self.F else torch.zeros((3, 1), dtype=torch.int32, device=self.device)
+        return self._hrt_lazy
+
+    @_hrt.setter
+    def _hrt(self, value):
+        self._hrt_lazy = value
+
     def walk_workspace(self, D: int, I: int) -> torch.Tensor:
         """Scratch for the heavy-row partial sums of the walk kernels (cached per (D, I))."""
         key = ("ws", D, min(I, 3))

@@ -109,6 +109,18 @@ int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const int32_t* t
                      void* csr_mem, size_t csr_bytes, void* scratch, size_t scratch_bytes,
                      gnnrag_csr* out, gnnrag_stream_t stream);
 
+/* The structure of a batch as the CONCATENATION of per-question structures that are already on the device (SURVEY.md
+ * section 8 f-1: "cached per-question int32 CSR built once at load time, batch = concatenation with offsets").
+ * parts: HOST array of B structures, each built by gnnrag_csr_build with B = 1 for ONE question (node ids 0 .. N-1,
+ * the same N and R1); question b of the batch gets node ids b * N .., facts in the order of `parts` (the order of the
+ * reference's batch tuple, dataset_load.py:481-506).  Questions are disjoint node ranges and the structure is sorted
+ * by destination node, so no sort is needed: every array is a copy with offsets added.  The result is bit-identical
+ * to gnnrag_csr_build on the concatenated tuple.  No scratch, no synchronisation (rel_total / rel_max are sums / the
+ * maximum of the parts' host fields).  Per-fact weights are attached afterwards (gnnrag_csr_permute_weight).
+ * csr_mem: gnnrag_csr_bytes(sum of the parts' F, B, N, R1, 0, 0) bytes. */
+int gnnrag_csr_concat(const gnnrag_csr* const* parts, int32_t B, int32_t N, int32_t R1, void* csr_mem, size_t csr_bytes,
+                      gnnrag_csr* out, gnnrag_stream_t stream);
+
 /* HOST helper (no device work): narrows the batch tuple's int64 id arrays (dataset_load.py:527) into one [3, F]
  * int32 block (heads, rels, tails) with up to `nthreads` threads and checks that every id lies in [0, 2^31):
  * GNNRAG_E_TUPLE otherwise.  `out` is host memory (pinned memory makes the following upload faster). */

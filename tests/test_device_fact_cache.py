@@ -78,3 +78,57 @@ def test_structure_from_the_device_resident_cache_is_bit_identical():
             else:
                 np.testing.assert_array_equal(pa[k], pb[k], err_msg=k)
     assert sorted(devc._dev) == [0, 1, 3, 5, 7, 9, 11]      # every question uploaded once
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["small", "hubs_and_heavy_rows"])
+def test_batch_structure_as_concatenation_of_cached_question_structures(shape):
+    """f-1 as SURVEY.md section 8 words it: per-question destination-sorted structures cached on the GPU at first use,
+    a batch's structure = their concatenation with offsets (gnnrag_csr_concat: no upload, no sort, no wait for the
+    stream).  Bit-identical to the structure built from the batch tuple - every array incl. the merged record stream,
+    the compact relation rows, the heavy / big node lists - for repeated and empty questions, and layer outputs
+    computed on either structure are bit-identical too."""
+    import torch
+    import gnnrag_amd  # noqa: F401
+    from gnnrag_amd import ops
+    from gnnrag_amd.data.fact_mat import DeviceStructureCache, FactCache
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(11)
+    if shape == "small":
+        ld = _StubLoader(rng, n_q=12, N=300, num_rel=25)
+        ld.kb_adj_mats[4] = (np.zeros(0, np.int64),) * 3                    # a question without typed edges
+        batches = ([0, 5, 7, 11], [3, 3, 1], [9], [4, 2, 4])
+    else:
+        ld = _StubLoader(rng, n_q=5, N=1500, num_rel=40)
+        for q in range(5):                                                   # hubs: rows of > 256 and > 4096 facts
+            n = len(ld.global2local_entity_maps[q])
+            e = 9000
+            ld.kb_adj_mats[q] = ((rng.zipf(1.5, e) % n).astype(np.int64), rng.integers(0, 40, e), rng.integers(0, n, e))
+        batches = ([0, 1, 2, 3, 4], [4, 0])
+    host, devc = FactCache(ld), DeviceStructureCache(ld, dev)
+    N, R1 = ld.max_local_entity, ld.num_kb_relation + 1
+    for ids in batches:
+        a, b = host.batch(ids), devc.batch(ids)
+        B = len(ids)
+        pa = ops.CsrPlan(a[0], a[1], a[2], B, N, R1, dev)
+        pb = ops.CsrPlan.concat(b.plans, N, R1, dev)
+        assert (pa.rel_total, pa.rel_max, pa.F) == (pb.rel_total, pb.rel_max, pb.F)
+        ha, hb = pa.to_host(), pb.to_host()
+        for k in ha:
+            if k == "big":
+                assert all(np.array_equal(x, y) for x, y in zip(ha[k], hb[k]))
+            else:
+                np.testing.assert_array_equal(ha[k], hb[k], err_msg=k)
+        np.testing.assert_array_equal(b.hrt_device.cpu().numpy(), np.stack([a[0], a[1], a[2]]))     # lazily built id block
+        # one fused layer on both structures
+        D, I = 200, 2
+        g = torch.Generator().manual_seed(B)
+        r = lambda *sh: (0.3 * torch.randn(*sh, generator=g)).to(dev)
+        dist = torch.rand(B, N, generator=g).to(dev)
+        T0, T1, ins, W = r(R1, D), r(R1, D), r(B, I, D), r(D, (2 * I + 1) * D)
+        outs = []
+        for pl in (pa, pb):
+            P = ops.relation_tables(pl, T0, T1, ins, W)
+            outs.append(ops.aggregate_fused(pl, dist, P))
+        assert torch.equal(outs[0], outs[1])
+    assert len(devc._plans) == len({i for ids in batches for i in ids})      # every question sorted once

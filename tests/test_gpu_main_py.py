@@ -12,8 +12,9 @@ for the same checkpoint and data (oracle/stage_ref.py: expected_test.info, expec
   * per question the same candidates in the same order, their probabilities within 1e-4 (north_star's bar),
   * identical per-question precision / recall / F1 / hit / EM and identical logged F1 / H@1 / EM of both splits;
 
-and once more with GNNRAG_FORCE_DIST=1, which puts shard_model and RCCL (all-gather of the scored nodes, all-reduce of
-the loss) on the path with world size 1.
+once more with GNNRAG_FORCE_DIST=1, which puts shard_model and RCCL (all-gather of the scored nodes, all-reduce of
+the loss) on the path with world size 1, and once with GNNRAG_DEVICE_STRUCTURES=1 (per-question sorted structures cached
+on the GPU, a batch's structure = their concatenation).
 
 oracle/_ref (staged reference sources + synthetic dataset + checkpoint + CPU expectations) is git-ignored and built by
 ``python oracle/stage_ref.py`` / ``__graft_entry__.build()`` in the build container; it travels to the GPU box with the
@@ -61,7 +62,7 @@ def _run_main_py(tmp_path, extra_env):
     lines = open(os.path.join(ck, "gpu_test.info")).read().splitlines()
     out_dir = os.path.join(REPO, "gpurun_out", "main_py")
     os.makedirs(out_dir, exist_ok=True)
-    tag = "dist" if extra_env else "single"
+    tag = "dist" if "GNNRAG_FORCE_DIST" in extra_env else "structures" if extra_env else "single"
     with open(os.path.join(out_dir, "run_%s.log" % tag), "w") as f:
         f.write(log[-20000:])
     shutil.copyfile(os.path.join(ck, "gpu_test.info"), os.path.join(out_dir, "gpu_test_%s.info" % tag))
@@ -69,11 +70,12 @@ def _run_main_py(tmp_path, extra_env):
 
 
 @pytest.mark.skipif(not STAGED, reason="oracle/_ref not staged (python oracle/stage_ref.py in the build container)")
-@pytest.mark.parametrize("mode", ["single", "force_dist"])
+@pytest.mark.parametrize("mode", ["single", "force_dist", "structure_cache"])
 def test_unmodified_main_py_eval_matches_cpu_reference(tmp_path, mode):
     want_metrics = json.load(open(os.path.join(CKPT, "expected.json")))
     want = [json.loads(l) for l in open(os.path.join(CKPT, "expected_test.info")).read().splitlines()]
-    metrics, got, log = _run_main_py(tmp_path, {"GNNRAG_FORCE_DIST": "1"} if mode == "force_dist" else {})
+    env = {"force_dist": {"GNNRAG_FORCE_DIST": "1"}, "structure_cache": {"GNNRAG_DEVICE_STRUCTURES": "1"}}.get(mode, {})
+    metrics, got, log = _run_main_py(tmp_path, env)
     assert "gnnrag_amd: native library mapped" in log, log[-2000:]        # the child ran on libgnnrag_hip.so
     assert metrics == want_metrics, (metrics, want_metrics)               # logged with 4 decimals by the reference
     assert len(got) == len(want) and len(got) > 0

@@ -84,10 +84,14 @@ def main():
                     # evaluation-only runs use it as it is, training runs keep the reference's RNG stream
                     # GNNRAG_DEVICE_FACTS=1 (single-rank evaluation): per-question id blocks stay on the GPU
                     dev = None
-                    if os.environ.get("GNNRAG_DEVICE_FACTS") and is_eval and split != "train":
+                    if ((os.environ.get("GNNRAG_DEVICE_FACTS") or os.environ.get("GNNRAG_DEVICE_STRUCTURES"))
+                            and is_eval and split != "train"):
                         import torch
                         dev = torch.device("cuda", torch.cuda.current_device())
-                    patch_loader(dataset[split], cache=(split != "train"), keep_rng_stream=not is_eval, device=dev)
+                    # GNNRAG_DEVICE_STRUCTURES=1: additionally every question's sorted structure stays on the GPU and a
+                    # batch's structure is their concatenation (no per-batch sort)
+                    patch_loader(dataset[split], cache=(split != "train"), keep_rng_stream=not is_eval, device=dev,
+                                 structures=bool(os.environ.get("GNNRAG_DEVICE_STRUCTURES")) and dev is not None)
             return dataset
 
         dataset_load.load_data = load_data
