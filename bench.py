@@ -137,13 +137,6 @@ def main():
     stack.init_reason(layer, batch, devin, devin.h0)          # uploads int32 tuple + device CSR build
     torch.cuda.synchronize()
     csr_first_ms = (time.perf_counter() - t0) * 1e3
-    et = batch.edge_tuple
-    t0 = time.perf_counter()
-    for _ in range(3):
-        ops.CsrPlan(et[0], et[1], et[2], cfg.B, cfg.N, cfg.R1, dev, validate=False)
-    torch.cuda.synchronize()
-    csr_build_ms = (time.perf_counter() - t0) * 1e3 / 3
-    csr_cached_ms, csr_concat_ms = cached_structure_ms(batch, dev, ops) if rank == 0 else (None, None)
 
     graph = None
     if args.launch == "graph":
@@ -255,6 +248,19 @@ def main():
             del layer32
         finally:
             ops.set_dense_math(old_math)
+
+    # structure-build timings AFTER the timed loops: this leg allocates and frees hundreds of device blocks (one
+    # structure per question), and run before the timed region it left the HIP runtime with a one-off ~45 ms stall a few
+    # thousand launches later - inside the timed loop of the workloads with many launches per step (C3: 2.06 instead of
+    # 0.50 ms per step; tools/c3_probe.sh)
+    et = batch.edge_tuple
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ops.CsrPlan(et[0], et[1], et[2], cfg.B, cfg.N, cfg.R1, dev, validate=False)
+    torch.cuda.synchronize()
+    csr_build_ms = (time.perf_counter() - t0) * 1e3 / 3
+    csr_cached_ms, csr_concat_ms = (cached_structure_ms(batch, dev, ops)
+                                    if rank == 0 and not os.environ.get("BENCH_SKIP_STRUCTURE_TIMING") else (None, None))
 
     ms_per_step = elapsed * 1e3 / args.steps
     typed_edges = global_B * cfg.E * cfg.L * cfg.T
