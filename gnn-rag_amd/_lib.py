@@ -79,6 +79,9 @@ SIGNATURES = {
                                             C.c_int32, _VP, C.c_size_t, _VP]),
     "gnnrag_seed_retrieve": (C.c_int, [_VP, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, _VP]),
     "gnnrag_topp_candidates": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_double, C.c_double, _VP, _VP, _VP]),
+    "gnnrag_topp_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "gnnrag_topp_candidates_ws": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_double, C.c_double, _VP, _VP, _VP,
+                                            C.c_size_t, _VP]),
     "gnnrag_relation_tables": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32,
                                          C.c_int32, _VP]),
     "gnnrag_update_score_fused": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_int32,

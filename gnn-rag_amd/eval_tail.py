@@ -25,7 +25,8 @@ import torch
 from . import ops
 
 
-TOPP_MAX_N = 16384      # slots per question the selection kernel sorts in one CU's LDS (eval_tail.hip)
+TOPP_MAX_N = 1 << 24    # (round 3: the kernel takes any N - questions with > 16384 slots filter first and sort the
+                        # survivors in a workspace; the host loop below stays as the documented fallback beyond 2^24)
 
 
 def _host_candidates(pred_dist: torch.Tensor, eligible: np.ndarray, local_entity: np.ndarray, ignore_prob: float,

@@ -889,9 +889,11 @@ def topp_candidates(pred_dist: torch.Tensor, eligible: torch.Tensor, ignore_prob
     slots = torch.empty((B, N), dtype=torch.int32, device=pred_dist.device)
     cnt = torch.empty((B, 2), dtype=torch.int32, device=pred_dist.device)
     with torch.cuda.device(pred_dist.device):
-        _lib.check(lib.gnnrag_topp_candidates(pred_dist.data_ptr(), eligible.data_ptr(), B, N, float(ignore_prob),
-                                              float(eps), slots.data_ptr(), cnt.data_ptr(), _stream()),
-                   "gnnrag_topp_candidates")
+        nws = lib.gnnrag_topp_workspace_bytes(B, N)          # > 0 for N > 16384: the survivors are sorted outside LDS
+        ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=pred_dist.device)
+        _lib.check(lib.gnnrag_topp_candidates_ws(pred_dist.data_ptr(), eligible.data_ptr(), B, N, float(ignore_prob),
+                                                 float(eps), slots.data_ptr(), cnt.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                 _stream()), "gnnrag_topp_candidates_ws")
     return slots, cnt
 
 

@@ -415,6 +415,13 @@ int gnnrag_frontier_read(const gnnrag_csr* csr, const void* fws, int32_t* counts
 int gnnrag_topp_candidates(const float* pred_dist, const uint8_t* eligible, int32_t B, int32_t N,
                            double ignore_prob, double eps, int32_t* out_slot, int32_t* out_cnt,
                            gnnrag_stream_t stream);
+/* The same selection for ANY N: questions with more than 16384 node slots (BASELINE config 5: 20 000) filter first,
+ * compact the survivors into `workspace` (gnnrag_topp_workspace_bytes(B, N) bytes of device scratch; 0 for N <= 16384)
+ * and sort them there - in LDS when at most 16384 slots survive the filter, else in the workspace. */
+size_t gnnrag_topp_workspace_bytes(int32_t B, int32_t N);
+int gnnrag_topp_candidates_ws(const float* pred_dist, const uint8_t* eligible, int32_t B, int32_t N,
+                              double ignore_prob, double eps, int32_t* out_slot, int32_t* out_cnt,
+                              void* workspace, size_t workspace_bytes, gnnrag_stream_t stream);
 
 /* out[b,:] = sum_n seed_info[b,n] * ent_emb[b,n,:]  - the seed retrieval of QueryReform.forward
  * (gnn/modules/query_update.py:40, torch.bmm over all N rows); only rows with a non-zero flag are
