@@ -30,7 +30,7 @@ class CsrStruct(C.Structure):
         ("big_deg", C.c_int32), ("reserved_", C.c_int32),
         ("edge_l", C.c_void_p * 2), ("rel_off", C.c_void_p), ("rel_rows", C.c_void_p),
         ("rel_total", C.c_int32), ("rel_max", C.c_int32),
-        ("edge_m", C.c_void_p), ("m_from", C.c_void_p),
+        ("edge_m", C.c_void_p), ("m_from", C.c_void_p), ("m_dst", C.c_void_p),
     ]
 
 

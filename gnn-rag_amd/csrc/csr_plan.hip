@@ -23,7 +23,7 @@ namespace gnnrag {
 
 struct CsrLayout {
   size_t row_ptr[2], edge[2], perm[2], w_gnn[2], w_rel[2], heavy[2], chunk_off[2], n_heavy, big_cnt, big_nodes;
-  size_t edge_l[2], rel_off, rel_rows, edge_m, m_from, total;
+  size_t edge_l[2], rel_off, rel_rows, edge_m, m_from, m_dst, total;
   int32_t heavy_cap;
 };
 
@@ -54,6 +54,7 @@ static CsrLayout csr_layout(int64_t F, int32_t B, int32_t N, int32_t R1, int has
   L.rel_rows = take((BR < Fp ? BR : Fp) * 2 * sizeof(int32_t));   // every compact row has >= 1 fact
   L.edge_m = take(2 * Fp * 2 * sizeof(int32_t));
   L.m_from = take(2 * Fp * sizeof(int32_t));
+  L.m_dst = take(2 * Fp * sizeof(int32_t));
   L.total = off;
   return L;
 }
@@ -141,7 +142,8 @@ __global__ __launch_bounds__(256) void k_csr_merge(const int32_t* __restrict__ p
                                                    const int32_t* __restrict__ rp0, const int32_t* __restrict__ rp1,
                                                    const int2* __restrict__ el0, const int2* __restrict__ el1,
                                                    const int32_t* __restrict__ rel_off, int32_t N, int64_t F,
-                                                   int64_t BN, int2* __restrict__ edge_m, int32_t* __restrict__ m_from) {
+                                                   int64_t BN, int2* __restrict__ edge_m, int32_t* __restrict__ m_from,
+                                                   int32_t* __restrict__ m_dst) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= F) return;
   // (an invalid tuple - node id outside [0, B*N) - is rejected by the build AFTER these kernels have run: such a fact
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(256) void k_csr_merge(const int32_t* __restrict__ p
     const int64_t m = i + rp1[n];
     edge_m[m] = el0[i];
     m_from[m] = (int32_t)i;
+    m_dst[m] = n;
   } else {
     const int n = nd;                             // destination in direction 1
     const int64_t m = i + rp0[n + 1];
@@ -161,6 +164,7 @@ __global__ __launch_bounds__(256) void k_csr_merge(const int32_t* __restrict__ p
     e.y += rel_off[q + 1] - rel_off[q] + 1;
     edge_m[m] = e;
     m_from[m] = (int32_t)(F + i);
+    m_dst[m] = n;
   }
 }
 
@@ -401,6 +405,7 @@ struct ConcatPart {
   const int32_t* perm[2];
   const int2* edge_m;
   const int32_t* m_from;
+  const int32_t* m_dst;
   const int2* rel_rows;
   int64_t foff;      // first fact of the question in the batch
   int32_t roff;      // first compact relation row of the question
@@ -417,6 +422,7 @@ struct ConcatArgs {
   int32_t* perm[2];
   int2* edge_m;
   int32_t* m_from;
+  int32_t* m_dst;
   int2* rel_rows;
   int32_t* rel_off;
 };
@@ -445,6 +451,7 @@ __global__ __launch_bounds__(256) void k_csr_concat(const ConcatArgs a) {
       const int f = q.m_from[i];                       // d * Fq + position in direction d
       a.edge_m[2 * q.foff + i] = e;
       a.m_from[2 * q.foff + i] = f < q.Fq ? f + (int32_t)q.foff : (int32_t)(a.F + (f - q.Fq) + q.foff);
+      a.m_dst[2 * q.foff + i] = q.m_dst[i] + node0;
     }
   } else {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.N; i += stride) {
@@ -650,6 +657,7 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
   out->rel_off = (int32_t*)(base + L.rel_off);
   out->edge_m = (int32_t*)(base + L.edge_m);
   out->m_from = (int32_t*)(base + L.m_from);
+  out->m_dst = (int32_t*)(base + L.m_dst);
   out->rel_rows = (int32_t*)(base + L.rel_rows);
   out->n_heavy = (int32_t*)(base + L.n_heavy);
   out->n_chunks = out->n_heavy + 2;
@@ -720,7 +728,8 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
   if (F > 0) {
     hipLaunchKernelGGL(k_csr_merge, dim3((unsigned)((F + 255) / 256), 2), dim3(256), 0, stream, out->perm[0],
                        out->perm[1], heads, tails, out->row_ptr[0], out->row_ptr[1], (const int2*)out->edge_l[0],
-                       (const int2*)out->edge_l[1], out->rel_off, N, F, BN, (int2*)out->edge_m, out->m_from);
+                       (const int2*)out->edge_l[1], out->rel_off, N, F, BN, (int2*)out->edge_m, out->m_from,
+                       out->m_dst);
     GNNRAG_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(k_csr_big, dim3((int)((BN + 255) / 256)), dim3(256), 0, stream, out->row_ptr[0],
@@ -759,6 +768,7 @@ static void csr_bind(gnnrag_csr* out, char* base, const CsrLayout& L, int64_t F,
   out->rel_off = (int32_t*)(base + L.rel_off);
   out->edge_m = (int32_t*)(base + L.edge_m);
   out->m_from = (int32_t*)(base + L.m_from);
+  out->m_dst = (int32_t*)(base + L.m_dst);
   out->rel_rows = (int32_t*)(base + L.rel_rows);
   out->n_heavy = (int32_t*)(base + L.n_heavy);
   out->n_chunks = out->n_heavy + 2;
@@ -797,7 +807,7 @@ extern "C" int gnnrag_csr_concat(const gnnrag_csr* const* parts, int32_t B, int3
     a.edge_l[d] = (int2*)out->edge_l[d];
     a.perm[d] = out->perm[d];
   }
-  a.edge_m = (int2*)out->edge_m; a.m_from = out->m_from; a.rel_rows = (int2*)out->rel_rows; a.rel_off = out->rel_off;
+  a.edge_m = (int2*)out->edge_m; a.m_from = out->m_from; a.m_dst = out->m_dst; a.rel_rows = (int2*)out->rel_rows; a.rel_off = out->rel_off;
   int64_t foff = 0;
   int32_t roff = 0;
   for (int b0 = 0; b0 < B; b0 += kConcatChunk) {
@@ -812,7 +822,7 @@ extern "C" int gnnrag_csr_concat(const gnnrag_csr* const* parts, int32_t B, int3
         q.edge_l[d] = (const int2*)p->edge_l[d];
         q.perm[d] = p->perm[d];
       }
-      q.edge_m = (const int2*)p->edge_m; q.m_from = p->m_from; q.rel_rows = (const int2*)p->rel_rows;
+      q.edge_m = (const int2*)p->edge_m; q.m_from = p->m_from; q.m_dst = p->m_dst; q.rel_rows = (const int2*)p->rel_rows;
       q.foff = foff; q.roff = roff; q.Fq = (int32_t)p->F; q.Rq = p->rel_total; q.b = b0 + k;
       foff += p->F;
       roff += p->rel_total;

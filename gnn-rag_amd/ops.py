@@ -327,6 +327,7 @@ class CsrPlan:
         out["rel_rows"] = self._view(self.c.rel_rows, 2 * self.rel_total, torch.int32).numpy().reshape(-1, 2)
         out["edge_m"] = self._view(self.c.edge_m, 4 * self.F, torch.int32).numpy().reshape(-1, 2)
         out["m_from"] = self._view(self.c.m_from, 2 * self.F, torch.int32).numpy()
+        out["m_dst"] = self._view(self.c.m_dst, 2 * self.F, torch.int32).numpy()
         return out
 
     def rel_rows(self) -> np.ndarray:

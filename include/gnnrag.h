@@ -90,6 +90,8 @@ typedef struct gnnrag_csr {
    * facts in ascending fact id, then direction 1's). */
   int32_t* edge_m;      /* [2F][2]                                                              */
   int32_t* m_from;      /* [2F]                                                                 */
+  int32_t* m_dst;       /* [2F]  destination node of every merged record (the streaming walk cuts the stream into
+                                 equal fact ranges and finds the row boundaries in it)                  */
 } gnnrag_csr;
 
 /* Bytes of caller-owned device memory a gnnrag_csr needs (persistent part / build scratch). */

@@ -40,11 +40,11 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_size_queries_and_struct_layout(lib):
-    assert ctypes.sizeof(_lib.CsrStruct) == 4 * 4 + 8 + 8 * 2 * 7 + 8 * 2 + 8 + 8 * 2 + 8 + 8 * 2 + 8 * 2 + 8 + 8 * 2
+    assert ctypes.sizeof(_lib.CsrStruct) == 4 * 4 + 8 + 8 * 2 * 7 + 8 * 2 + 8 + 8 * 2 + 8 + 8 * 2 + 8 * 2 + 8 + 8 * 3
     n = lib.gnnrag_csr_bytes(768000, 64, 2000, 602, 0, 0)
     # 2 row_ptr arrays + 2 x (edge 8 B + compact-relation edge 8 B + perm 4 B) per fact, plus small
     # lists + one int per node for the per-question big-node lists + (question, relation) rows
-    lo = 3 * 128001 * 4 + 768000 * 64 + 64 * 602 * 8          # (+ 24 B per fact: the merged record stream)
+    lo = 3 * 128001 * 4 + 768000 * 72 + 64 * 602 * 8          # (+ 32 B per fact: the merged record stream)
     assert lo <= n <= lo + 64 * 1024
     assert lib.gnnrag_csr_bytes(768000, 64, 2000, 602, 1, 1) >= n + 4 * 768000 * 4
     assert lib.gnnrag_csr_bytes(-1, 64, 2000, 602, 0, 0) == 0

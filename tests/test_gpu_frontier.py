@@ -126,13 +126,10 @@ def test_frontier_lists_tables_and_sums(dev, case):
     assert float(nbr_fr[~on].abs().max()) == 0.0 if (~on).any() else True
     s = max(1.0, float(nbr_full.abs().max()))
     assert float((nbr_fr - nbr_full).abs().max()) <= 4e-6 * s
-    # with the SAME table values the light rows are bit-identical (one chain in fact order in both kernels)
+    # with the SAME table values both walks add a row's live facts in position order; the streaming walk cuts the merged
+    # stream into equal fact ranges, so a row cut by a range boundary groups its sum differently: equal to rounding
     nbr_same = fr.aggregate(P_full)
-    deg = np.bincount(np.asarray(batch.edge_tuple[0]), minlength=cfg.B * cfg.N) + \
-        np.bincount(np.asarray(batch.edge_tuple[2]), minlength=cfg.B * cfg.N)
-    light = torch.from_numpy((deg <= 32) & flags.astype(bool)).to(dev)
-    if case not in ("dense_prior", "more_seeds_than_the_lds_list"):
-        assert torch.equal(nbr_same[light], nbr_full[light])
+    assert float((nbr_same - nbr_full).abs().max()) <= 2e-6 * s
 
 
 @pytest.mark.parametrize("shape", ["b3", "wres56", "ktiled_small", "wide_slices", "pos_emb_norm"])

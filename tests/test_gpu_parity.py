@@ -79,6 +79,7 @@ def test_csr_plan_bit_exact(dev, name):
     nrel = np.diff(got["rel_off"])
     em = np.zeros((2 * F, 2), np.int64)
     frm = np.zeros(2 * F, np.int64)
+    mdst = np.zeros(2 * F, np.int64)
     for d in (0, 1):
         n_of = dst[d][want["perm%d" % d]]                          # destination of every sorted position
         m = np.arange(F) + (rp1[n_of] if d == 0 else rp0[n_of + 1])
@@ -87,6 +88,8 @@ def test_csr_plan_bit_exact(dev, name):
             rec[:, 1] += nrel[n_of // cfg.N] + 1
         em[m] = rec
         frm[m] = d * F + np.arange(F)
+        mdst[m] = n_of
+    np.testing.assert_array_equal(got["m_dst"], mdst)              # destination node of every merged record
     np.testing.assert_array_equal(got["edge_m"], em)
     np.testing.assert_array_equal(got["m_from"], frm)
     assert np.array_equal(np.sort(frm), np.arange(2 * F))           # every fact of both directions exactly once
