@@ -161,9 +161,11 @@ def main():
             for t in range(cfg.T):
                 if cfg.T > 1:
                     graph._graph_in[1].copy_(g_ins[t], non_blocking=True)
-                d = graph.replay()[2][cfg.L - 1]
+                d = graph.replay(first=(t == 0))[2][cfg.L - 1]      # relation projections once per step (= per forward)
         else:
             layer.local_entity_emb = devin.h0
+            if layer._stack is not None:
+                layer._stack.new_forward()        # a step is one forward of a batch: its first iteration projects the relations
             d, _ = stack.run_layers(layer, cfg, devin)
         if distributed:
             # the all-gather of this step's distribution is enqueued behind it and waited for one step later: it

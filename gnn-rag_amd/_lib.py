@@ -123,6 +123,7 @@ ABI_VERSION = 10
 PATH_AUTO, PATH_UNFUSED, PATH_FUSED = 0, 1, 2
 PATH_ONLY_FWD, PATH_ONLY_INV = 0x10, 0x20        # OR-ed into the path: one-direction layers (NSM)
 PATH_SEED_PRIOR = 0x40                           # OR-ed into the path: the (first layer's) prior is a seed distribution
+PATH_REUSE_PROJ = 0x80                           # gnnrag_reason_stack: the workspace still holds the relation projections
 E_TUPLE = -4
 _lib = None
 

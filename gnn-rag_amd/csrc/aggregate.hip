@@ -455,7 +455,14 @@ __global__ __launch_bounds__(256) void k_heavy_reduce(const WalkArgs a, int na) 
 #define GNNRAG_SLICE_ABL 0      // timing-only ablations of k_walk_slice (wrong results): 1 no table staging loads,
 #endif                          // 2 no output stores, 8 no (p, rel) pair loads
 constexpr int kSliceW = 16;                 // floats per slice (4 lanes x float4)
-constexpr int kSliceThreads = 1024;
+#ifndef GNNRAG_SLICE_THREADS
+#define GNNRAG_SLICE_THREADS 1024     // threads per LDS-walk workgroup (two workgroups per CU either way: the table slices fill its LDS)
+#endif
+#ifndef GNNRAG_SLICE_WPE
+#define GNNRAG_SLICE_WPE 8            // waves per SIMD the register budget is cut for (1024 threads x 2 workgroups = 8: 64 VGPRs)
+#endif
+constexpr int kSliceThreads = GNNRAG_SLICE_THREADS;
+constexpr int kSliceWaves = kSliceThreads / 64;
 
 __global__ __launch_bounds__(256) void k_fact_prior(const int2* __restrict__ e0, const int2* __restrict__ e1,
                                                     const float* __restrict__ w0, const float* __restrict__ w1,
@@ -675,7 +682,7 @@ __device__ __forceinline__ float* slice_out(const WalkArgs& a, int n, int i, int
 // Two 1024-thread workgroups per CU need 8 waves per SIMD, i.e. <= 64 VGPRs: ask for it where the
 // accumulators allow (one float4 per lane in FUSED mode).
 template <int MODE, int NI>
-__global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k_walk_slice(const WalkArgs a, const int2* __restrict__ pr,
+__global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? GNNRAG_SLICE_WPE : 4)) void k_walk_slice(const WalkArgs a, const int2* __restrict__ pr,
                                                               int64_t F, int nslice, int nfull, int pl) {
   typedef SliceAcc<MODE, NI> Acc;
   constexpr int NA = Acc::n;
@@ -781,7 +788,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
       acc.zero();
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
-        slice_walk_wave<MODE, NI>(acc, prd[d], e[1 + 2 * d], e[2 + 2 * d], wave, 16, lane, Td[d], q, Rg);
+        slice_walk_wave<MODE, NI>(acc, prd[d], e[1 + 2 * d], e[2 + 2 * d], wave, kSliceWaves, lane, Td[d], q, Rg);
         if (ND == 2 || d == 1) {
           slice_wave_reduce<MODE, NI>(acc);
           if (grp == 0) {
@@ -793,7 +800,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? 8 : 4)) void k
             const int i = tid >> 2, sb = tid & 3;
             f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int w = 0; w < 16; ++w) t += *reinterpret_cast<const f32x4*>(red + (w * NA + i) * 16 + 4 * sb);
+            for (int w = 0; w < kSliceWaves; ++w) t += *reinterpret_cast<const f32x4*>(red + (w * NA + i) * 16 + 4 * sb);
             const int cc = col0 + Acc::coff(i) + 4 * sb;
             if (cc < D) *reinterpret_cast<f32x4*>(slice_out<MODE>(a, e[0], i, d, cc)) = t;
           }

@@ -30,6 +30,10 @@ bool update_rows_supported(const float* h, const float* nbr, const float* W, con
                            int32_t I, int32_t math);
 bool update_b3_shape_ok(int64_t BN, int32_t D, int32_t ldw);
 
+// frontier.hip: relation tables of small batches on the one-workgroup-per-tile, split-k kernel (exact fp32)
+int tables_small_launch(const gnnrag_csr* csr, const float* T_fwd, const float* T_inv, const float* ins, const float* W,
+                        float* P, int32_t D, int32_t I, hipStream_t stream);
+
 // frontier.hip: the frontier of a (sparse) prior; also zeroes two float ranges on the way (score buffer, zero row)
 int frontier_build_z(const gnnrag_csr* csr, const float* dist, void* fws, size_t fws_bytes, float* zero_a,
                      int64_t zero_na, float* zero_b, int64_t zero_nb, hipStream_t stream);

@@ -133,6 +133,7 @@ struct TabFrArgs {
   const int32_t* counts;      // [B][2] device: (.., listed relation rows) per question
   float* P;                   // [2, rel_total, D]
   int32_t D, I, rel_total, B;
+  int32_t dense;              // != 0: no lists - every compact row is computed, one workgroup per (16-row tile, d, cg)
 };
 
 // Work item = (question, tile of 16 listed rows, direction, 64-column group); the FOUR WAVES of a workgroup split the
@@ -148,19 +149,19 @@ __global__ __launch_bounds__(256) void k_tables_frontier(TabFrArgs a, int tiles_
   // One workgroup per (question, direction, column group) walks the question's tiles: with a seed frontier there is one
   // (a dozen listed relations); launching a workgroup per POSSIBLE tile cost more in dispatch than the work itself
   // (8192 mostly empty workgroups: 20 us at C2 against 6.6 us for one question).
-  const int nitem = a.B * 2 * ncg;
+  const int nitem = a.dense ? ((a.rel_total + 15) >> 4) * 2 * ncg : a.B * 2 * ncg;
   for (int item = blockIdx.x; item < nitem; item += gridDim.x)
-  for (int tile = 0; tile < tiles_per_q; ++tile) {
-    int r = item;
+  for (int tile = a.dense ? item / (2 * ncg) : 0; tile < (a.dense ? item / (2 * ncg) + 1 : tiles_per_q); ++tile) {
+    int r = a.dense ? item % (2 * ncg) : item;
     const int cg = r % ncg; r /= ncg;
     const int d = r & 1; r >>= 1;
-    const int g = r;
-    const int cnt = a.counts[2 * g + 1];
+    const int g = a.dense ? 0 : r;
+    const int cnt = a.dense ? a.rel_total : a.counts[2 * g + 1];
     if (tile * 16 >= cnt) break;                       // workgroup-uniform
-    const int32_t* list = a.list + a.rel_off[g];
+    const int32_t* list = a.dense ? nullptr : a.list + a.rel_off[g];
     const int c0 = cg * 64;
     const int m = tile * 16 + fr;
-    const int prow = list[m < cnt ? m : cnt - 1];
+    const int prow = a.dense ? (m < cnt ? m : cnt - 1) : list[m < cnt ? m : cnt - 1];
     const int2 br = a.rel_rows[prow];
     const float* trow = a.T[d] + (size_t)br.y * D;
     const float* qrow = a.ins + (size_t)br.x * a.I * D;
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void k_tables_frontier(TabFrArgs a, int tiles_
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int mm = tile * 16 + fg * 4 + rr;
-          if (mm < cnt && col < D) a.P[((size_t)d * a.rel_total + list[mm]) * D + col] = v[rr];
+          if (mm < cnt && col < D) a.P[((size_t)d * a.rel_total + (a.dense ? mm : list[mm])) * D + col] = v[rr];
         }
       }
     }
@@ -393,7 +394,7 @@ extern "C" int gnnrag_relation_tables_frontier(const gnnrag_csr* csr, const void
   a.rel_off = csr->rel_off;
   a.list = (const int32_t*)(base + w.trows);
   a.counts = (const int32_t*)(base + w.counts);
-  a.P = P; a.D = D; a.I = I; a.rel_total = csr->rel_total; a.B = csr->B;
+  a.P = P; a.D = D; a.I = I; a.rel_total = csr->rel_total; a.B = csr->B; a.dense = 0;
   const int tiles_per_q = (csr->rel_max + 15) / 16;             // worst case: every relation of a question listed
   const int64_t nitem = (int64_t)csr->B * 2 * ((D + 63) / 64);
   hipLaunchKernelGGL(k_tables_frontier, dim3((unsigned)(nitem < 4096 ? nitem : 4096)), dim3(256), 0, (hipStream_t)stream, a,
@@ -446,4 +447,24 @@ extern "C" int gnnrag_frontier_read(const gnnrag_csr* csr, const void* fws, int3
   }
   delete[] per_q;
   return e == hipSuccess ? 0 : (int)e;
+}
+
+// The same kernel over ALL compact rows (no frontier): the relation tables of small batches (one WebQSP question: ~600
+// rows x K = I * D = 112) - on the k-tiled generated-operand GEMM that is 11 us of launch / staging / barriers for
+// 8 MFLOP.  Exact fp32.  Returns GNNRAG_E_UNSUPPORTED outside its range (the caller takes the GEMM).
+int gnnrag::tables_small_launch(const gnnrag_csr* csr, const float* T_fwd, const float* T_inv, const float* ins,
+                                const float* W, float* P, int32_t D, int32_t I, hipStream_t stream) {
+  if (D % 4 || D > 256 || csr->rel_total <= 0) return GNNRAG_E_UNSUPPORTED;
+  if (2.0 * 2 * csr->rel_total * (double)I * D * D > 1.5e8) return GNNRAG_E_UNSUPPORTED;      // a job for the GEMM kernels
+  if ((((uintptr_t)T_fwd | (uintptr_t)T_inv | (uintptr_t)ins | (uintptr_t)W) & 15) != 0) return GNNRAG_E_UNSUPPORTED;
+  TabFrArgs a;
+  a.T[0] = T_fwd; a.T[1] = T_inv; a.ins = ins; a.W = W;
+  a.rel_rows = (const int2*)csr->rel_rows;
+  a.rel_off = csr->rel_off;
+  a.list = nullptr; a.counts = nullptr;
+  a.P = P; a.D = D; a.I = I; a.rel_total = csr->rel_total; a.B = csr->B; a.dense = 1;
+  const int nitem = ((csr->rel_total + 15) / 16) * 2 * ((D + 63) / 64);
+  hipLaunchKernelGGL(k_tables_frontier, dim3(nitem), dim3(256), 0, stream, a, 0);
+  GNNRAG_LAUNCH_CHECK();
+  return 0;
 }

@@ -39,6 +39,9 @@
 #ifndef GNNRAG_GEMM_WRES
 #define GNNRAG_GEMM_WRES 1       // short-K problems in exact fp32 run the W-resident kernel (k_gemm_wres)
 #endif
+#ifndef GNNRAG_UPDATE_SKINNY
+#define GNNRAG_UPDATE_SKINNY 1   // self-block update of small batches (< 4096 rows) on the one-wave-per-tile kernel
+#endif
 #ifndef GNNRAG_GEMM_ABL
 #define GNNRAG_GEMM_ABL 0        // timing-only ablation builds (tools/tune_variants.py): 1 no MFMA, 2 no epilogue
                                  // traffic, 4 no global loads in the k loop, 8 no LDS restaging in the k loop
@@ -877,6 +880,96 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs g) {
   }
 }
 
+// ---- the self-block update of SMALL batches (B*N < 4096: one WebQSP question, BASELINE config 1) ------------------------
+// The k-tiled kernel runs such a problem on M/64 workgroups and spends ~13 us on a 12 MFLOP product (2000 x 56 x 56):
+// staging, two barriers per 32 k, an LDS-transposed epilogue.  Here one WAVE owns a 16-row tile and ALL output columns
+// (NT <= 13 accumulator tiles), reads its A and W fragments straight from global memory (L2 resident), every load of a
+// 32-wide k step issued before the step's MFMAs, exact fp32 (v_mfma_f32_16x16x4_f32); the epilogue works in the MFMA C
+// layout (a 16-lane row holds 64 contiguous bytes of an output row) and reduces the score with DPP row operations.
+// Row gates (add_flag) as in k_gemm_wres: an unflagged row adds no `add`.
+template <int NT>
+__global__ __launch_bounds__(256) void k_update_skinny(GemmArgs g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int tile = blockIdx.x * 4 + wave;
+  const int m0 = tile * 16;
+  if (m0 >= g.M) return;
+  const int K = g.K, Nout = g.Nout;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = zero4;
+  const float* arow = g.A0 + (size_t)min(m0 + fr, g.M - 1) * g.K0;
+  const float* wrow[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) wrow[nt] = g.W + (size_t)min(nt * 16 + fr, Nout - 1) * g.ldw + g.wc0;
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    f32x4 a[2], b[2][NT];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int k = k0 + c * 16 + fg * 4;
+      const bool ok = k < K;                              // K % 4 == 0: a float4 is inside or outside as a whole
+      a[c] = ok ? *reinterpret_cast<const f32x4*>(arow + k) : zero4;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[c][nt] = ok ? *reinterpret_cast<const f32x4*>(wrow[nt] + k) : zero4;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][e], b[c][nt][e], acc[nt], 0, 0, 0);
+  }
+  // epilogue in the C layout: lane (fr, fg) holds rows m0 + 4 fg + q, column nt * 16 + fr
+  const int rbase = m0 + 4 * fg;
+  unsigned fl = 0x01010101u;
+  if (g.add_flag) fl = *reinterpret_cast<const unsigned*>(g.add_flag + rbase);      // (M + 4 bytes, rbase % 4 == 0)
+  float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = nt * 16 + fr;
+    const bool cok = col < Nout;
+    const float bia = (cok && g.bias) ? g.bias[col] : 0.f;
+    const float wsc = cok ? g.w_s[col] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = rbase + q;
+      float v = 0.f;
+      if (cok && row < g.M) {
+        float ad = 0.f;
+        if (g.add && ((fl >> (8 * q)) & 0xffu)) ad = g.add[(size_t)row * Nout + col];
+        v = fmaxf((acc[nt][q] + bia) + ad, 0.f);
+        g.C[(size_t)row * Nout + col] = v;
+      }
+      part[q] += v * wsc;
+    }
+  }
+  const float tot = row16_sum4(part, lane);
+  const int srow = rbase + row16_sum4_index(fr);
+  // fp32 on purpose: score - 1e11 rounds to exactly -1e11, as in the reference
+  if (fr < 4 && srow < g.M) g.score[srow] = (tot + g.b_s[0]) + (1.0f - g.mask[srow]) * kVeryNeg;
+}
+
+static bool update_skinny_ok(const GemmArgs& g) {
+  return g.M < 4096 && !g.A1 && g.K == g.K0 && g.K % 4 == 0 && g.Nout <= 208 && g.ldw % 4 == 0 && g.wc0 % 4 == 0 &&
+         aligned16(g.A0) && aligned16(g.W) && (!g.add || g.add_rows >= g.M) &&
+         (!g.add_flag || ((uintptr_t)g.add_flag & 3) == 0);
+}
+
+static int launch_update_skinny(const GemmArgs& g, hipStream_t stream) {
+  const int nt = (g.Nout + 15) / 16;
+  const dim3 grid((unsigned)(((g.M + 15) / 16 + 3) / 4));
+#define GNNRAG_USK(N) case N: hipLaunchKernelGGL((k_update_skinny<N>), grid, dim3(256), 0, stream, g); break;
+  switch (nt) {
+    GNNRAG_USK(1) GNNRAG_USK(2) GNNRAG_USK(3) GNNRAG_USK(4) GNNRAG_USK(5) GNNRAG_USK(6) GNNRAG_USK(7) GNNRAG_USK(8)
+    GNNRAG_USK(9) GNNRAG_USK(10) GNNRAG_USK(11) GNNRAG_USK(12) GNNRAG_USK(13)
+    default: return GNNRAG_E_UNSUPPORTED;
+  }
+#undef GNNRAG_USK
+  GNNRAG_LAUNCH_CHECK();
+  return 0;
+}
+
 static bool math_ok(int math) { return math == GNNRAG_MATH_FP32 || math == GNNRAG_MATH_BF16X3 || math == GNNRAG_MATH_MIXED; }
 
 template <int EPI, int AMODE>
@@ -983,6 +1076,7 @@ static int update_common(GemmArgs g, int64_t BN, int32_t D, hipStream_t stream, 
     const int S = (GNNRAG_GEMM_WRES && math != GNNRAG_MATH_BF16X3 && al && g.M >= 4096 &&
                    (!g.add_flag || ((uintptr_t)g.add_flag & 3) == 0)) ? wres_stride(g) : 0;
     if (S) return launch_wres<EPI_UPDATE>(g, S, stream);
+    if (GNNRAG_UPDATE_SKINNY && update_skinny_ok(g)) return launch_update_skinny(g, stream);    // small batches: exact fp32
     if (g.add_flag) return GNNRAG_E_UNSUPPORTED;      // the k-tiled kernel has no row-gated form: nothing launched
     return launch_gemm<EPI_UPDATE, AMODE_PLAIN>(g, stream, math);
   }
@@ -1052,6 +1146,7 @@ bool gnnrag::update_rows_supported(const float* h, const float* nbr, const float
   const bool al = aligned16(h) && aligned16(W) && aligned16(h_out) && aligned16(nbr) && ldw % 4 == 0;
   if (!al) return false;
   if (GNNRAG_UPDATE_B3 && math != GNNRAG_MATH_FP32 && update_b3_shape_ok(BN, D, ldw)) return true;
+  if (GNNRAG_UPDATE_SKINNY && BN < 4096 && D % 4 == 0) return true;                 // k_update_skinny
   if (!(GNNRAG_GEMM_WRES && math != GNNRAG_MATH_BF16X3 && BN >= 4096)) return false;
   GemmArgs g;
   memset(&g, 0, sizeof(g));
@@ -1091,6 +1186,10 @@ extern "C" int gnnrag_relation_tables(const gnnrag_csr* csr, const float* T_fwd,
   if (!csr || !T_fwd || !T_inv || !ins || !W || !P || D <= 0 || I <= 0 || csr->rel_total < 0 || !math_ok(math))
     return GNNRAG_E_BADARG;
   if (csr->rel_total == 0) return 0;      // no facts, no tables
+  {   // small batches (one question): one workgroup per 16-row tile, split k, exact fp32 - in every math mode
+    const int rc = tables_small_launch(csr, T_fwd, T_inv, ins, W, P, D, I, (hipStream_t)stream);
+    if (rc != GNNRAG_E_UNSUPPORTED) return rc;
+  }
   if (math == GNNRAG_MATH_MIXED) math = GNNRAG_MATH_BF16X3;
   if (math == GNNRAG_MATH_BF16X3 && GNNRAG_TABLES_WRES) {     // W-resident kernel (tables_b3.hip) where its shapes allow
     const int rc = tables_b3_launch(csr, T_fwd, T_inv, ins, W, P, D, I, (hipStream_t)stream);

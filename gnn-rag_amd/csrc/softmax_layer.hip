@@ -94,7 +94,7 @@ static bool fused_is_cheaper(int64_t B, int64_t N, int64_t rel_total, int64_t D,
 }
 
 static bool path_ok(int32_t path) {
-  const int base = path & 0xf, flags = path & ~0xf & ~GNNRAG_PATH_SEED_PRIOR;
+  const int base = path & 0xf, flags = path & ~0xf & ~GNNRAG_PATH_SEED_PRIOR & ~GNNRAG_PATH_REUSE_PROJ;
   if (base < GNNRAG_PATH_AUTO || base > GNNRAG_PATH_FUSED) return false;
   return flags == 0 || flags == GNNRAG_PATH_ONLY_FWD || flags == GNNRAG_PATH_ONLY_INV;
 }
@@ -240,6 +240,17 @@ static int rel_projections(const gnnrag_csr* csr, int32_t n, const gnnrag_layer_
   return 0;
 }
 
+// whether gnnrag_rel_transform accepted these operands (16-byte alignment): then - and only then - it wrote the planes
+static bool aligned_for_rel_transform(const float* a, const float* b, const gnnrag_layer_params* layers, int L,
+                                      int pos_rows) {
+  uintptr_t x = (uintptr_t)a | (uintptr_t)b;
+  for (int j = 0; j < L; ++j) {
+    x |= (uintptr_t)layers[j].W_rel | (uintptr_t)layers[j].b_rel;
+    if (pos_rows > 0) x |= (uintptr_t)layers[j].pos_fwd | (uintptr_t)layers[j].pos_inv;
+  }
+  return (x & 15) == 0;
+}
+
 extern "C" size_t gnnrag_stack_workspace_bytes(const gnnrag_csr* csr, int32_t L, int32_t D, int32_t I) {
   if (!csr || L <= 0 || D <= 0 || I <= 0) return 0;
   // one layer's workspace + the relation projections of all L layers (one contiguous block, computed up front)
@@ -309,7 +320,12 @@ extern "C" int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnra
   const size_t plane_bytes = tables_vq_planes_bytes(csr->R1);
   char* planes_all = base + w.total + align_up((size_t)L * 2 * RD * sizeof(float), 256);
   bool planes_written = false;
-  if (upfront) {
+  const bool reuse = upfront && (path & GNNRAG_PATH_REUSE_PROJ) != 0;
+  path &= ~GNNRAG_PATH_REUSE_PROJ;
+  if (reuse) {
+    // the previous call on this workspace left T (and the planes, where this shape writes them) in place
+    planes_written = want_planes && (D & 3) == 0 && aligned_for_rel_transform(relfeat_fwd, relfeat_inv, layers, L, pos_rows);
+  } else if (upfront) {
     const int rc = rel_projections(csr, L, layers, relfeat_fwd, relfeat_inv, pos_rows, Tall,
                                    want_planes ? planes_all : nullptr, &planes_written, D, math, stream);
     if (rc) return rc;

@@ -788,20 +788,30 @@ class LayerStack:
         # the stack-sized workspace: relation projections of all L layers up front in one launch
         nbytes = max(lib.gnnrag_stack_workspace_bytes(C.byref(plan.c), self.L, D, self.I), 256)
         self._ws_buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        self._graph = None
+        self._graph = self._graph_rest = None
         self.h = self.score = self.dist = None                   # graph mode: the fixed buffers of the captured sequence
+        # the relation projections of the L layers depend on the parameters and the relation features only: the first
+        # run of a forward computes them into the workspace, the runs of its later iterations reuse them
+        # (GNNRAG_PATH_REUSE_PROJ).  A stack is bound to one batch (the module builds a new one per batch); a caller that
+        # keeps one stack across forwards calls new_forward() at the start of each.
+        self._proj_valid = False
+
+    def new_forward(self):
+        """The next run() recomputes the relation projections (start of a new forward / batch)."""
+        self._proj_valid = False
 
     def _new_outputs(self):
         f32, dev, L, B, N, D = torch.float32, self.device, self.L, self.B, self.N, self.D
         return (torch.empty((L, B, N, D), dtype=f32, device=dev), torch.empty((L, B, N), dtype=f32, device=dev),
                 torch.empty((L, B, N), dtype=f32, device=dev))
 
-    def _args(self, h0, dist0, ins, out):
+    def _args(self, h0, dist0, ins, out, reuse=False):
         h, score, dist = out
         return (C.byref(self.plan.c), self.L, self._params, h0.data_ptr(), dist0.data_ptr(), ins.data_ptr(),
                 self._relfeat.data_ptr(), self._relfeat_inv.data_ptr(), self.pos_rows, self._ws.data_ptr(),
                 self._bs.data_ptr(), self._mask.data_ptr(), h.data_ptr(), score.data_ptr(),
-                dist.data_ptr(), self._ws_buf.data_ptr(), self._ws_buf.numel(), self.D, self.I, self.path, self.math)
+                dist.data_ptr(), self._ws_buf.data_ptr(), self._ws_buf.numel(), self.D, self.I,
+                self.path | (_lib.PATH_REUSE_PROJ if reuse else 0), self.math)
 
     def _inputs(self, h0, dist0, ins):
         h0 = _chk(h0, "local_entity_emb").reshape(self.B * self.N, self.D)
@@ -816,9 +826,11 @@ class LayerStack:
         """Runs the L layers; returns freshly allocated (h [L,B,N,D], score [L,B,N], dist [L,B,N])."""
         h0, dist0, ins = self._inputs(h0, dist0, ins)
         out = self._new_outputs()
+        reuse = self._proj_valid and self.L > 1
         with torch.cuda.device(h0.device):
-            _lib.check(_lib.load().gnnrag_reason_stack(*self._args(h0, dist0, ins, out), _stream()),
+            _lib.check(_lib.load().gnnrag_reason_stack(*self._args(h0, dist0, ins, out, reuse), _stream()),
                        "gnnrag_reason_stack")
+        self._proj_valid = True
         return out
 
     def capture(self, h0, dist0, ins):
@@ -833,7 +845,7 @@ class LayerStack:
         self.h, self.score, self.dist = self._new_outputs()
         self.h[self.L - 1].copy_(h0.reshape(self.B, self.N, self.D))
         h0g, dist0, ins = self._inputs(self.h[self.L - 1], dist0, ins)
-        g = C.c_void_p()
+        g, g2 = C.c_void_p(), C.c_void_p()
         with torch.cuda.device(h0g.device):
             # stream capture is not allowed on the legacy default stream (torch's default): capture on a side stream
             side = torch.cuda.Stream()
@@ -842,20 +854,30 @@ class LayerStack:
                 _lib.check(_lib.load().gnnrag_reason_stack_capture(
                     *self._args(h0g, dist0, ins, (self.h, self.score, self.dist)), _stream(), C.byref(g)),
                     "gnnrag_reason_stack_capture")
+                # second graph: the same sequence WITHOUT the relation projections - the iterations 2..T of a forward
+                # (the eager run every capture needs left them in the workspace; every replay of the first graph
+                # rewrites them)
+                _lib.check(_lib.load().gnnrag_reason_stack_capture(
+                    *self._args(h0g, dist0, ins, (self.h, self.score, self.dist), reuse=True), _stream(), C.byref(g2)),
+                    "gnnrag_reason_stack_capture")
             torch.cuda.current_stream().wait_stream(side)
-        self._graph, self._graph_in = g, (dist0, ins)
+        self._graph, self._graph_rest, self._graph_in = g, g2, (dist0, ins)
 
-    def replay(self):
+    def replay(self, first: bool = True):
+        """Replays the captured sequence.  ``first=False``: the graph without the relation-projection launch (the later
+        iterations of a forward; the first one's replay left the projections in the workspace)."""
         if self._graph is None:
             raise RuntimeError("capture() first")
         with torch.cuda.device(self.device):
-            _lib.check(_lib.load().gnnrag_graph_launch(self._graph, _stream()), "gnnrag_graph_launch")
+            _lib.check(_lib.load().gnnrag_graph_launch(self._graph if first or self.L < 2 else self._graph_rest, _stream()),
+                       "gnnrag_graph_launch")
         return self.h, self.score, self.dist
 
     def release_graph(self):
-        if self._graph is not None:
-            _lib.load().gnnrag_graph_destroy(self._graph)
-            self._graph = None
+        for name in ("_graph", "_graph_rest"):
+            if getattr(self, name, None) is not None:
+                _lib.load().gnnrag_graph_destroy(getattr(self, name))
+                setattr(self, name, None)
 
     def __del__(self):
         try:

@@ -309,6 +309,12 @@ int gnnrag_update_score_fused(const float* h, const float* nbr, const float* W_e
  * the flag (to rounding of the relation-table products), a dense one slowly.  Needs D % 4 == 0, D <= 256, both
  * directions, the fused path; ignored otherwise. */
 #define GNNRAG_PATH_SEED_PRIOR 0x40
+/* OR-ed into `path` of gnnrag_reason_stack (with a gnnrag_stack_workspace_bytes workspace): the workspace still holds
+ * the relation projections (and their bf16 planes) that an EARLIER gnnrag_reason_stack call on the same workspace
+ * computed for the same layers' parameters and the same relation features - they depend on nothing else
+ * (reasongnn.py:75-79: rel_linear{j}(rel_features)), so the iterations 2..T of one ReaRev forward skip that launch.
+ * The caller vouches for "same parameters, same relation features, workspace untouched in between". */
+#define GNNRAG_PATH_REUSE_PROJ 0x80
 size_t gnnrag_layer_workspace_bytes(const gnnrag_csr* csr, int32_t D, int32_t I);
 int gnnrag_reason_layer(const gnnrag_csr* csr,
                         const float* h, const float* dist, const float* ins,

@@ -826,7 +826,7 @@ def test_whole_iteration_call_and_graph_replay_are_bit_identical(dev, cfgname):
         c = 0
         for t in range(cfg.T):
             ins_buf.copy_(pad(devin.ins[t]))
-            h, score, dist = st.replay()
+            h, score, dist = st.replay(first=(t == 0))      # iterations 2..T: the graph without the relation projections
             for j in range(cfg.L):
                 assert np.array_equal(h[j][..., :D].cpu().numpy(), outs["per_layer"]["h"][c])
                 assert (h[j][..., D:] == 0).all()                                 # padded columns stay exactly zero

@@ -42,6 +42,11 @@ VARIANTS = {
     "sl_g4": {"GNNRAG_SLICE_BL_GROUP": 4},
     "sl_nostage": {"GNNRAG_SLICE_ABL": 1}, "sl_nostore": {"GNNRAG_SLICE_ABL": 2},
     "sl_nopairs": {"GNNRAG_SLICE_ABL": 8}, "sl_nomem": {"GNNRAG_SLICE_ABL": 11},
+    # LDS walk with 512-thread workgroups (still two per CU: 4 waves per SIMD, 128 VGPRs) and 1 / 2 / 4 table rows in flight
+    "sl_t512_g1": {"GNNRAG_SLICE_THREADS": 512, "GNNRAG_SLICE_WPE": 4, "GNNRAG_SLICE_BL_GROUP": 1},
+    "sl_t512_g2": {"GNNRAG_SLICE_THREADS": 512, "GNNRAG_SLICE_WPE": 4, "GNNRAG_SLICE_BL_GROUP": 2},
+    "sl_t512_g4": {"GNNRAG_SLICE_THREADS": 512, "GNNRAG_SLICE_WPE": 4, "GNNRAG_SLICE_BL_GROUP": 4},
+    "sl_t1024_w4_g4": {"GNNRAG_SLICE_WPE": 4, "GNNRAG_SLICE_BL_GROUP": 4},
     "vq_nolds": {"GNNRAG_VQ_ABL": 1}, "vq_noa": {"GNNRAG_VQ_ABL": 2}, "vq_nostage": {"GNNRAG_VQ_ABL": 4},
     "upd_nolds": {"GNNRAG_UPD_ABL": 1}, "upd_noa": {"GNNRAG_UPD_ABL": 2}, "upd_noadd": {"GNNRAG_UPD_ABL": 4},
     "upd_nostore": {"GNNRAG_UPD_ABL": 8}, "upd_nosplit": {"GNNRAG_UPD_ABL": 16}, "upd_mfma_only": {"GNNRAG_UPD_ABL": 31},
