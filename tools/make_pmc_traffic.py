@@ -40,7 +40,7 @@ def main(fetch_db, write_db, out, workload="C2"):
         commit = subprocess.run(["git", "-C", repo, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     except Exception:
         commit = ""
-    res = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on tools/prof_ops.py (%s, dense and seed priors alternate)" % workload,
+    res = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on tools/prof_ops.py --ops agg,aggfd,fr (%s; fused walk: dense-prior launches only; unfused walk: dense and seed priors alternate)" % workload,
            "workload": workload, "commit": commit or os.environ.get("GNNRAG_COMMIT", "unknown (no .git on the GPU box)"),
            "kernel_sources_sha256": bench.kernel_sources_digest(),
            "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests at 64 B)"}
@@ -48,6 +48,9 @@ def main(fetch_db, write_db, out, workload="C2"):
                  or ("k_heavy" in k and "ILi2E" in k))
     res.update(aggregate_fused_fetch_bytes_raw=f, aggregate_fused_write_bytes=w,
                aggregate_fused_hbm_bytes_per_launch=2 * f + w)
+    # the seed-prior (frontier) form of layer 0: frontier + table rows + neighbour sums of the frontier
+    f, w = group(lambda k: "k_frontier_build" in k or "k_tables_frontier" in k or "k_walk_frontier" in k)
+    res.update(frontier_fetch_bytes_raw=f, frontier_write_bytes=w, frontier_hbm_bytes_per_launch=2 * f + w)
     f, w = group(lambda k: ("k_walk_light" in k or "k_heavy" in k) and "ILi0E" in k)
     res.update(aggregate_fetch_bytes_raw=f, aggregate_write_bytes=w, aggregate_hbm_bytes_per_launch=2 * f + w)
     res["per_kernel_fetch_KB"] = {k[:60]: v for k, v in fetch.items() if "gnnrag" in k}

@@ -53,6 +53,9 @@ def main():
                     ops.masked_softmax(sc, B, N)
             if "tab" in which:
                 P = ops.relation_tables(layer.plan, Tf, Ti, devin.ins[0], e2e.weight)
+            if "aggfd" in which:                                                # fused walk, dense prior only (what a step runs)
+                Pd = ops.relation_tables(layer.plan, Tf, Ti, devin.ins[0], e2e.weight)
+                ops.aggregate_fused(layer.plan, dist1, Pd)
             if "aggf" in which:
                 P = ops.relation_tables(layer.plan, Tf, Ti, devin.ins[0], e2e.weight) if "tab" not in which else P
                 nbr = ops.aggregate_fused(layer.plan, dist1, P)                 # dense prior
