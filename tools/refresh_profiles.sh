@@ -20,7 +20,7 @@ cp $OUT/pmc_traffic_C2.json $R/profiles/pmc_traffic.json        # the default be
 cd $R
 python bench.py > $OUT/bench_default.log 2>&1
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python $R/bench.py --no-cpu-baseline --spread-steps 0 > $OUT/bench_under_rocprof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python $R/bench.py --no-cpu-baseline --spread-steps 0 --clock-ramp-ms 0 > $OUT/bench_under_rocprof.log 2>&1
 cd $R
 python tools/rocpd_stats.py $(find $OUT/trace -name 'bench_results.db' | head -1) > $OUT/kernel_stats_bench.txt 2>&1
 for W in C1 C3 C4 C5 C2fb C2u; do
@@ -32,7 +32,7 @@ for W in C1 C3; do
   python bench.py --workload $W --no-cpu-baseline --steps 30 --launch graph > $OUT/bench_${W}_graph.log 2>&1
 done
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_C5 -o bench -- python $R/bench.py --workload C5 --no-cpu-baseline --steps 10 --spread-steps 0 > $OUT/bench_C5_under_rocprof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_C5 -o bench -- python $R/bench.py --workload C5 --no-cpu-baseline --steps 10 --spread-steps 0 --clock-ramp-ms 0 > $OUT/bench_C5_under_rocprof.log 2>&1
 cd $R
 python tools/rocpd_stats.py $(find $OUT/trace_C5 -name 'bench_results.db' | head -1) > $OUT/kernel_stats_bench_C5.txt 2>&1
 find $OUT -name '*.db' -delete
