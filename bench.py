@@ -692,7 +692,81 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
     return out
 
 
+def reference_cpu_leg(cfg, sample_b):
+    """The REAL reference layer (`ReasonGNNLayer` from the sources staged into the git-ignored oracle/_ref/gnn by
+    oracle/stage_ref.py - /root/reference itself does not exist on the GPU box) on the host cores, on a bounded sample:
+    sample_b questions of the same shape, same parameters, eval mode, no_grad; `build_matrix` timed separately.
+    Returns None when the staged sources are absent."""
+    ref = os.path.join(REPO, "oracle", "_ref", "gnn")
+    if not os.path.isfile(os.path.join(ref, "modules", "kg_reasoning", "reasongnn.py")):
+        return None
+    from gnnrag_amd import synth
+    sys.path.insert(0, ref)
+    try:
+        from modules.kg_reasoning.reasongnn import ReasonGNNLayer as RefLayer
+    finally:
+        sys.path.remove(ref)
+    sub = synth.GraphConfig(**{**cfg.__dict__, "B": sample_b, "name": cfg.name + "-cpu-sample"})
+    batch, feats, params = synth.make_batch(sub), synth.make_features(sub), synth.make_layer_params(sub)
+    args = dict(use_cuda=False, normalized_gnn=sub.normalized_gnn, num_ins=sub.I, num_gnn=sub.L, pos_emb=sub.pos_emb,
+                linear_dropout=0.0)
+    layer = RefLayer(args, batch.num_entity, sub.num_kb_relation, sub.D, "bfs")
+    layer.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in params.items() if not k.startswith("type_layer.")})
+    layer.eval()
+    tens = dict(local_entity=torch.from_numpy(batch.local_entity), local_entity_emb=torch.from_numpy(feats["h0"]),
+                rel_features=torch.from_numpy(feats["rel_features"]), rel_features_inv=torch.from_numpy(feats["rel_features_inv"]),
+                query_entities=torch.from_numpy(batch.query_entities).float())
+    seed = torch.from_numpy(batch.seed_dist).float()
+    ins = torch.from_numpy(feats["ins"][0])
+    import warnings
+
+    def one_pass():
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            t0 = time.perf_counter()
+            layer.init_reason(kb_adj_mat=batch.edge_tuple, **tens)       # build_matrix (base_gnn.py:19-51)
+            t1 = time.perf_counter()
+            dist = seed
+            for j in range(sub.L):
+                dist, _ = layer(dist, ins, step=j)
+            return t1 - t0, time.perf_counter() - t1
+
+    ncpu = os.cpu_count() or 1
+    best = None
+    for nt in sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu}):
+        torch.set_num_threads(nt)
+        _, dt = one_pass()
+        if best is None or dt < best[0]:
+            best = (dt, nt)
+    torch.set_num_threads(best[1])
+    runs = [one_pass() for _ in range(2)]
+    t = float(np.median([r[1] for r in runs]))
+    return {"value": sub.B * sub.E * sub.L / t, "unit": "typed-edge*layers/s", "cores": best[1], "kind": "reference",
+            "sample": "%d questions of the same %s shape (N=%d, E=%d, D=%d, I=%d, L=%d) through the reference's own "
+                      "ReasonGNNLayer (sources staged by oracle/stage_ref.py), torch CPU, thread count chosen by a probe, "
+                      "2 timed passes, median %.2f s/pass; build_matrix %.2f s per batch on top"
+                      % (sub.B, cfg.name, sub.N, sub.E, sub.D, sub.I, sub.L, t, float(np.median([r[0] for r in runs]))),
+            "seconds_per_pass": t, "build_matrix_seconds": float(np.median([r[0] for r in runs]))}
+
+
 def cpu_baseline_leg(cfg, sample_b):
+    """The reference's CPU path on a bounded sample of the same workload: the REAL reference layer when its sources were
+    staged (kind "reference"), with the torch-CPU restatement (oracle/rearev_torch_cpu.py, kind "port") timed beside it;
+    only the port when they were not."""
+    out = port_cpu_leg(cfg, sample_b)
+    try:
+        ref = reference_cpu_leg(cfg, sample_b)
+    except Exception as e:                       # the staged reference is test infrastructure: never fail the bench on it
+        ref = None
+        out["reference_error"] = repr(e)[:300]
+    if ref is not None:
+        ref["port"] = {k: out[k] for k in ("value", "cores", "seconds_per_pass", "sample")}
+        ref["live_reference_survey"] = out["live_reference_survey"]
+        return ref
+    return out
+
+
+def port_cpu_leg(cfg, sample_b):
     """The reference's CPU op sequence (oracle/rearev_torch_cpu.py, a port: /root/reference is not
     on the GPU box) on a bounded sample of the same workload: sample_b questions of the same
     shape, all host cores, 1 warm-up + 2 timed L-layer passes."""
