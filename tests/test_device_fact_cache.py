@@ -132,3 +132,16 @@ def test_batch_structure_as_concatenation_of_cached_question_structures(shape):
             outs.append(ops.aggregate_fused(pl, dist, P))
         assert torch.equal(outs[0], outs[1])
     assert len(devc._plans) == len({i for ids in batches for i in ids})      # every question sorted once
+    # a rank's shard of a structure-cache batch (shard.shard_edge_tuple -> BatchFacts.shard): the questions' structures
+    # and, lazily, the re-based id block
+    from gnnrag_amd import shard
+    ids = batches[0]
+    a, b = host.batch(ids), devc.batch(ids)
+    lo, hi = 1, len(ids)
+    sa, sb = shard.shard_edge_tuple(a, N, lo, hi), shard.shard_edge_tuple(b, N, lo, hi)
+    pa = ops.CsrPlan(sa[0], sa[1], sa[2], hi - lo, N, R1, dev).to_host()
+    pb = ops.CsrPlan.concat(sb.plans, N, R1, dev).to_host()
+    for k in pa:
+        if k != "big":
+            np.testing.assert_array_equal(pa[k], pb[k], err_msg="shard " + k)
+    np.testing.assert_array_equal(sb.hrt_device.cpu().numpy(), np.stack([sa[0], sa[1], sa[2]]))
