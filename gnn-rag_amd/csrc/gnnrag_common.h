@@ -62,10 +62,35 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #if defined(__HIPCC__)
-// bf16 planes of 4 consecutive fp32 values (truncation split: x = hi + mid + lo EXACTLY - hi keeps the
-// top 8 significand bits, the remainder x - hi is exact in fp32 and has <= 16 bits, and so on)
+// bf16 planes of 4 consecutive fp32 values: x = hi + mid + lo EXACTLY (for finite x below the bf16 overflow threshold).
+// Round-to-nearest split on the hardware converter (round 3): hi = bf16(x) (v_cvt_pk_bf16_f32, two values per
+// instruction, already packed), r = x - hi is exact in fp32 (at most 16 significant bits; |r| <= ulp(hi) / 2), mid =
+// bf16(r), r - mid is exact with at most 8 significant bits (round-to-nearest remainders shrink by half an ulp each
+// time, the sign carries the spare bit), lo = bf16(r - mid) is exact.  18 VALU per 4 values; the truncation split
+// (mask, subtract, mask, subtract, shift / or packing) needed 26.
 struct Split3 { uint2 hi, mid, lo; };
+#ifndef GNNRAG_SPLIT_RN
+#define GNNRAG_SPLIT_RN 1
+#endif
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16_rn(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2_t));
+}
 __device__ __forceinline__ Split3 split3(f32x4 x) {
+#if GNNRAG_SPLIT_RN
+  Split3 s;
+  const unsigned h01 = pack_bf16_rn(x[0], x[1]), h23 = pack_bf16_rn(x[2], x[3]);
+  const float r0 = x[0] - __uint_as_float(h01 << 16), r1 = x[1] - __uint_as_float(h01 & 0xffff0000u);
+  const float r2 = x[2] - __uint_as_float(h23 << 16), r3 = x[3] - __uint_as_float(h23 & 0xffff0000u);
+  const unsigned m01 = pack_bf16_rn(r0, r1), m23 = pack_bf16_rn(r2, r3);
+  const float q0 = r0 - __uint_as_float(m01 << 16), q1 = r1 - __uint_as_float(m01 & 0xffff0000u);
+  const float q2 = r2 - __uint_as_float(m23 << 16), q3 = r3 - __uint_as_float(m23 & 0xffff0000u);
+  s.hi = make_uint2(h01, h23);
+  s.mid = make_uint2(m01, m23);
+  s.lo = make_uint2(pack_bf16_rn(q0, q1), pack_bf16_rn(q2, q3));
+  return s;
+#else
+  // truncation split: hi keeps the top 8 significand bits, the remainder x - hi is exact in fp32 and has <= 16 bits ...
   unsigned h[4], m[4], l[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -81,6 +106,7 @@ __device__ __forceinline__ Split3 split3(f32x4 x) {
   s.mid = make_uint2((m[0] >> 16) | m[1], (m[2] >> 16) | m[3]);
   s.lo = make_uint2((l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u));
   return s;
+#endif
 }
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
