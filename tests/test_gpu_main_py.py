@@ -50,7 +50,11 @@ def _run_main_py(tmp_path, extra_env):
             "--entity_dim", "50", "--kg_dim", "25", "--num_iter", "3", "--num_ins", "2", "--num_gnn", "3",
             "--batch_size", "16", "--test_batch_size", "16", "--name", "synth",
             "--is_eval", "--load_experiment", "synth-final.ckpt", "--checkpoint_dir", ck, "--experiment_name", "gpu"]
-    env = dict(os.environ, GNNRAG_DEVICE_FACTS="1", **extra_env)
+    import socket
+    with socket.socket() as sk:                       # a free rendezvous port for the forced process group
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, GNNRAG_DEVICE_FACTS="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **extra_env)
     r = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=600)
     log = r.stdout + r.stderr
     assert r.returncode == 0, log[-4000:]
