@@ -514,10 +514,13 @@ constexpr int kSliceBigCap = 72;    // big nodes of one question kept in LDS; a 
 struct SetRows {
   int beg[2], len[2];
   int2 first[2][2];
+  int2 second[2];     // merged rows: the pairs 8..15 of the node's run, requested with the first ones (a set ahead)
   int n;
   bool valid, big;
 };
 
+// MG (compile time): merged rows - direction 1's members are constants, the compiler drops them
+template <bool MG>
 __device__ __forceinline__ void set_load_rows(SetRows& s, const WalkArgs& a, int g, int set, int nsets, int grp) {
   const int nl = set * 16 + grp;
   s.valid = set < nsets && nl < a.N;
@@ -533,7 +536,7 @@ __device__ __forceinline__ void set_load_rows(SetRows& s, const WalkArgs& a, int
       s.big |= s.len[d] > a.big_deg;
     }
   }
-  if (a.merged) {           // both directions as one run: [rp0[n] + rp1[n], rp0[n+1] + rp1[n+1])
+  if (MG) {                 // both directions as one run: [rp0[n] + rp1[n], rp0[n+1] + rp1[n+1])
     s.beg[0] += s.beg[1];
     s.len[0] += s.len[1];
     s.beg[1] = 0;
@@ -541,14 +544,24 @@ __device__ __forceinline__ void set_load_rows(SetRows& s, const WalkArgs& a, int
   }
 }
 
+template <bool MG>
 __device__ __forceinline__ void set_load_first(SetRows& s, const int2* const (&prd)[2], int sub, int zr) {
 #pragma unroll
-  for (int d = 0; d < 2; ++d)
+  for (int d = 0; d < (MG ? 1 : 2); ++d)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
       s.first[d][h] = (s.valid && !s.big && 4 * h + sub < s.len[d])
                           ? ((GNNRAG_SLICE_ABL & 8) ? make_int2(0x3f800000, sub) : prd[d][s.beg[d] + 4 * h + sub])
                           : make_int2(0, zr);          // no fact: prior 0, the table's zero row
+  if (MG) {
+    // a merged run holds ~12 records on average: nearly every 16-node set has a node with more than 8, and the second
+    // step's pairs, requested only when the first step starts, arrived after ~60 instructions of cover - a stall per set
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      s.second[h] = (s.valid && !s.big && 8 + 4 * h + sub < s.len[0]) ? prd[0][s.beg[0] + 8 + 4 * h + sub] : make_int2(0, zr);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) s.first[1][h] = make_int2(0, zr);
+  }
 }
 
 // value of lane k of this lane's quad (DPP quad_perm broadcast: VALU speed, no LDS crossbar)
@@ -681,7 +694,7 @@ __device__ __forceinline__ float* slice_out(const WalkArgs& a, int n, int i, int
 
 // Two 1024-thread workgroups per CU need 8 waves per SIMD, i.e. <= 64 VGPRs: ask for it where the
 // accumulators allow (one float4 per lane in FUSED mode).
-template <int MODE, int NI>
+template <int MODE, int NI, bool MG>
 __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? GNNRAG_SLICE_WPE : 4)) void k_walk_slice(const WalkArgs a, const int2* __restrict__ pr,
                                                               int64_t F, int nslice, int nfull, int pl) {
   typedef SliceAcc<MODE, NI> Acc;
@@ -745,15 +758,31 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? GNNRAG_SLICE_W
   // stage the two table slices (float4 granules; rows are D*4 bytes apart).  FUSED: the question's own
   // tables P[d, g]; REASON: the shared tables T_d
   constexpr int GR = SW / 4;                           // float4 granules per staged row
-  for (int idx = tid; idx < 2 * Rg * GR; idx += kSliceThreads) {
-    const int d = idx >= Rg * GR;
-    if (a.skip_dir == d + 1) continue;                 // (a direction that is not walked is never read)
-    const int rem = idx - d * (Rg * GR);
-    const int r = rem / GR, k = rem % GR;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    const float* tab = a.T[d] + (size_t)roff * D;
-    if (!(GNNRAG_SLICE_ABL & 1) && col0 + 4 * k < D) v = *reinterpret_cast<const f32x4*>(tab + (size_t)r * D + col0 + 4 * k);
-    *reinterpret_cast<f32x4*>(Ts + ((size_t)d * (Rg + 1) + r) * SW + 4 * k) = v;
+  // five granules per thread requested before the first is written (one chunk covers 602 relations x 16 columns: the
+  // loop used to be load -> LDS write -> load ..., five dependent round trips to L2 / HBM in front of the walk)
+  {
+    constexpr int UN = 5;
+    const int total = 2 * Rg * GR;
+    for (int base = 0; base < total; base += kSliceThreads * UN) {
+      f32x4 v[UN];
+      int dst[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int idx = base + u * kSliceThreads + tid;
+        const int idc = idx < total ? idx : total - 1;
+        const int d = idc >= Rg * GR;
+        const int rem = idc - d * (Rg * GR);
+        const int r = rem / GR, k = rem % GR;
+        const bool live = idx < total && a.skip_dir != d + 1;      // (a direction that is not walked is never read)
+        dst[u] = live ? (int)(((size_t)d * (Rg + 1) + r) * SW + 4 * k) : -1;
+        v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* tab = a.T[d] + (size_t)roff * D;
+        if (live && !(GNNRAG_SLICE_ABL & 1) && col0 + 4 * k < D) v[u] = *reinterpret_cast<const f32x4*>(tab + (size_t)r * D + col0 + 4 * k);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+        if (dst[u] >= 0) *reinterpret_cast<f32x4*>(Ts + dst[u]) = v[u];
+    }
   }
   if (tid < 2 * GR) {                                  // the zero row of each direction (slots without a fact point at it)
     const int d = tid / GR, k = tid % GR;
@@ -846,27 +875,39 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? GNNRAG_SLICE_W
   };
   SetRows s0, s1, s2;
   int t0 = next_set();
-  set_load_rows(s0, a, g, t0, nsets, grp);
+  set_load_rows<MG>(s0, a, g, t0, nsets, grp);
   int t1 = t0 < nsets ? next_set() : nsets;
-  set_load_rows(s1, a, g, t1, nsets, grp);
-  set_load_first(s0, prd, sub, Rg);
+  set_load_rows<MG>(s1, a, g, t1, nsets, grp);
+  set_load_first<MG>(s0, prd, sub, Rg);
   while (t0 < nsets) {
     const int t2 = t1 < nsets ? next_set() : nsets;
-    set_load_rows(s2, a, g, t2, nsets, grp);
-    set_load_first(s1, prd, sub, Rg);
+    set_load_rows<MG>(s2, a, g, t2, nsets, grp);
+    set_load_first<MG>(s1, prd, sub, Rg);
 
     if (s0.valid && s0.big && nlist == 0) {     // no list for this question: the owner group walks it
       s0.big = false;
-      set_load_first(s0, prd, sub, Rg);
+      set_load_first<MG>(s0, prd, sub, Rg);
     }
     if (s0.valid && !s0.big) {
       Acc acc;
       acc.zero();
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
+        if (MG && d == 1) continue;             // merged rows: one run per node
         const int beg = s0.beg[d], len = s0.len[d];
         int2 c0 = s0.first[d][0], c1 = s0.first[d][1];
-        for (int j = 0; j < len; j += 8) {
+        int j = 0;
+        if (MG) {
+          // first step peeled: its successor's pairs are already here (set_load_first requested them a set ago)
+          if (len > 0) {
+            slice_fma4<MODE, NI>(acc, c0, Td[d], q);
+            if (!GNNRAG_SLICE_HALFSTEP || __ballot(4 < len)) slice_fma4<MODE, NI>(acc, c1, Td[d], q);
+          }
+          c0 = s0.second[0];
+          c1 = s0.second[1];
+          j = 8;
+        }
+        for (; j < len; j += 8) {
           int2 n0 = make_int2(0, Rg), n1 = make_int2(0, Rg);
           if (!(GNNRAG_SLICE_ABL & 8) && j + 8 + sub < len) n0 = prd[d][beg + j + 8 + sub];
           if (!(GNNRAG_SLICE_ABL & 8) && j + 12 + sub < len) n1 = prd[d][beg + j + 12 + sub];
@@ -877,7 +918,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? GNNRAG_SLICE_W
           c0 = n0;
           c1 = n1;
         }
-        if (ND == 2 || d == 1) {
+        if (ND == 2 || d == 1 || MG) {
 #pragma unroll
           for (int i = 0; i < NA; ++i)
             if (col_ok[i] && (!(GNNRAG_SLICE_ABL & 2) || acc.v[i][0] == 1234.5f))
@@ -1276,8 +1317,13 @@ static int launch_slice(const WalkArgs& a, const gnnrag_csr* csr, void* workspac
   const size_t lds = slice_lds_bytes(a.R1, SliceAcc<MODE, NI>::n, SW);
   static DeviceMask cap_raised;    // per kernel instantiation, per device
   {
-    const int rc = raise_lds_cap(k_walk_slice<MODE, NI>, cap_raised);
+    const int rc = raise_lds_cap(k_walk_slice<MODE, NI, false>, cap_raised);
     if (rc) return rc;
+    if constexpr (MODE == MODE_FUSED) {
+      static DeviceMask cap_raised_m;
+      const int rc2 = raise_lds_cap(k_walk_slice<MODE, NI, true>, cap_raised_m);
+      if (rc2) return rc2;
+    }
   }
   // per XCD: items = (questions of the XCD) x slices, slots = 2 workgroups on each of its CUs
   int cus = 0;
@@ -1311,8 +1357,14 @@ static int launch_slice(const WalkArgs& a, const gnnrag_csr* csr, void* workspac
       return 0;
     }
   }
-  hipLaunchKernelGGL((k_walk_slice<MODE, NI>), dim3(nblk), dim3(kSliceThreads), lds, stream, a, (const int2*)pr, F,
-                     nslice, nfull, pl);
+  if (MODE == MODE_FUSED && a.merged) {
+    if constexpr (MODE == MODE_FUSED)
+      hipLaunchKernelGGL((k_walk_slice<MODE, NI, true>), dim3(nblk), dim3(kSliceThreads), lds, stream, a, (const int2*)pr, F,
+                         nslice, nfull, pl);
+  } else {
+    hipLaunchKernelGGL((k_walk_slice<MODE, NI, false>), dim3(nblk), dim3(kSliceThreads), lds, stream, a, (const int2*)pr, F,
+                       nslice, nfull, pl);
+  }
   GNNRAG_LAUNCH_CHECK();
   return 0;   // hubs were walked inside the kernel, nothing to add afterwards
 }
