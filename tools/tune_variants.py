@@ -47,6 +47,7 @@ VARIANTS = {
     "sl_t512_g2": {"GNNRAG_SLICE_THREADS": 512, "GNNRAG_SLICE_WPE": 4, "GNNRAG_SLICE_BL_GROUP": 2},
     "sl_t512_g4": {"GNNRAG_SLICE_THREADS": 512, "GNNRAG_SLICE_WPE": 4, "GNNRAG_SLICE_BL_GROUP": 4},
     "sl_t1024_w4_g4": {"GNNRAG_SLICE_WPE": 4, "GNNRAG_SLICE_BL_GROUP": 4},
+    "vq_un4": {"GNNRAG_VQ_UN": 4}, "vq_un5": {"GNNRAG_VQ_UN": 5}, "vq_un6": {"GNNRAG_VQ_UN": 6},
     "split_trunc": {"GNNRAG_SPLIT_RN": 0},      # the truncation form of the exact 3-way bf16 split (rounds 1-2)
     "vq_nolds": {"GNNRAG_VQ_ABL": 1}, "vq_noa": {"GNNRAG_VQ_ABL": 2}, "vq_nostage": {"GNNRAG_VQ_ABL": 4},
     "upd_nolds": {"GNNRAG_UPD_ABL": 1}, "upd_noa": {"GNNRAG_UPD_ABL": 2}, "upd_noadd": {"GNNRAG_UPD_ABL": 4},
