@@ -42,6 +42,9 @@
                                  // (4 per node and slice) lose to the gather walk's full 3200-byte rows, so it is off
 #endif
 
+#ifndef GNNRAG_LIGHT_ABL
+#define GNNRAG_LIGHT_ABL 0        // timing-only ablations of the gather walk (results wrong on purpose): 1 no table
+#endif                            // gathers, 2 no output stores, 4 all gathers from table rows 0..63 (L2 hits)
 #ifndef GNNRAG_SLICE_WIDE
 #define GNNRAG_SLICE_WIDE 1         // LDS walk: 32-column slices for questions whose tables allow two of them per CU
 #endif
@@ -79,6 +82,12 @@ __device__ __forceinline__ typename VecT<VEC>::type vzero() {
   typename VecT<VEC>::type z = {};
   return z;
 }
+__device__ __forceinline__ float vsplat1(float x, float) { return x; }
+__device__ __forceinline__ f32x2 vsplat1(float x, f32x2) { return (f32x2){x, x}; }
+__device__ __forceinline__ f32x4 vsplat1(float x, f32x4) { return (f32x4){x, x, x, x}; }
+__device__ __forceinline__ float vfirst(float x) { return x; }
+__device__ __forceinline__ float vfirst(f32x2 x) { return x[0]; }
+__device__ __forceinline__ float vfirst(f32x4 x) { return x[0]; }
 __device__ __forceinline__ float vrelu(float x) { return fmaxf(x, 0.f); }
 __device__ __forceinline__ f32x2 vrelu(f32x2 x) { return __builtin_elementwise_max(x, (f32x2){0.f, 0.f}); }
 __device__ __forceinline__ f32x4 vrelu(f32x4 x) {
@@ -148,28 +157,42 @@ __device__ __forceinline__ void consume_batch(float p, int r, int cnt, const flo
   constexpr int U = (CPL == 1) ? 8 : (CPL == 2) ? 4 : 2;   // table rows in flight per wave
   if constexpr (LPN == 64) {
     // one node per wave: (p, rel) of a fact are wave-uniform -> scalar control flow
+    // The kernel is bound by the CU's vector-memory path (64 B / clk: an 800-byte table row is ~13 clocks of it, hit or
+    // miss - GNNRAG_LIGHT_ABL: all rows from L2-resident lines saves 10 %, no row loads 50 %), so a slot of the last,
+    // partial round must not load anything: its load is skipped by a scalar branch, not fed a duplicate row.
     unsigned long long live = __ballot(p != 0.f);
     while (live) {
       float pj[U];
       int rj[U];
+      bool lv[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
+        lv[u] = live != 0;
         if (live) {
           const int j = __builtin_ctzll(live);
           live &= live - 1;
           pj[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), j));
           rj[u] = __builtin_amdgcn_readlane(r, j);
+          if (GNNRAG_LIGHT_ABL & 4) rj[u] &= 63;
         } else {
-          pj[u] = 0.f;          // padding: +0 * f(row rj[0]) leaves the sum unchanged
-          rj[u] = rj[0];
+          pj[u] = 0.f;          // padding: +0 * 0 leaves the sum unchanged
+          rj[u] = 0;
         }
       }
       V t[U][CPL];
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int m = 0; m < CPL; ++m)
-          t[u][m] = cv[m] ? vload<VEC>(T + (size_t)rj[u] * D + col[m]) : vzero<VEC>();
+        for (int m = 0; m < CPL; ++m) {
+          if (GNNRAG_LIGHT_ABL & 1) {
+            t[u][m] = vsplat1(__int_as_float(rj[u]), V());
+          } else {
+            t[u][m] = vzero<VEC>();
+            if (lv[u]) {
+              if (cv[m]) t[u][m] = vload<VEC>(T + (size_t)rj[u] * D + col[m]);
+            }
+          }
+        }
 #pragma unroll
       for (int u = 0; u < U; ++u) fma_row<MODE, VEC, CPL, NI>(pj[u], t[u], cv, q, acc);
     }
@@ -219,6 +242,27 @@ __device__ __forceinline__ void load_fact(const int2* __restrict__ edge, const f
   }
 }
 
+// Hub rows are stored in relation order (csr_plan.hip, hub_sort_scratch): a run of adjacent facts of one relation is
+// one table row times the SUM of the run's priors.  The run's last lane gets the sum (segmented scan over the wave, a
+// fixed tree: deterministic), the other lanes of the run 0, which consume_batch skips - one gather per run instead of
+// one per fact.  Correct for any order (an unsorted row just has shorter runs).
+__device__ __forceinline__ void merge_runs(float& p, int r, int lane) {
+  const int rp = __shfl_up(r, 1, 64), rn = __shfl_down(r, 1, 64);
+  int f = (lane == 0) || (rp != r);
+  if (__ballot(!f) == 0) return;               // no two neighbours share a relation
+  float x = p;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float y = __shfl_up(x, o, 64);
+    const int g = __shfl_up(f, o, 64);
+    if (lane >= o) {
+      if (!f) x += y;
+      f |= g;
+    }
+  }
+  p = ((lane == 63) || (rn != r)) ? x : 0.f;
+}
+
 template <int LPN>
 __device__ __forceinline__ int wave_max_over_groups(int v) {
 #pragma unroll
@@ -245,10 +289,22 @@ __device__ __forceinline__ const float* table_of(const WalkArgs& a, int mode, in
 }
 
 // ---- light rows: one LPN-lane group per destination node, both directions ------------------
+// A node's work is a chain of dependent memory round trips (row bounds -> fact records -> priors -> table rows -> store)
+// and an average row has a dozen facts: at full occupancy the kernel is bound by that chain, not by bandwidth.  Every
+// lane group therefore walks NPW nodes: the row bounds of all of them are requested together, then their first fact
+// batches and priors, and only then are the table rows gathered node after node - one chain per NPW nodes.
+#ifndef GNNRAG_HEAVY_GRID
+#define GNNRAG_HEAVY_GRID 512     // workgroups (4 waves, a 256-fact chunk per wave and turn) of the hub-row kernel per direction
+#endif
+#ifndef GNNRAG_LIGHT_NPW
+#define GNNRAG_LIGHT_NPW 2        // C5, dense prior, light + hub rows (us): 1: 961, 2: 943, 4: 1005, 8: 1043
+#endif
 template <int MODE, int VEC, int LPN, int CPL, int NI>
 __global__ __launch_bounds__(256) void k_walk_light(const WalkArgs a) {
   typedef typename VecT<VEC>::type V;
   constexpr int NA = AccN<MODE, NI>::n;
+  constexpr int NPW = GNNRAG_LIGHT_NPW;
+  constexpr int GPB = 256 / LPN;                // lane groups of a workgroup
   int blk = blockIdx.x;
   if (a.bpg > 0) {
     // XCD-aware order (workgroup b runs on XCD b % 8): all workgroups of question g go to XCD
@@ -258,13 +314,9 @@ __global__ __launch_bounds__(256) void k_walk_light(const WalkArgs a) {
     if (g >= a.B) return;
     blk = g * a.bpg + slot % a.bpg;
   }
-  const int gtid = blk * 256 + threadIdx.x;
   const int sub = threadIdx.x & (LPN - 1);
-  int n = gtid / LPN;
-  const bool live = n < a.BN;
-  if (!live) n = a.BN - 1;  // keep every lane in the shuffles
+  const int grp = threadIdx.x / LPN;
   const int D = a.D;
-  const int b = n / a.N;
   int col[CPL];
   bool cv[CPL];
 #pragma unroll
@@ -272,64 +324,99 @@ __global__ __launch_bounds__(256) void k_walk_light(const WalkArgs a) {
     col[m] = (sub + m * LPN) * VEC;
     cv[m] = col[m] < D;
   }
-  // structure first: both directions' row bounds, first fact batches and priors are in flight
-  // together before anything is consumed
-  int beg[2], len[2];
-  bool heavy[2];
+  // structure first: all nodes' row bounds, then all first fact batches and priors, are in flight together before
+  // anything is consumed
+  int nn[NPW], beg[NPW][2], len[NPW][2];
+  bool live[NPW], heavy[NPW][2];
 #pragma unroll
-  for (int d = 0; d < 2; ++d) {
-    beg[d] = a.row_ptr[d][n];
-    len[d] = a.row_ptr[d][n + 1] - beg[d];
-    heavy[d] = len[d] > a.heavy_deg;
-    if (!live || heavy[d]) len[d] = 0;
+  for (int t = 0; t < NPW; ++t) {
+    int n = (blk * NPW + t) * GPB + grp;
+    live[t] = n < a.BN;
+    if (!live[t]) n = a.BN - 1;  // keep every lane in the shuffles
+    nn[t] = n;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      beg[t][d] = a.row_ptr[d][n];
+      len[t][d] = a.row_ptr[d][n + 1] - beg[t][d];
+    }
   }
-  float p0[2];
-  int r0[2];
+  // first fact batch of every node and direction without branches: all records are requested, then all priors
+  float p0[NPW][2];
+  int r0[NPW][2];
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  i32x2 e0[NPW][2];
 #pragma unroll
-  for (int d = 0; d < 2; ++d) load_fact<MODE>(a.edge[d], a.w[d], a.dist, beg[d], sub, len[d], p0[d], r0[d]);
-  V q[NA][CPL];
-  load_q<MODE, VEC, CPL, NA>(a, b, col, cv, q);
-
-  V acc[NA][CPL];
+  for (int t = 0; t < NPW; ++t)
 #pragma unroll
-  for (int d = 0; d < 2; ++d) {
-    if (MODE == MODE_REASON || d == 0) {
-#pragma unroll
-      for (int i = 0; i < NA; ++i)
-#pragma unroll
-        for (int m = 0; m < CPL; ++m) acc[i][m] = vzero<VEC>();
+    for (int d = 0; d < 2; ++d) {
+      heavy[t][d] = len[t][d] > a.heavy_deg;
+      if (!live[t] || heavy[t][d]) len[t][d] = 0;
+      const int idx = sub < len[t][d] ? beg[t][d] + sub : 0;      // record 0 exists in every structure (F >= 1 slots)
+      e0[t][d] = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(a.edge[d]) + idx);
     }
-    const float* T = table_of(a, MODE, d, b);
-    const int maxlen = wave_max_over_groups<LPN>(len[d]);
-    for (int base = 0; base < maxlen; base += LPN) {
-      float p = p0[d];
-      int r = r0[d];
-      if (base > 0) load_fact<MODE>(a.edge[d], a.w[d], a.dist, beg[d], base + sub, len[d], p, r);
-      consume_batch<MODE, VEC, LPN, CPL, NA>(p, r, min(LPN, maxlen - base), T, D, col, cv, q, acc);
+#pragma unroll
+  for (int t = 0; t < NPW; ++t)
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const bool fv = sub < len[t][d];
+      const int idx = fv ? beg[t][d] + sub : 0;
+      float p;
+      if constexpr (MODE == MODE_TYPE) {
+        p = a.w[d] ? __builtin_nontemporal_load(a.w[d] + idx) : 1.f;
+      } else {
+        p = a.dist[fv ? e0[t][d].x : 0];
+        if (a.w[d]) p *= __builtin_nontemporal_load(a.w[d] + idx);
+      }
+      p0[t][d] = fv ? p : 0.f;
+      r0[t][d] = fv ? e0[t][d].y : 0;
     }
-    if constexpr (MODE == MODE_REASON) {
-      if (live && !heavy[d]) {
-        float* orow = a.out + (size_t)n * (2 * a.I) * D;
+#pragma unroll
+  for (int t = 0; t < NPW; ++t) {
+    const int n = nn[t];
+    const int b = n / a.N;
+    V q[NA][CPL];
+    load_q<MODE, VEC, CPL, NA>(a, b, col, cv, q);
+    V acc[NA][CPL];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      if (MODE == MODE_REASON || d == 0) {
 #pragma unroll
         for (int i = 0; i < NA; ++i)
 #pragma unroll
-          for (int m = 0; m < CPL; ++m)
-            if (cv[m]) vstore_nt<VEC>(orow + (size_t)(2 * (a.i0 + i) + d) * D + col[m], acc[i][m]);
+          for (int m = 0; m < CPL; ++m) acc[i][m] = vzero<VEC>();
+      }
+      const float* T = table_of(a, MODE, d, b);
+      const int maxlen = wave_max_over_groups<LPN>(len[t][d]);
+      for (int base = 0; base < maxlen; base += LPN) {
+        float p = p0[t][d];
+        int r = r0[t][d];
+        if (base > 0) load_fact<MODE>(a.edge[d], a.w[d], a.dist, beg[t][d], base + sub, len[t][d], p, r);
+        consume_batch<MODE, VEC, LPN, CPL, NA>(p, r, min(LPN, maxlen - base), T, D, col, cv, q, acc);
+      }
+      if constexpr (MODE == MODE_REASON) {
+        if (live[t] && !heavy[t][d]) {
+          float* orow = a.out + (size_t)n * (2 * a.I) * D;
+#pragma unroll
+          for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int m = 0; m < CPL; ++m)
+              if (cv[m]) vstore_nt<VEC>(orow + (size_t)(2 * (a.i0 + i) + d) * D + col[m], acc[i][m]);
+        }
       }
     }
-  }
-  if constexpr (MODE != MODE_REASON) {
-    // both directions summed.  If a direction is heavy its chunks are added by k_heavy_reduce
-    // afterwards (which also applies TYPE's final ReLU); store the light part raw in that case.
-    if (live) {
-      const bool fin = !(heavy[0] || heavy[1]);
+    if constexpr (MODE != MODE_REASON) {
+      // both directions summed.  If a direction is heavy its chunks are added by k_heavy_reduce
+      // afterwards (which also applies TYPE's final ReLU); store the light part raw in that case.
+      if (live[t]) {
+        const bool fin = !(heavy[t][0] || heavy[t][1]);
 #pragma unroll
-      for (int m = 0; m < CPL; ++m)
-        if (cv[m]) {
-          V v = acc[0][m];
-          if (MODE == MODE_TYPE && fin) v = vrelu(v);
-          vstore<VEC>(a.out + (size_t)n * D + col[m], v);
-        }
+        for (int m = 0; m < CPL; ++m)
+          if (cv[m] && (!(GNNRAG_LIGHT_ABL & 2) || vfirst(acc[0][m]) == 12345.f)) {
+            V v = acc[0][m];
+            if (MODE == MODE_TYPE && fin) v = vrelu(v);
+            vstore<VEC>(a.out + (size_t)n * D + col[m], v);
+          }
+      }
     }
   }
 }
@@ -376,6 +463,7 @@ __global__ __launch_bounds__(256) void k_heavy_partial(const WalkArgs a) {
       float p;
       int r;
       load_fact<MODE>(a.edge[d], a.w[d], a.dist, beg, base + sub, len, p, r);
+      merge_runs(p, r, sub);
       consume_batch<MODE, VEC, 64, CPL, NA>(p, r, min(64, len - base), T, D, col, cv, q, acc);
     }
     float* prow = a.partial + ((size_t)d * a.max_chunks + c) * (NA * D);
@@ -387,17 +475,17 @@ __global__ __launch_bounds__(256) void k_heavy_partial(const WalkArgs a) {
   }
 }
 
-// ---- heavy rows, pass 2: one wave per heavy row sums its chunks in chunk order -----------------
+// ---- heavy rows, pass 2: one workgroup per heavy row sums its chunks in chunk order ------------
+// (a thread per output column: the 343 chunks of a BASELINE-config-5 hub are one chain of 22 groups of 16 loads)
 // REASON writes its own (i, d) output slots (grid.y = direction).  TYPE/FUSED add into the row the
 // light kernel left (one launch per direction, a.dir, so two lists never touch a row concurrently).
 template <int MODE>
 __global__ __launch_bounds__(256) void k_heavy_reduce(const WalkArgs a, int na) {
   const int d = (MODE == MODE_REASON) ? (int)blockIdx.y : a.dir;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int D = a.D;
   const int cnt = min(a.n_heavy[d], a.heavy_cap);
   const int32_t* off = a.chunk_off[d];
-  for (int e = blockIdx.x * 4 + wave; e < cnt; e += gridDim.x * 4) {
+  for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
     const int n = a.heavy[d][e];
     const int c0 = off[e], c1 = min(off[e + 1], a.max_chunks);
     bool relu = false;
@@ -406,16 +494,16 @@ __global__ __launch_bounds__(256) void k_heavy_reduce(const WalkArgs a, int na) 
       const int l1 = a.row_ptr[1][n + 1] - a.row_ptr[1][n];
       relu = (d == 1) || !(l1 > a.heavy_deg);
     }
-    for (int x = lane; x < na * D; x += 64) {
+    for (int x = threadIdx.x; x < na * D; x += 256) {
       float s = 0.f;
       const float* pp = a.partial + ((size_t)d * a.max_chunks) * (na * D) + x;
       int c = c0;
-      for (; c + 8 <= c1; c += 8) {                  // 8 independent loads in flight, summed in chunk order
-        float v[8];
+      for (; c + 16 <= c1; c += 16) {                // 16 independent loads in flight, summed in chunk order
+        float v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = pp[(size_t)(c + u) * (na * D)];
+        for (int u = 0; u < 16; ++u) v[u] = pp[(size_t)(c + u) * (na * D)];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
+        for (int u = 0; u < 16; ++u) s += v[u];
       }
       for (; c < c1; ++c) s += pp[(size_t)c * (na * D)];
       if (MODE == MODE_REASON) {
@@ -1172,11 +1260,11 @@ static bool pick_shape(int D, Shape* s) {
 
 template <int MODE, int VEC, int LPN, int CPL, int NI>
 static int launch_one(WalkArgs a, hipStream_t stream) {
-  const int groups_per_block = 256 / LPN;
-  int nblk = (a.BN + groups_per_block - 1) / groups_per_block;
+  const int nodes_per_block = (256 / LPN) * GNNRAG_LIGHT_NPW;
+  int nblk = (a.BN + nodes_per_block - 1) / nodes_per_block;
   a.bpg = 0;
-  if (MODE == MODE_FUSED && a.N % groups_per_block == 0) {
-    a.bpg = a.N / groups_per_block;
+  if (MODE == MODE_FUSED && a.N % nodes_per_block == 0) {
+    a.bpg = a.N / nodes_per_block;
     nblk = 8 * ((a.B + 7) / 8) * a.bpg;
   }
   if (!a.heavy_only) {
@@ -1184,16 +1272,16 @@ static int launch_one(WalkArgs a, hipStream_t stream) {
     GNNRAG_LAUNCH_CHECK();
   }
   // heavy rows (count lives on the device: fixed grids, grid-stride loops, no host sync)
-  hipLaunchKernelGGL((k_heavy_partial<MODE, VEC, CPL, NI>), dim3(512, 2), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((k_heavy_partial<MODE, VEC, CPL, NI>), dim3(GNNRAG_HEAVY_GRID, 2), dim3(256), 0, stream, a);
   GNNRAG_LAUNCH_CHECK();
   const int na = AccN<MODE, NI>::n;
   if (MODE == MODE_REASON) {
-    hipLaunchKernelGGL((k_heavy_reduce<MODE>), dim3(64, 2), dim3(256), 0, stream, a, na);
+    hipLaunchKernelGGL((k_heavy_reduce<MODE>), dim3(512, 2), dim3(256), 0, stream, a, na);
     GNNRAG_LAUNCH_CHECK();
   } else {
     for (int d = 0; d < 2; ++d) {
       a.dir = d;
-      hipLaunchKernelGGL((k_heavy_reduce<MODE>), dim3(64, 1), dim3(256), 0, stream, a, na);
+      hipLaunchKernelGGL((k_heavy_reduce<MODE>), dim3(512, 1), dim3(256), 0, stream, a, na);
       GNNRAG_LAUNCH_CHECK();
     }
   }

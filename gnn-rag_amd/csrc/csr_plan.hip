@@ -15,6 +15,7 @@
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 
 #include "gnnrag_common.h"
@@ -78,6 +79,73 @@ static size_t sort_temp_bytes(int64_t F, unsigned bits) {
     bytes = (size_t)16 * (size_t)(F > 0 ? F : 1) + ((size_t)1 << 20);  // conservative bound (no device to ask)
   }
   return bytes;
+}
+
+// Hub rows (more than kHeavyDeg facts) are put in RELATION order at plan time (stable inside a relation): the walk adds
+// the priors of a run of equal relations and gathers the run's table row once (k_heavy_partial) - a Freebase hub has
+// far more facts than distinct relations (BASELINE config 5: 183 000 hub facts of a question, 56 000 distinct (hub,
+// relation) pairs).  rocPRIM's segmented radix sort over the hub rows' (relation, fact id) pairs; every other row keeps
+// the fact order.  Scratch: two key arrays, a second fact-id array, the segment bounds and rocPRIM's own.
+static size_t seg_sort_temp_bytes(int64_t F, int32_t segments, unsigned bits) {
+  size_t bytes = 0;
+  const uint32_t* kin = nullptr;
+  uint32_t* kout = nullptr;
+  const int32_t* vin = nullptr;
+  int32_t* vout = nullptr;
+  const int32_t* off = nullptr;
+  hipError_t e = rocprim::segmented_radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, (unsigned)F, (unsigned)segments,
+                                                     off, off, 0u, bits, (hipStream_t)0, false);
+  if (e != hipSuccess || bytes == 0) {
+    (void)hipGetLastError();
+    bytes = (size_t)16 * (size_t)(F > 0 ? F : 1) + (size_t)64 * (size_t)segments + ((size_t)1 << 20);
+  }
+  return bytes;
+}
+
+struct HubSortScratch {
+  size_t key_in, key_out, perm2, seg, temp, total;
+};
+
+static HubSortScratch hub_sort_scratch(int64_t F, int32_t R1, int32_t heavy_cap) {
+  HubSortScratch H;
+  const size_t Fp = (size_t)(F > 0 ? F : 1);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off = align_up(off + bytes, 256);
+    return o;
+  };
+  H.key_in = take(Fp * sizeof(uint32_t));
+  H.key_out = take(Fp * sizeof(uint32_t));
+  H.perm2 = take(Fp * sizeof(int32_t));
+  H.seg = take((size_t)2 * heavy_cap * sizeof(int32_t));
+  H.temp = take(seg_sort_temp_bytes(F, heavy_cap, key_bits((size_t)R1)));
+  H.total = off;
+  return H;
+}
+
+// key[i] = relation of the fact at sorted position i
+__global__ __launch_bounds__(256) void k_csr_relkey(const int32_t* __restrict__ perm, const int32_t* __restrict__ rels,
+                                                    int64_t F, uint32_t* __restrict__ key) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < F) key[i] = (uint32_t)rels[perm[i]];
+}
+
+// the hub rows as sort segments: [row_ptr[n], row_ptr[n + 1]) for the listed nodes, empty for the unused list entries
+__global__ __launch_bounds__(256) void k_csr_hub_segments(const int32_t* __restrict__ row_ptr,
+                                                          const int32_t* __restrict__ list,
+                                                          const int32_t* __restrict__ count, int32_t cap,
+                                                          int32_t* __restrict__ seg_begin, int32_t* __restrict__ seg_end) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= cap) return;
+  int b = 0, n = 0;
+  if (e < min(*count, cap)) {
+    const int node = list[e];
+    b = row_ptr[node];
+    n = row_ptr[node + 1];
+  }
+  seg_begin[e] = b;
+  seg_end[e] = n;
 }
 
 // One thread per sorted position: gather the (source, relation) record and the weights of the
@@ -624,7 +692,8 @@ extern "C" size_t gnnrag_csr_scratch_bytes(int64_t F, int32_t B, int32_t N, int3
   const size_t Fp = (size_t)(F > 0 ? F : 1);
   const unsigned bits = key_bits((size_t)B * (size_t)N);
   return align_up(Fp * sizeof(uint32_t), 256) + align_up(sort_temp_bytes(F, bits), 256) +
-         align_up((size_t)B * (size_t)R1 * sizeof(int32_t), 256);
+         align_up((size_t)B * (size_t)R1 * sizeof(int32_t), 256) +
+         hub_sort_scratch(F, R1, (int32_t)(Fp / kHeavyDeg + 1)).total;
 }
 
 extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const int32_t* tails,
@@ -676,11 +745,13 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
   if (F > 0) {
     temp_bytes = sort_temp_bytes(F, bits);
     temp_bytes = align_up(temp_bytes, 256);
-    if (scratch_bytes < keys_bytes + temp_bytes + (size_t)B * R1 * sizeof(int32_t)) return GNNRAG_E_WORKSPACE;
+    if (scratch_bytes < gnnrag_csr_scratch_bytes(F, B, N, R1)) return GNNRAG_E_WORKSPACE;
   }
   uint32_t* keys_sorted = (uint32_t*)scratch;
   void* temp = (char*)scratch + keys_bytes;
   int32_t* g2l = (int32_t*)((char*)scratch + keys_bytes + temp_bytes);
+  const HubSortScratch H = hub_sort_scratch(F, R1, L.heavy_cap);
+  char* hub_base = (char*)scratch + keys_bytes + temp_bytes + align_up((size_t)B * (size_t)R1 * sizeof(int32_t), 256);
 
   // relations each question uses -> compact numbering (before the fills, which store it per fact)
   if (F > 0) {
@@ -707,11 +778,6 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
       size_t tb = temp_bytes;
       GNNRAG_HIP(rocprim::radix_sort_pairs(temp, tb, (const uint32_t*)dst, keys_sorted, iota,
                                            out->perm[d], (size_t)F, 0u, bits, stream, false));
-      const int nb = (int)((F + 255) / 256);
-      hipLaunchKernelGGL(k_csr_fill, dim3(nb), dim3(256), 0, stream, out->perm[d], src, rels, w_gnn,
-                         w_rel, F, g2l, (int64_t)B * R1, N, R1, (int2*)out->edge[d], (int2*)out->edge_l[d],
-                         out->w_gnn[d], out->w_rel[d]);
-      GNNRAG_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_csr_row_ptr, dim3(nb_rows), dim3(256), 0, stream, keys_sorted, F, BN,
                        out->row_ptr[d]);
@@ -720,6 +786,31 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
                        out->row_ptr[d], BN, (int32_t)kHeavyDeg, out->heavy[d], out->heavy_cap,
                        out->n_heavy + d);
     GNNRAG_LAUNCH_CHECK();
+    if (F > 0) {
+      // hub rows in relation order (see hub_sort_scratch): fact ids of the hub rows re-sorted by relation, stable
+      const int nb = (int)((F + 255) / 256);
+      uint32_t* key_in = (uint32_t*)(hub_base + H.key_in);
+      uint32_t* key_out = (uint32_t*)(hub_base + H.key_out);
+      int32_t* perm2 = (int32_t*)(hub_base + H.perm2);
+      int32_t* seg_begin = (int32_t*)(hub_base + H.seg);
+      int32_t* seg_end = seg_begin + L.heavy_cap;
+      hipLaunchKernelGGL(k_csr_hub_segments, dim3((L.heavy_cap + 255) / 256), dim3(256), 0, stream, out->row_ptr[d],
+                         out->heavy[d], out->n_heavy + d, L.heavy_cap, seg_begin, seg_end);
+      GNNRAG_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_csr_relkey, dim3(nb), dim3(256), 0, stream, out->perm[d], rels, F, key_in);
+      GNNRAG_LAUNCH_CHECK();
+      GNNRAG_HIP(hipMemcpyAsync(perm2, out->perm[d], (size_t)F * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+      size_t stb = H.total - H.temp;
+      GNNRAG_HIP(rocprim::segmented_radix_sort_pairs(hub_base + H.temp, stb, (const uint32_t*)key_in, key_out,
+                                                     (const int32_t*)out->perm[d], perm2, (unsigned)F,
+                                                     (unsigned)L.heavy_cap, (const int32_t*)seg_begin,
+                                                     (const int32_t*)seg_end, 0u, key_bits((size_t)R1), stream, false));
+      GNNRAG_HIP(hipMemcpyAsync(out->perm[d], perm2, (size_t)F * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+      hipLaunchKernelGGL(k_csr_fill, dim3(nb), dim3(256), 0, stream, out->perm[d], src, rels, w_gnn,
+                         w_rel, F, g2l, (int64_t)B * R1, N, R1, (int2*)out->edge[d], (int2*)out->edge_l[d],
+                         out->w_gnn[d], out->w_rel[d]);
+      GNNRAG_LAUNCH_CHECK();
+    }
   }
   hipLaunchKernelGGL(k_csr_heavy_chunks, dim3(2), dim3(1024), 0, stream, out->row_ptr[0], out->row_ptr[1],
                      out->heavy[0], out->heavy[1], out->n_heavy, out->heavy_cap, out->chunk_off[0],

@@ -30,6 +30,9 @@ def _csr_numpy(heads, rels, tails, B, N):
     out = {}
     for d, (src, dst) in enumerate(((heads, tails), (tails, heads))):
         order = np.argsort(dst, kind="stable")
+        # hub rows (more than 256 facts) are kept in relation order, stable inside a relation (csr_plan.hip)
+        hub = np.bincount(dst, minlength=B * N)[dst[order]] > 256
+        order = order[np.lexsort((np.where(hub, rels[order], 0), dst[order]))]
         out["perm%d" % d] = order.astype(np.int32)
         out["edge%d" % d] = np.stack([src[order], rels[order]], 1).astype(np.int32)
         out["row_ptr%d" % d] = np.searchsorted(dst[order], np.arange(B * N + 1), side="left").astype(np.int32)

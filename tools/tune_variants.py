@@ -48,6 +48,12 @@ VARIANTS = {
     "sl_t512_g4": {"GNNRAG_SLICE_THREADS": 512, "GNNRAG_SLICE_WPE": 4, "GNNRAG_SLICE_BL_GROUP": 4},
     "sl_t1024_w4_g4": {"GNNRAG_SLICE_WPE": 4, "GNNRAG_SLICE_BL_GROUP": 4},
     "vq_un4": {"GNNRAG_VQ_UN": 4}, "vq_un5": {"GNNRAG_VQ_UN": 5}, "vq_un6": {"GNNRAG_VQ_UN": 6},
+    # gather walk (tables larger than LDS, BASELINE config 5; GNNRAG_TUNE_WORKLOAD=C5): nodes per lane group whose
+    # structure loads are requested together, workgroups of the hub-row kernel
+    "light_npw1": {"GNNRAG_LIGHT_NPW": 1}, "light_npw2": {"GNNRAG_LIGHT_NPW": 2}, "light_npw8": {"GNNRAG_LIGHT_NPW": 8},
+    "heavy_grid512": {"GNNRAG_HEAVY_GRID": 512}, "heavy_grid2048": {"GNNRAG_HEAVY_GRID": 2048},
+    "light_nogather": {"GNNRAG_LIGHT_ABL": 1}, "light_nostore": {"GNNRAG_LIGHT_ABL": 2}, "light_l2hit": {"GNNRAG_LIGHT_ABL": 4},
+    "light_nomem": {"GNNRAG_LIGHT_ABL": 3},
     "split_trunc": {"GNNRAG_SPLIT_RN": 0},      # the truncation form of the exact 3-way bf16 split (rounds 1-2)
     "vq_nolds": {"GNNRAG_VQ_ABL": 1}, "vq_noa": {"GNNRAG_VQ_ABL": 2}, "vq_nostage": {"GNNRAG_VQ_ABL": 4},
     "upd_nolds": {"GNNRAG_UPD_ABL": 1}, "upd_noa": {"GNNRAG_UPD_ABL": 2}, "upd_noadd": {"GNNRAG_UPD_ABL": 4},
