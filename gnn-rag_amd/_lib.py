@@ -31,6 +31,7 @@ class CsrStruct(C.Structure):
         ("edge_l", C.c_void_p * 2), ("rel_off", C.c_void_p), ("rel_rows", C.c_void_p),
         ("rel_total", C.c_int32), ("rel_max", C.c_int32),
         ("edge_m", C.c_void_p), ("m_from", C.c_void_p), ("m_dst", C.c_void_p),
+        ("hub_q_off", C.c_void_p * 2), ("hub_wbase", C.c_void_p * 2),
     ]
 
 
@@ -119,7 +120,7 @@ SIGNATURES = {
     "gnnrag_error_string": (C.c_char_p, [C.c_int]),
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 PATH_AUTO, PATH_UNFUSED, PATH_FUSED = 0, 1, 2
 PATH_ONLY_FWD, PATH_ONLY_INV = 0x10, 0x20        # OR-ed into the path: one-direction layers (NSM)
 PATH_SEED_PRIOR = 0x40                           # OR-ed into the path: the (first layer's) prior is a seed distribution

@@ -113,6 +113,13 @@ struct WalkArgs {
   int32_t max_chunks, heavy_cap, heavy_deg;
   int32_t BN, N, D, I, i0, R1, B;   // R1: table rows (FUSED: largest per-question count, sizes the LDS slices)
   int32_t bpg;                // FUSED: workgroups per question for the XCD-aware mapping (0 = off)
+  // dense hub form (FUSED gather walk; see k_hub_dense): per-question hub offsets of the structure, the hub-by-relation
+  // weights (null = form off), their capacity in floats, one (relation, partial weight) record per 256-fact chunk
+  const int32_t* hub_q_off[2];
+  const int32_t* hub_wbase[2];
+  float* hub_w;
+  long long hub_w_cap;
+  int2* hub_bnd;
   int32_t dir;                // k_heavy_reduce in read-modify-write modes: direction of this launch
   int32_t heavy_only;         // host side: the light rows were already walked by another kernel
   const int32_t* big_cnt;     // LDS walk: per-question count / list of nodes with > big_deg facts in a direction
@@ -240,6 +247,12 @@ __device__ __forceinline__ void load_fact(const int2* __restrict__ edge, const f
       if (w) p *= __builtin_nontemporal_load(w + idx);
     }
   }
+}
+
+// dense hub form: on when the caller handed a weight buffer that holds both directions' hub-by-relation blocks (the
+// sizes live on the device: every kernel of either form is launched and the form not in use returns at once)
+__device__ __forceinline__ bool hub_dense_on(const WalkArgs& a) {
+  return a.hub_w != nullptr && (long long)a.hub_wbase[0][a.B] + (long long)a.hub_wbase[1][a.B] <= a.hub_w_cap;
 }
 
 // Hub rows are stored in relation order (csr_plan.hip, hub_sort_scratch): a run of adjacent facts of one relation is
@@ -424,6 +437,9 @@ __global__ __launch_bounds__(256) void k_walk_light(const WalkArgs a) {
 // ---- heavy rows, pass 1: one wave per 256-fact chunk -> partial sums --------------------------
 template <int MODE, int VEC, int CPL, int NI>
 __global__ __launch_bounds__(256) void k_heavy_partial(const WalkArgs a) {
+  if constexpr (MODE == MODE_FUSED) {
+    if (hub_dense_on(a)) return;               // the hub rows are a dense product in this call (k_hub_dense)
+  }
   typedef typename VecT<VEC>::type V;
   constexpr int NA = AccN<MODE, NI>::n;
   const int d = blockIdx.y;
@@ -481,6 +497,9 @@ __global__ __launch_bounds__(256) void k_heavy_partial(const WalkArgs a) {
 // light kernel left (one launch per direction, a.dir, so two lists never touch a row concurrently).
 template <int MODE>
 __global__ __launch_bounds__(256) void k_heavy_reduce(const WalkArgs a, int na) {
+  if constexpr (MODE == MODE_FUSED) {
+    if (hub_dense_on(a)) return;
+  }
   const int d = (MODE == MODE_REASON) ? (int)blockIdx.y : a.dir;
   const int D = a.D;
   const int cnt = min(a.n_heavy[d], a.heavy_cap);
@@ -514,6 +533,287 @@ __global__ __launch_bounds__(256) void k_heavy_reduce(const WalkArgs a, int na) 
         if (relu) v = fmaxf(v, 0.f);
         a.out[(size_t)n * D + x] = v;
       }
+    }
+  }
+}
+
+
+// ---- hub rows as a small dense product (FUSED gather walk) ------------------------------------------------------------
+// A Freebase hub has far more facts than the question has relations (BASELINE config 5: 37 hubs per question hold 183 000
+// of its 220 000 inverse facts; 6001 relations in use), and the gather walk is bound by the CU's vector-memory path: a
+// table row per fact - or per run of equal relations, k_heavy_partial - is what costs.  With the hub rows in relation
+// order the hub part of a question is  out[hubs, :] = Wgt[hubs, relations] . P[relations, :],  Wgt[h, r] = sum of the
+// priors of hub h's facts of relation r:
+//   k_hub_zero     zeroes the weight blocks (sizes on the device);
+//   k_hub_weights  one wave per 256-fact chunk: segmented sums over runs of equal relations.  A run that STARTS in the
+//                  chunk is stored to its own Wgt slot (rows are sorted, so nobody else writes it); the part of a run
+//                  that started in an earlier chunk goes to the chunk's boundary record (relation, partial sum);
+//   k_hub_dense    Wgt . P on the matrix cores in exact fp32 (v_mfma_f32_16x16x4_f32): workgroup = (16 hubs, 64
+//                  columns) of a question, its four waves split the relations and add their tiles in wave order; P is
+//                  streamed once per 16 hubs in coalesced pieces instead of gathered row by row;
+//   k_hub_finish   one workgroup per hub: row += dense result + the row's boundary records in chunk order.
+// Every sum has a fixed order: deterministic.  Needs the hub rows in relation order (structures of this library).
+#ifndef GNNRAG_HUB_DENSE
+#define GNNRAG_HUB_DENSE 1
+#endif
+
+__global__ __launch_bounds__(256) void k_hub_zero(const WalkArgs a) {
+  if (!hub_dense_on(a)) return;
+  const long long n4 = ((long long)a.hub_wbase[0][a.B] + a.hub_wbase[1][a.B]) >> 2;
+  f32x4* w = reinterpret_cast<f32x4*>(a.hub_w);
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) w[i] = z;
+}
+
+__global__ __launch_bounds__(256) void k_hub_weights(const WalkArgs a) {
+  if (!hub_dense_on(a)) return;
+  const int d = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int cnt = min(a.n_heavy[d], a.heavy_cap);
+  const int nch = min(a.n_chunks[d], a.max_chunks);
+  const int32_t* off = a.chunk_off[d];
+  float* wdir = a.hub_w + (d ? a.hub_wbase[0][a.B] : 0);
+  for (int c = blockIdx.x * 4 + wave; c < nch; c += gridDim.x * 4) {
+    int lo = 0, hi = cnt;                       // largest e with off[e] <= c
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (off[mid] <= c) lo = mid; else hi = mid;
+    }
+    const int n = a.heavy[d][lo];
+    const int lc = c - off[lo];
+    const int beg = a.row_ptr[d][n] + lc * kHeavyDeg;
+    const int len = min(kHeavyDeg, a.row_ptr[d][n + 1] - beg);
+    const int q = n / a.N;
+    const int nrel4 = ((a.rel_off[q + 1] - a.rel_off[q]) + 3) & ~3;
+    float* wrow = wdir + a.hub_wbase[d][q] + (size_t)(lo - a.hub_q_off[d][q]) * nrel4;
+    int open_rel = lc > 0 ? a.edge[d][beg - 1].y : -1;   // relation of the run that is open where the batch starts
+    bool first_run = lc > 0;                              // still inside a run that started before this chunk?
+    float carry = 0.f;                                    // the open run's sum so far inside this chunk
+    bool pend = false, pend_first = false;                // a run reached the end of the last batch: not stored yet
+    int bnd_rel = -1;
+    float bnd_sum = 0.f;
+    // the chunk's four batches of records, then their priors, are requested before the first is used
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    i32x2 ev[4];
+    float pv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int o = k * 64 + lane;
+      ev[k] = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(a.edge[d]) + (o < len ? beg + o : beg));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int o = k * 64 + lane;
+      float pp = a.dist[ev[k].x];
+      if (a.w[d]) pp *= __builtin_nontemporal_load(a.w[d] + (o < len ? beg + o : beg));
+      pv[k] = o < len ? pp : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int base = k * 64;
+      if (base >= len) break;
+      float p = pv[k];
+      int r = ev[k].y;
+      const int nv = min(64, len - base);
+      if (lane >= nv) r = -2;                             // padding: a run of its own, never stored
+      int rp = __shfl_up(r, 1, 64);
+      if (lane == 0) rp = open_rel;
+      int f = (r != rp) ? 1 : 0;                          // first fact of a run
+      float x = p;
+      if (lane == 0 && !f) x += carry;
+      const unsigned long long hb = __ballot(f && lane < nv);
+      if (pend && (hb & 1ull)) {                          // the run carried over ended with the batch before
+        if (pend_first) {
+          bnd_rel = open_rel;
+          bnd_sum = carry;
+        } else if (lane == 0) {
+          wrow[open_rel] = carry;
+        }
+      }
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {                  // segmented inclusive scan (fixed tree)
+        const float y = __shfl_up(x, o, 64);
+        const int g = __shfl_up(f, o, 64);
+        if (lane >= o) {
+          if (!f) x += y;
+          f |= g;
+        }
+      }
+      const int rn = __shfl_down(r, 1, 64);
+      const bool last_valid = lane == nv - 1;
+      const bool tail = lane < nv && (last_valid || rn != r);
+      const bool more = base + 64 < len;                  // this wave has another batch of the chunk
+      const bool in_first = first_run && (hb & ((2ull << lane) - 1ull)) == 0;
+      if (tail && !(last_valid && more) && !in_first) wrow[r] = x;
+      if (first_run) {
+        const int t = hb ? __builtin_ctzll(hb) - 1 : nv - 1;      // last lane of the first run in this batch
+        if (t >= 0 && (hb || !more)) {                            // ... and the run (or the chunk) ends here
+          bnd_rel = __builtin_amdgcn_readlane(r, t);
+          bnd_sum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), t));
+        }
+      }
+      pend = more;
+      pend_first = first_run && hb == 0;                  // (first_run is still the value this batch started with)
+      if (hb) first_run = false;
+      carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), nv - 1));
+      open_rel = __builtin_amdgcn_readlane(r, nv - 1);
+    }
+    if (lane == 0) a.hub_bnd[(size_t)d * a.max_chunks + c] = make_int2(bnd_rel, __float_as_int(bnd_sum));
+  }
+}
+
+constexpr int kHubWaves = 8;   // waves of a k_hub_dense workgroup: they split the relations
+constexpr int kHubCols = 32;   // columns of a workgroup (two MFMA column tiles)
+
+// MT tiles of 16 hubs x 32 columns of one question: every table row piece is loaded once for all MT tiles
+template <int MT>
+__device__ __forceinline__ void hub_dense_tiles(const WalkArgs& a, float (*s_part)[3][2][64][4], int d, int e0, int nh,
+                                                int h0, const float* __restrict__ Wq, const float* __restrict__ Pq,
+                                                int nrel, int nrel4, int c0) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int D = a.D;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // Column tile nt holds the columns c0 + 2 j + nt (j = 0..15): lane (fr, fg) needs P[k][c0 + 2 fr + nt], nt = 0, 1 -
+  // ONE 8-byte load per relation row, 128 contiguous bytes across the 16 lanes of a row.
+  const int cb = c0 + 2 * fr;                      // this lane's two columns (D % 4 == 0: both in or both out)
+  const bool cok = cb < D;
+  const int cbl = cok ? cb : D - 2;                // loads are unconditional (clamped): no branch, no wait between them
+  const float* wrow[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) wrow[i] = Wq + (size_t)min(h0 + i * 16 + fr, nh - 1) * nrel4;
+  f32x4 acc[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i][0] = acc[i][1] = zero4;
+  const int nkg = (nrel4 + 15) >> 4;
+  // A lane (fr, fg): weights of hub fr for the relations k .. k + 3, k = 16 kg + 4 fg (one 16-byte load).  MFMA e of a
+  // group contracts the relations {16 kg + 4 fg + e}: any split of k is fine as long as A and B agree.
+  constexpr int U = MT == 1 ? 4 : 2;
+  for (int kg0 = wave; kg0 < nkg; kg0 += U * kHubWaves) {
+    f32x4 av[U][MT];
+    f32x2 bv[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      // past the question's relations the WEIGHTS are zero (zeroed padding / the select below); the table rows are
+      // then read from the last row instead of being zeroed: 0 x finite
+      const int k = (kg0 + kHubWaves * u) * 16 + fg * 4;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wrow[i] + min(k, nrel4 - 4));
+        av[u][i] = k < nrel4 ? w4 : zero4;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        bv[u][e] = *reinterpret_cast<const f32x2*>(Pq + (size_t)min(k + e, nrel - 1) * D + cbl);
+    }
+    __builtin_amdgcn_sched_barrier(0);     // all loads are requested before the first MFMA (the scheduler would
+                                           // otherwise keep three in flight to save registers)
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i][e], bv[u][e][nt], acc[i][nt], 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<f32x4*>(&s_part[wave - 1][i][nt][lane][0]) = acc[i][nt];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    // C layout: lane (fr, fg) holds hubs 4 fg + r of column slot fr, i.e. column c0 + 2 fr + nt of tile nt
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      f32x4 v[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        v[nt] = acc[i][nt];
+#pragma unroll
+        for (int w = 0; w < kHubWaves - 1; ++w) v[nt] += *reinterpret_cast<const f32x4*>(&s_part[w][i][nt][lane][0]);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int m = h0 + i * 16 + fg * 4 + rr;
+        if (m < nh && cok) {
+          const int slot = a.chunk_off[d][e0 + m];       // the hub's first chunk slot of the partial-sum scratch
+          const f32x2 o = {v[0][rr], v[1][rr]};
+          *reinterpret_cast<f32x2*>(a.partial + ((size_t)d * a.max_chunks + slot) * D + cb) = o;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(64 * kHubWaves) void k_hub_dense(const WalkArgs a) {
+  if (!hub_dense_on(a)) return;
+  __shared__ __attribute__((aligned(16))) float s_part[kHubWaves - 1][3][2][64][4];   // [wave 1..][hub tile][column tile][lane][4 hubs]
+  const int D = a.D, ncg = (D + kHubCols - 1) / kHubCols;
+  // one workgroup per (question, direction, 32-column group): 7 x 32 of them with hubs at BASELINE config 5 - one per
+  // CU, every table row piece loaded once.  (A first version, one workgroup per (16 hubs, 64 columns), had 384 uneven
+  // workgroups re-reading the table per hub tile: 141 us against the ~35 us of its MFMAs.)
+  const int item = blockIdx.x;
+  const int cg = item % ncg, q = (item / ncg) % a.B, d = item / (ncg * a.B);
+  const int e0 = a.hub_q_off[d][q], nh = a.hub_q_off[d][q + 1] - e0;
+  if (nh <= 0) return;
+  const int nrel = a.rel_off[q + 1] - a.rel_off[q], nrel4 = (nrel + 3) & ~3;
+  const float* Wq = a.hub_w + (d ? a.hub_wbase[0][a.B] : 0) + a.hub_wbase[d][q];
+  const float* Pq = a.T[d] + (size_t)a.rel_off[q] * D;
+  const int c0 = cg * kHubCols;
+  for (int h0 = 0; h0 < nh; h0 += 48) {
+    const int left = nh - h0;
+    if (left > 32) hub_dense_tiles<3>(a, s_part, d, e0, nh, h0, Wq, Pq, nrel, nrel4, c0);
+    else if (left > 16) hub_dense_tiles<2>(a, s_part, d, e0, nh, h0, Wq, Pq, nrel, nrel4, c0);
+    else hub_dense_tiles<1>(a, s_part, d, e0, nh, h0, Wq, Pq, nrel, nrel4, c0);
+  }
+}
+
+// one workgroup per hub; its four 256-thread groups take a quarter of the hub's chunks each and are added in group order
+__global__ __launch_bounds__(1024) void k_hub_finish(const WalkArgs a) {
+  if (!hub_dense_on(a)) return;
+  __shared__ float s_q[3][256];
+  const int d = a.dir, D = a.D;
+  const int grp = threadIdx.x >> 8, tx = threadIdx.x & 255;
+  const int cnt = min(a.n_heavy[d], a.heavy_cap);
+  const int32_t* off = a.chunk_off[d];
+  const int2* bnd = a.hub_bnd + (size_t)d * a.max_chunks;
+  for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
+    const int n = a.heavy[d][e];
+    const int q = n / a.N;
+    const int c0 = off[e], c1 = min(off[e + 1], a.max_chunks);
+    const int per = (c1 - c0 + 3) >> 2;
+    const int cb = min(c0 + grp * per, c1), ce = min(cb + per, c1);
+    const float* Pq = a.T[d] + (size_t)a.rel_off[q] * D;
+    for (int x0 = 0; x0 < D; x0 += 256) {
+      const int x = x0 + tx;
+      float s = 0.f;
+      if (x < D) {
+        int c = cb;
+        for (; c + 8 <= ce; c += 8) {                // 8 boundary records and their table rows in flight, added in chunk order
+          int2 b[8];
+          float t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) b[u] = bnd[c + u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[u] = b[u].x >= 0 ? Pq[(size_t)b[u].x * D + x] : 0.f;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) s = fmaf(__int_as_float(b[u].y), t[u], s);
+        }
+        for (; c < ce; ++c) {
+          const int2 b = bnd[c];
+          if (b.x >= 0) s = fmaf(__int_as_float(b.y), Pq[(size_t)b.x * D + x], s);
+        }
+      }
+      if (grp > 0) s_q[grp - 1][tx] = s;
+      __syncthreads();
+      if (grp == 0 && x < D)
+        a.out[(size_t)n * D + x] += a.partial[((size_t)d * a.max_chunks + c0) * D + x] + (((s + s_q[0][tx]) + s_q[1][tx]) + s_q[2][tx]);
+      __syncthreads();
     }
   }
 }
@@ -1044,6 +1344,15 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? GNNRAG_SLICE_W
 #define GNNRAG_WALK_STREAM 1     // compiled in; chosen at run time by the environment variable only
 #endif
 constexpr int kStreamRowBits = 12;          // table rows of both directions incl. the zero rows: 2 (Rg + 1) <= 4096
+// GNNRAG_HUB_DENSE=0 in the environment keeps the chunked hub kernels (A/B, tests of both forms)
+static bool hub_dense_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("GNNRAG_HUB_DENSE");
+    return GNNRAG_HUB_DENSE && !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 static bool walk_stream_enabled() {
   const char* e = getenv("GNNRAG_WALK_STREAM");
   return e && e[0] == '1';
@@ -1275,6 +1584,17 @@ static int launch_one(WalkArgs a, hipStream_t stream) {
   hipLaunchKernelGGL((k_heavy_partial<MODE, VEC, CPL, NI>), dim3(GNNRAG_HEAVY_GRID, 2), dim3(256), 0, stream, a);
   GNNRAG_LAUNCH_CHECK();
   const int na = AccN<MODE, NI>::n;
+  if constexpr (MODE == MODE_FUSED) {
+    if (a.hub_w) {      // dense hub form (returns at once on the device when the weight blocks do not fit)
+      hipLaunchKernelGGL(k_hub_zero, dim3(1024), dim3(256), 0, stream, a);
+      GNNRAG_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_hub_weights, dim3(2048, 2), dim3(256), 0, stream, a);
+      GNNRAG_LAUNCH_CHECK();
+      const int items = ((a.D + kHubCols - 1) / kHubCols) * a.B * 2;
+      hipLaunchKernelGGL(k_hub_dense, dim3(items), dim3(64 * kHubWaves), 0, stream, a);
+      GNNRAG_LAUNCH_CHECK();
+    }
+  }
   if (MODE == MODE_REASON) {
     hipLaunchKernelGGL((k_heavy_reduce<MODE>), dim3(512, 2), dim3(256), 0, stream, a, na);
     GNNRAG_LAUNCH_CHECK();
@@ -1283,6 +1603,12 @@ static int launch_one(WalkArgs a, hipStream_t stream) {
       a.dir = d;
       hipLaunchKernelGGL((k_heavy_reduce<MODE>), dim3(512, 1), dim3(256), 0, stream, a, na);
       GNNRAG_LAUNCH_CHECK();
+      if constexpr (MODE == MODE_FUSED) {
+        if (a.hub_w) {
+          hipLaunchKernelGGL(k_hub_finish, dim3(512), dim3(1024), 0, stream, a);
+          GNNRAG_LAUNCH_CHECK();
+        }
+      }
     }
   }
   return 0;
@@ -1538,7 +1864,24 @@ int gnnrag::aggregate_fused_dirs(const gnnrag_csr* csr, const float* dist, const
       a.stream_scratch_bytes = workspace_bytes - used;
     }
   }
-  switch (gnnrag_aggregate_fused_variant(csr, D)) {
+  const int variant = gnnrag_aggregate_fused_variant(csr, D);
+  if (variant == GNNRAG_WALK_L2_GATHER && (D & 3) == 0 && hub_dense_enabled() && csr->hub_q_off[0] && csr->hub_wbase[0]) {
+    // dense hub form: boundary records and weight blocks live where the LDS walk keeps its prior pairs (unused by the
+    // gather walk); whether the blocks fit is decided on the device (hub_dense_on)
+    const size_t used = partial_bytes(csr, D, 1), avail = prior_bytes(csr);
+    const size_t bnd_bytes = align_up((size_t)2 * (size_t)csr->max_chunks * sizeof(int2), 256);
+    if (workspace_bytes >= used + avail && avail > bnd_bytes + 4096) {
+      for (int d = 0; d < 2; ++d) {
+        a.hub_q_off[d] = csr->hub_q_off[d];
+        a.hub_wbase[d] = csr->hub_wbase[d];
+      }
+      a.hub_bnd = (int2*)((char*)workspace + used);
+      a.hub_w = (float*)((char*)workspace + used + bnd_bytes);
+      const size_t cap = (avail - bnd_bytes) / sizeof(float);
+      a.hub_w_cap = (long long)(cap < ((size_t)1 << 30) ? cap : ((size_t)1 << 30));
+    }
+  }
+  switch (variant) {
     case GNNRAG_WALK_L2_GATHER: return launch_walk<MODE_FUSED>(a, 1, stream);   // tables too big for LDS
     // 32-column slices when two of them still fit a CU's LDS (questions that use up to ~300 relations): half
     // as many workgroups re-walk the question's facts

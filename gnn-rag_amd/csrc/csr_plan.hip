@@ -24,7 +24,7 @@ namespace gnnrag {
 
 struct CsrLayout {
   size_t row_ptr[2], edge[2], perm[2], w_gnn[2], w_rel[2], heavy[2], chunk_off[2], n_heavy, big_cnt, big_nodes;
-  size_t edge_l[2], rel_off, rel_rows, edge_m, m_from, m_dst, total;
+  size_t edge_l[2], rel_off, rel_rows, edge_m, m_from, m_dst, hub_q_off[2], hub_wbase[2], hub_qcnt, total;
   int32_t heavy_cap;
 };
 
@@ -56,6 +56,9 @@ static CsrLayout csr_layout(int64_t F, int32_t B, int32_t N, int32_t R1, int has
   L.edge_m = take(2 * Fp * 2 * sizeof(int32_t));
   L.m_from = take(2 * Fp * sizeof(int32_t));
   L.m_dst = take(2 * Fp * sizeof(int32_t));
+  for (int d = 0; d < 2; ++d) L.hub_q_off[d] = take(((size_t)B + 1) * sizeof(int32_t));
+  for (int d = 0; d < 2; ++d) L.hub_wbase[d] = take(((size_t)B + 1) * sizeof(int32_t));
+  L.hub_qcnt = take((size_t)B * sizeof(int32_t));
   L.total = off;
   return L;
 }
@@ -191,14 +194,73 @@ __global__ __launch_bounds__(256) void k_csr_row_ptr(const uint32_t* __restrict_
   row_ptr[n] = (int32_t)lo;
 }
 
-__global__ __launch_bounds__(256) void k_csr_heavy(const int32_t* __restrict__ row_ptr, int64_t BN,
-                                                   int32_t heavy_deg, int32_t* __restrict__ list,
-                                                   int32_t cap, int32_t* __restrict__ count) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= BN) return;
-  if (row_ptr[n + 1] - row_ptr[n] > heavy_deg) {
-    const int32_t pos = atomicAdd(count, 1);
-    if (pos < cap) list[pos] = (int32_t)n;  // order is irrelevant: each row's own sum order is fixed
+// The heavy rows (hubs) of a direction, listed in ascending node order - i.e. question by question - with the
+// per-question offsets the dense hub form of the gather walk needs (aggregate.hip, k_hub_dense):
+//   hub_q_off[b]  first list entry of question b          (hub_q_off[B] = n_heavy)
+//   hub_wbase[b]  sum over earlier questions of hubs x relations-in-use (rounded up to 4): offset of question b's
+//                 hub-by-relation weight block; saturates at INT32_MAX
+// Two launches of one workgroup per question: count, then an ordered compaction behind the earlier questions' counts.
+__global__ __launch_bounds__(256) void k_csr_hub_count(const int32_t* __restrict__ row_ptr, int32_t N,
+                                                       int32_t heavy_deg, int32_t* __restrict__ qcnt) {
+  __shared__ int s[4];
+  const int b = blockIdx.x;
+  const int32_t* rp = row_ptr + (int64_t)b * N;
+  int c = 0;
+  for (int j = threadIdx.x; j < N; j += 256) c += (rp[j + 1] - rp[j]) > heavy_deg ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) qcnt[b] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ __launch_bounds__(256) void k_csr_hub_fill(const int32_t* __restrict__ row_ptr, int32_t N, int32_t B,
+                                                      int32_t heavy_deg, const int32_t* __restrict__ qcnt,
+                                                      const int32_t* __restrict__ rel_off, int32_t* __restrict__ list,
+                                                      int32_t cap, int32_t* __restrict__ count,
+                                                      int32_t* __restrict__ hub_q_off, int32_t* __restrict__ hub_wbase) {
+  __shared__ int s_w[4];
+  __shared__ int s_base;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) {      // a batch has at most a few hundred questions: serial prefix
+    int base = 0;
+    long long wb = 0;
+    for (int q = 0; q < b; ++q) {
+      base += qcnt[q];
+      wb += (long long)qcnt[q] * (((rel_off[q + 1] - rel_off[q]) + 3) & ~3);
+    }
+    s_base = base;
+    hub_q_off[b] = base;
+    hub_wbase[b] = wb > 0x7fffffffLL ? 0x7fffffff : (int)wb;
+    if (b == B - 1) {
+      base += qcnt[b];
+      wb += (long long)qcnt[b] * (((rel_off[b + 1] - rel_off[b]) + 3) & ~3);
+      hub_q_off[B] = base;
+      hub_wbase[B] = wb > 0x7fffffffLL ? 0x7fffffff : (int)wb;
+      *count = base;
+    }
+  }
+  __syncthreads();
+  int run = s_base;
+  const int32_t* rp = row_ptr + (int64_t)b * N;
+  for (int j0 = 0; j0 < N; j0 += 256) {
+    const int j = j0 + tid;
+    const bool on = j < N && (rp[j + 1] - rp[j]) > heavy_deg;
+    const unsigned long long m = __ballot(on);
+    if (lane == 0) s_w[wave] = __popcll(m);
+    __syncthreads();
+    int off = run, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) off += s_w[w];
+      tot += s_w[w];
+    }
+    if (on) {
+      const int pos = off + __popcll(m & ((1ull << lane) - 1));
+      if (pos < cap) list[pos] = (int32_t)((int64_t)b * N + j);
+    }
+    run += tot;
+    __syncthreads();
   }
 }
 
@@ -682,6 +744,16 @@ extern "C" int gnnrag_narrow_tuple(const int64_t* heads, const int64_t* rels, co
   return 0;
 }
 
+static int hub_lists(gnnrag_csr* out, int d, int32_t* qcnt, hipStream_t stream) {
+  hipLaunchKernelGGL(k_csr_hub_count, dim3(out->B), dim3(256), 0, stream, out->row_ptr[d], out->N, (int32_t)kHeavyDeg, qcnt);
+  GNNRAG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_csr_hub_fill, dim3(out->B), dim3(256), 0, stream, out->row_ptr[d], out->N, out->B,
+                     (int32_t)kHeavyDeg, qcnt, out->rel_off, out->heavy[d], out->heavy_cap, out->n_heavy + d,
+                     out->hub_q_off[d], out->hub_wbase[d]);
+  GNNRAG_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" size_t gnnrag_csr_bytes(int64_t F, int32_t B, int32_t N, int32_t R1, int has_w_gnn, int has_w_rel) {
   if (F < 0 || B <= 0 || N <= 0 || R1 <= 0) return 0;
   return csr_layout(F, B, N, R1, has_w_gnn, has_w_rel).total;
@@ -727,6 +799,10 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
   out->edge_m = (int32_t*)(base + L.edge_m);
   out->m_from = (int32_t*)(base + L.m_from);
   out->m_dst = (int32_t*)(base + L.m_dst);
+  for (int d = 0; d < 2; ++d) {
+    out->hub_q_off[d] = (int32_t*)(base + L.hub_q_off[d]);
+    out->hub_wbase[d] = (int32_t*)(base + L.hub_wbase[d]);
+  }
   out->rel_rows = (int32_t*)(base + L.rel_rows);
   out->n_heavy = (int32_t*)(base + L.n_heavy);
   out->n_chunks = out->n_heavy + 2;
@@ -782,10 +858,7 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
     hipLaunchKernelGGL(k_csr_row_ptr, dim3(nb_rows), dim3(256), 0, stream, keys_sorted, F, BN,
                        out->row_ptr[d]);
     GNNRAG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_csr_heavy, dim3((int)((BN + 255) / 256)), dim3(256), 0, stream,
-                       out->row_ptr[d], BN, (int32_t)kHeavyDeg, out->heavy[d], out->heavy_cap,
-                       out->n_heavy + d);
-    GNNRAG_LAUNCH_CHECK();
+    GNNRAG_RC(hub_lists(out, d, (int32_t*)(base + L.hub_qcnt), stream));
     if (F > 0) {
       // hub rows in relation order (see hub_sort_scratch): fact ids of the hub rows re-sorted by relation, stable
       const int nb = (int)((F + 255) / 256);
@@ -860,6 +933,10 @@ static void csr_bind(gnnrag_csr* out, char* base, const CsrLayout& L, int64_t F,
   out->edge_m = (int32_t*)(base + L.edge_m);
   out->m_from = (int32_t*)(base + L.m_from);
   out->m_dst = (int32_t*)(base + L.m_dst);
+  for (int d = 0; d < 2; ++d) {
+    out->hub_q_off[d] = (int32_t*)(base + L.hub_q_off[d]);
+    out->hub_wbase[d] = (int32_t*)(base + L.hub_wbase[d]);
+  }
   out->rel_rows = (int32_t*)(base + L.rel_rows);
   out->n_heavy = (int32_t*)(base + L.n_heavy);
   out->n_chunks = out->n_heavy + 2;
@@ -929,9 +1006,7 @@ extern "C" int gnnrag_csr_concat(const gnnrag_csr* const* parts, int32_t B, int3
                      (int32_t)F, (int32_t)RT);
   GNNRAG_LAUNCH_CHECK();
   for (int d = 0; d < 2; ++d) {
-    hipLaunchKernelGGL(k_csr_heavy, dim3((int)((BN + 255) / 256)), dim3(256), 0, stream, out->row_ptr[d], BN,
-                       (int32_t)kHeavyDeg, out->heavy[d], out->heavy_cap, out->n_heavy + d);
-    GNNRAG_LAUNCH_CHECK();
+    GNNRAG_RC(hub_lists(out, d, (int32_t*)((char*)csr_mem + L.hub_qcnt), stream));
   }
   hipLaunchKernelGGL(k_csr_heavy_chunks, dim3(2), dim3(1024), 0, stream, out->row_ptr[0], out->row_ptr[1],
                      out->heavy[0], out->heavy[1], out->n_heavy, out->heavy_cap, out->chunk_off[0],

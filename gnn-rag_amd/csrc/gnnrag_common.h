@@ -19,6 +19,12 @@
     if (e_ != hipSuccess) return (int)e_;              \
   } while (0)
 
+#define GNNRAG_RC(call)                                \
+  do {                                                 \
+    const int rc_ = (call);                            \
+    if (rc_) return rc_;                               \
+  } while (0)
+
 namespace gnnrag {
 
 constexpr int kWave = 64;            // CDNA wavefront

@@ -311,8 +311,9 @@ class CsrPlan:
         nh = self._view(self.c.n_heavy, 2, torch.int32).numpy()
         out["n_heavy"] = nh
         for d in (0, 1):
-            out["heavy%d" % d] = np.sort(self._view(self.c.heavy[d], int(min(nh[d], self.c.heavy_cap)),
-                                                    torch.int32).numpy())
+            out["heavy%d" % d] = self._view(self.c.heavy[d], int(min(nh[d], self.c.heavy_cap)), torch.int32).numpy()
+            out["hub_q_off%d" % d] = self._view(self.c.hub_q_off[d], self.B + 1, torch.int32).numpy()
+            out["hub_wbase%d" % d] = self._view(self.c.hub_wbase[d], self.B + 1, torch.int32).numpy()
         for key, t in self._w.items():
             if isinstance(key, str):
                 out[key] = t.cpu().numpy()

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GNNRAG_ABI_VERSION 10
+#define GNNRAG_ABI_VERSION 11
 
 #define GNNRAG_E_BADARG      (-1)  /* null pointer / negative size / inconsistent sizes   */
 #define GNNRAG_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set (see DESIGN)  */
@@ -47,8 +47,10 @@ typedef void* gnnrag_stream_t; /* hipStream_t */
 /* Destination-sorted structure of one batch of question subgraphs, both directions.
  * Replaces the 7 COO tensors of BaseGNNLayer.build_matrix (base_gnn.py:19-51), of which
  * ReaRev uses fact2tail/head2fact (forward) and fact2head/tail2fact (inverse).
- * Facts of one destination are stored in ascending fact id, so every sum has one fixed
- * order (bit-reproducible, independent of how a batch is sharded over GPUs). */
+ * Facts of one destination are stored in ascending fact id - except hub rows (more than heavy_deg
+ * facts), which are stored in ascending (relation id, fact id) so that the walk can add the priors of
+ * a run of equal relations and fetch the run's table row once - so every sum has one fixed order
+ * (bit-reproducible, independent of how a batch is sharded over GPUs). */
 typedef struct gnnrag_csr {
   int32_t B;            /* questions in the batch                                          */
   int32_t N;            /* max_local_entity: node slots per question                       */
@@ -62,7 +64,7 @@ typedef struct gnnrag_csr {
                                       base_gnn.py:38-47) or NULL                           */
   float*   w_rel[2];    /* [F] weight_rel_list (TypeLayer norm_rel, layer_init.py:39-40)
                                       or NULL                                              */
-  int32_t* heavy[2];    /* [heavy_cap] list of heavy destination nodes                     */
+  int32_t* heavy[2];    /* [heavy_cap] list of heavy destination nodes, ascending          */
   int32_t* chunk_off[2];/* [heavy_cap+1] first 256-fact chunk of each heavy node (prefix)  */
   int32_t* n_heavy;     /* [2] device counters: heavy nodes per direction                  */
   int32_t* n_chunks;    /* [2] device counters: heavy chunks per direction                 */
@@ -92,6 +94,11 @@ typedef struct gnnrag_csr {
   int32_t* m_from;      /* [2F]                                                                 */
   int32_t* m_dst;       /* [2F]  destination node of every merged record (the streaming walk cuts the stream into
                                  equal fact ranges and finds the row boundaries in it)                  */
+  /* Dense hub form of the gather walk (tables larger than LDS): the hubs of question b are the list entries
+   * hub_q_off[d][b] .. hub_q_off[d][b+1]; hub_wbase[d][b] = sum over earlier questions of hubs x relations in use
+   * (rounded up to 4) = offset of the question's hub-by-relation weight block (saturates at INT32_MAX). */
+  int32_t* hub_q_off[2];/* [B+1]                                                                */
+  int32_t* hub_wbase[2];/* [B+1]                                                                */
 } gnnrag_csr;
 
 /* Bytes of caller-owned device memory a gnnrag_csr needs (persistent part / build scratch). */

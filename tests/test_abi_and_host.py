@@ -35,12 +35,12 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, n), "missing export: " + n
         assert n in _lib.SIGNATURES, "binding lacks a signature for " + n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.gnnrag_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.gnnrag_abi_version() == _lib.ABI_VERSION == 11
     assert b"bad argument" in lib.gnnrag_error_string(-1)
 
 
 def test_size_queries_and_struct_layout(lib):
-    assert ctypes.sizeof(_lib.CsrStruct) == 4 * 4 + 8 + 8 * 2 * 7 + 8 * 2 + 8 + 8 * 2 + 8 + 8 * 2 + 8 * 2 + 8 + 8 * 3
+    assert ctypes.sizeof(_lib.CsrStruct) == 4 * 4 + 8 + 8 * 2 * 7 + 8 * 2 + 8 + 8 * 2 + 8 + 8 * 2 + 8 * 2 + 8 + 8 * 3 + 8 * 4
     n = lib.gnnrag_csr_bytes(768000, 64, 2000, 602, 0, 0)
     # 2 row_ptr arrays + 2 x (edge 8 B + compact-relation edge 8 B + perm 4 B) per fact, plus small
     # lists + one int per node for the per-question big-node lists + (question, relation) rows

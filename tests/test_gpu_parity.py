@@ -58,7 +58,10 @@ def test_csr_plan_bit_exact(dev, name):
         np.testing.assert_array_equal(got["w_gnn"][d], (wl * wl)[want["perm%d" % d]])
         np.testing.assert_array_equal(got["w_rel"][d], wrl[want["perm%d" % d]])
         deg = np.diff(want["row_ptr%d" % d])
-        np.testing.assert_array_equal(got["heavy%d" % d], np.flatnonzero(deg > 256).astype(np.int32))
+        hubs = np.flatnonzero(deg > 256)
+        np.testing.assert_array_equal(got["heavy%d" % d], hubs.astype(np.int32))     # ascending: question by question
+        per_q = np.bincount(hubs // cfg.N, minlength=cfg.B)
+        np.testing.assert_array_equal(got["hub_q_off%d" % d], np.concatenate([[0], np.cumsum(per_q)]))
         assert got["n_chunks"][d] == int(np.ceil(deg[deg > 256] / 256).sum())
     deg2 = np.maximum(np.diff(want["row_ptr0"]), np.diff(want["row_ptr1"])).reshape(cfg.B, cfg.N)
     for b in range(cfg.B):
@@ -69,6 +72,9 @@ def test_csr_plan_bit_exact(dev, name):
     cnt = np.bincount(pairs[:, 0], minlength=cfg.B) if len(pairs) else np.zeros(cfg.B, np.int64)
     np.testing.assert_array_equal(got["rel_off"], np.concatenate([[0], np.cumsum(cnt)]))
     assert plan.rel_total == len(pairs) and plan.rel_max == int(cnt.max())
+    for d in (0, 1):        # offsets of the per-question hub-by-relation weight blocks (dense hub form of the gather walk)
+        per_q = np.diff(got["hub_q_off%d" % d])
+        np.testing.assert_array_equal(got["hub_wbase%d" % d], np.concatenate([[0], np.cumsum(per_q * ((cnt + 3) // 4 * 4))]))
     for d in (0, 1):
         e, el = got["edge%d" % d], got["edge_l%d" % d]
         np.testing.assert_array_equal(el[:, 0], e[:, 0])
