@@ -120,6 +120,7 @@ struct WalkArgs {
   float* hub_w;
   long long hub_w_cap;
   int2* hub_bnd;
+  int32_t hub_ks;             // relation ranges a question's dense product is cut into (one workgroup each)
   int32_t dir;                // k_heavy_reduce in read-modify-write modes: direction of this launch
   int32_t heavy_only;         // host side: the light rows were already walked by another kernel
   const int32_t* big_cnt;     // LDS walk: per-question count / list of nodes with > big_deg facts in a direction
@@ -251,8 +252,20 @@ __device__ __forceinline__ void load_fact(const int2* __restrict__ edge, const f
 
 // dense hub form: on when the caller handed a weight buffer that holds both directions' hub-by-relation blocks (the
 // sizes live on the device: every kernel of either form is launched and the form not in use returns at once)
+// (the buffer holds the weight blocks and, behind them, hub_ks partial rows per hub: see hub_part)
+__device__ __forceinline__ long long hub_w_total(const WalkArgs& a) {
+  return (long long)a.hub_wbase[0][a.B] + (long long)a.hub_wbase[1][a.B];
+}
 __device__ __forceinline__ bool hub_dense_on(const WalkArgs& a) {
-  return a.hub_w != nullptr && (long long)a.hub_wbase[0][a.B] + (long long)a.hub_wbase[1][a.B] <= a.hub_w_cap;
+  if (a.hub_w == nullptr) return false;
+  const long long hubs = (long long)min(a.n_heavy[0], a.heavy_cap) + min(a.n_heavy[1], a.heavy_cap);
+  return hub_w_total(a) + hubs * a.hub_ks * a.D <= a.hub_w_cap;
+}
+// partial output row of hub entry e (direction d) from relation range ks
+__device__ __forceinline__ float* hub_part(const WalkArgs& a, int ks, int d, int e) {
+  const long long hubs = (long long)min(a.n_heavy[0], a.heavy_cap) + min(a.n_heavy[1], a.heavy_cap);
+  const long long eg = (d ? min(a.n_heavy[0], a.heavy_cap) : 0) + e;
+  return a.hub_w + hub_w_total(a) + ((long long)ks * hubs + eg) * a.D;
 }
 
 // Hub rows are stored in relation order (csr_plan.hip, hub_sort_scratch): a run of adjacent facts of one relation is
@@ -427,7 +440,7 @@ __global__ __launch_bounds__(256) void k_walk_light(const WalkArgs a) {
           if (cv[m] && (!(GNNRAG_LIGHT_ABL & 2) || vfirst(acc[0][m]) == 12345.f)) {
             V v = acc[0][m];
             if (MODE == MODE_TYPE && fin) v = vrelu(v);
-            vstore<VEC>(a.out + (size_t)n * D + col[m], v);
+            vstore<VEC>(a.out + (size_t)n * D + col[m], v);   // (non-temporal stores: no difference, 756 vs 757 us at C5)
           }
       }
     }
@@ -662,21 +675,23 @@ __global__ __launch_bounds__(256) void k_hub_weights(const WalkArgs a) {
   }
 }
 
-constexpr int kHubWaves = 8;   // waves of a k_hub_dense workgroup: they split the relations
-constexpr int kHubCols = 32;   // columns of a workgroup (two MFMA column tiles)
+constexpr int kHubWaves = 8;   // waves of a k_hub_dense workgroup: 32 columns each (7 of them at D = 200)
 
-// MT tiles of 16 hubs x 32 columns of one question: every table row piece is loaded once for all MT tiles
+// MT tiles of 16 hubs x the wave's 32 columns over the k groups [kg_beg, kg_end) of one question: every table row piece
+// is loaded once for all MT tiles
 template <int MT>
-__device__ __forceinline__ void hub_dense_tiles(const WalkArgs& a, float (*s_part)[3][2][64][4], int d, int e0, int nh,
-                                                int h0, const float* __restrict__ Wq, const float* __restrict__ Pq,
-                                                int nrel, int nrel4, int c0) {
+__device__ __forceinline__ void hub_dense_tiles(const WalkArgs& a, int ks, int d, int e0, int nh, int h0,
+                                                const float* __restrict__ Wq, const float* __restrict__ Pq, int nrel,
+                                                int nrel4, int kg_beg, int kg_end) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int D = a.D;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   // Column tile nt holds the columns c0 + 2 j + nt (j = 0..15): lane (fr, fg) needs P[k][c0 + 2 fr + nt], nt = 0, 1 -
-  // ONE 8-byte load per relation row, 128 contiguous bytes across the 16 lanes of a row.
-  const int cb = c0 + 2 * fr;                      // this lane's two columns (D % 4 == 0: both in or both out)
+  // ONE 8-byte load per relation row, 128 contiguous bytes across the 16 lanes of a row; the workgroup's waves read a
+  // row's whole 4 D bytes at the same moment.
+  const int cb = wave * 32 + 2 * fr;               // this lane's two columns (D % 4 == 0: both in or both out)
+  if (wave * 32 >= D) return;                      // (no barrier in this function)
   const bool cok = cb < D;
   const int cbl = cok ? cb : D - 2;                // loads are unconditional (clamped): no branch, no wait between them
   const float* wrow[MT];
@@ -685,22 +700,22 @@ __device__ __forceinline__ void hub_dense_tiles(const WalkArgs& a, float (*s_par
   f32x4 acc[MT][2];
 #pragma unroll
   for (int i = 0; i < MT; ++i) acc[i][0] = acc[i][1] = zero4;
-  const int nkg = (nrel4 + 15) >> 4;
   // A lane (fr, fg): weights of hub fr for the relations k .. k + 3, k = 16 kg + 4 fg (one 16-byte load).  MFMA e of a
   // group contracts the relations {16 kg + 4 fg + e}: any split of k is fine as long as A and B agree.
   constexpr int U = MT == 1 ? 4 : 2;
-  for (int kg0 = wave; kg0 < nkg; kg0 += U * kHubWaves) {
+  for (int kg0 = kg_beg; kg0 < kg_end; kg0 += U) {
     f32x4 av[U][MT];
     f32x2 bv[U][4];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      // past the question's relations the WEIGHTS are zero (zeroed padding / the select below); the table rows are
-      // then read from the last row instead of being zeroed: 0 x finite
-      const int k = (kg0 + kHubWaves * u) * 16 + fg * 4;
+      // past the range / the question's relations the WEIGHTS are zero (select below, zeroed padding); the table rows
+      // are then read from the last row instead of being zeroed: 0 x finite
+      const bool on = kg0 + u < kg_end;
+      const int k = (kg0 + u) * 16 + fg * 4;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const f32x4 w4 = *reinterpret_cast<const f32x4*>(wrow[i] + min(k, nrel4 - 4));
-        av[u][i] = k < nrel4 ? w4 : zero4;
+        av[u][i] = (on && k < nrel4) ? w4 : zero4;
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -718,58 +733,41 @@ __device__ __forceinline__ void hub_dense_tiles(const WalkArgs& a, float (*s_par
           for (int nt = 0; nt < 2; ++nt)
             acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i][e], bv[u][e][nt], acc[i][nt], 0, 0, 0);
   }
-  if (wave > 0) {
+  // C layout: lane (fr, fg) holds hubs 4 fg + r of column slot fr, i.e. column c0 + 2 fr + nt of tile nt
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<f32x4*>(&s_part[wave - 1][i][nt][lane][0]) = acc[i][nt];
-  }
-  __syncthreads();
-  if (wave == 0) {
-    // C layout: lane (fr, fg) holds hubs 4 fg + r of column slot fr, i.e. column c0 + 2 fr + nt of tile nt
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      f32x4 v[2];
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        v[nt] = acc[i][nt];
-#pragma unroll
-        for (int w = 0; w < kHubWaves - 1; ++w) v[nt] += *reinterpret_cast<const f32x4*>(&s_part[w][i][nt][lane][0]);
-      }
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int m = h0 + i * 16 + fg * 4 + rr;
-        if (m < nh && cok) {
-          const int slot = a.chunk_off[d][e0 + m];       // the hub's first chunk slot of the partial-sum scratch
-          const f32x2 o = {v[0][rr], v[1][rr]};
-          *reinterpret_cast<f32x2*>(a.partial + ((size_t)d * a.max_chunks + slot) * D + cb) = o;
-        }
+    for (int rr = 0; rr < 4; ++rr) {
+      const int m = h0 + i * 16 + fg * 4 + rr;
+      if (m < nh && cok) {
+        const f32x2 o = {acc[i][0][rr], acc[i][1][rr]};
+        *reinterpret_cast<f32x2*>(hub_part(a, ks, d, e0 + m) + cb) = o;
       }
     }
-  }
-  __syncthreads();
 }
 
+// One workgroup per (relation range, question, direction): its waves cover the D columns, so the range's table rows are
+// read once, as whole rows, for all hubs of the question (48 at a time), and the weight columns of the range once per
+// wave (L1).  The hub_ks partial rows of a hub are added in range order by k_hub_finish.  (Two earlier forms are in
+// workgroups per (16 hubs, 64 columns) re-read the table per hub tile, workgroups per 32-column group read
+// 128-byte pieces of 800-byte rows - 141 and 94 us against the ~15 us of the MFMAs at BASELINE config 5.)
 __global__ __launch_bounds__(64 * kHubWaves) void k_hub_dense(const WalkArgs a) {
   if (!hub_dense_on(a)) return;
-  __shared__ __attribute__((aligned(16))) float s_part[kHubWaves - 1][3][2][64][4];   // [wave 1..][hub tile][column tile][lane][4 hubs]
-  const int D = a.D, ncg = (D + kHubCols - 1) / kHubCols;
-  // one workgroup per (question, direction, 32-column group): 7 x 32 of them with hubs at BASELINE config 5 - one per
-  // CU, every table row piece loaded once.  (A first version, one workgroup per (16 hubs, 64 columns), had 384 uneven
-  // workgroups re-reading the table per hub tile: 141 us against the ~35 us of its MFMAs.)
   const int item = blockIdx.x;
-  const int cg = item % ncg, q = (item / ncg) % a.B, d = item / (ncg * a.B);
+  const int ks = item % a.hub_ks, q = (item / a.hub_ks) % a.B, d = item / (a.hub_ks * a.B);
   const int e0 = a.hub_q_off[d][q], nh = a.hub_q_off[d][q + 1] - e0;
   if (nh <= 0) return;
   const int nrel = a.rel_off[q + 1] - a.rel_off[q], nrel4 = (nrel + 3) & ~3;
   const float* Wq = a.hub_w + (d ? a.hub_wbase[0][a.B] : 0) + a.hub_wbase[d][q];
-  const float* Pq = a.T[d] + (size_t)a.rel_off[q] * D;
-  const int c0 = cg * kHubCols;
+  const float* Pq = a.T[d] + (size_t)a.rel_off[q] * a.D;
+  const int nkg = (nrel4 + 15) >> 4;
+  const int per = (nkg + a.hub_ks - 1) / a.hub_ks;
+  const int kg_beg = min(ks * per, nkg), kg_end = min(kg_beg + per, nkg);     // (an empty range still writes its zero rows)
   for (int h0 = 0; h0 < nh; h0 += 48) {
     const int left = nh - h0;
-    if (left > 32) hub_dense_tiles<3>(a, s_part, d, e0, nh, h0, Wq, Pq, nrel, nrel4, c0);
-    else if (left > 16) hub_dense_tiles<2>(a, s_part, d, e0, nh, h0, Wq, Pq, nrel, nrel4, c0);
-    else hub_dense_tiles<1>(a, s_part, d, e0, nh, h0, Wq, Pq, nrel, nrel4, c0);
+    if (left > 32) hub_dense_tiles<3>(a, ks, d, e0, nh, h0, Wq, Pq, nrel, nrel4, kg_beg, kg_end);
+    else if (left > 16) hub_dense_tiles<2>(a, ks, d, e0, nh, h0, Wq, Pq, nrel, nrel4, kg_beg, kg_end);
+    else hub_dense_tiles<1>(a, ks, d, e0, nh, h0, Wq, Pq, nrel, nrel4, kg_beg, kg_end);
   }
 }
 
@@ -791,7 +789,10 @@ __global__ __launch_bounds__(1024) void k_hub_finish(const WalkArgs a) {
     const float* Pq = a.T[d] + (size_t)a.rel_off[q] * D;
     for (int x0 = 0; x0 < D; x0 += 256) {
       const int x = x0 + tx;
-      float s = 0.f;
+      float s = 0.f, dense = 0.f;
+      if (grp == 0 && x < D) {                       // the dense product's partial rows, in range order
+        for (int ks = 0; ks < a.hub_ks; ++ks) dense += hub_part(a, ks, d, e)[x];
+      }
       if (x < D) {
         int c = cb;
         for (; c + 8 <= ce; c += 8) {                // 8 boundary records and their table rows in flight, added in chunk order
@@ -812,7 +813,7 @@ __global__ __launch_bounds__(1024) void k_hub_finish(const WalkArgs a) {
       if (grp > 0) s_q[grp - 1][tx] = s;
       __syncthreads();
       if (grp == 0 && x < D)
-        a.out[(size_t)n * D + x] += a.partial[((size_t)d * a.max_chunks + c0) * D + x] + (((s + s_q[0][tx]) + s_q[1][tx]) + s_q[2][tx]);
+        a.out[(size_t)n * D + x] += dense + (((s + s_q[0][tx]) + s_q[1][tx]) + s_q[2][tx]);
       __syncthreads();
     }
   }
@@ -1590,8 +1591,7 @@ static int launch_one(WalkArgs a, hipStream_t stream) {
       GNNRAG_LAUNCH_CHECK();
       hipLaunchKernelGGL(k_hub_weights, dim3(2048, 2), dim3(256), 0, stream, a);
       GNNRAG_LAUNCH_CHECK();
-      const int items = ((a.D + kHubCols - 1) / kHubCols) * a.B * 2;
-      hipLaunchKernelGGL(k_hub_dense, dim3(items), dim3(64 * kHubWaves), 0, stream, a);
+      hipLaunchKernelGGL(k_hub_dense, dim3(a.hub_ks * a.B * 2), dim3(64 * kHubWaves), 0, stream, a);
       GNNRAG_LAUNCH_CHECK();
     }
   }
@@ -1865,7 +1865,8 @@ int gnnrag::aggregate_fused_dirs(const gnnrag_csr* csr, const float* dist, const
     }
   }
   const int variant = gnnrag_aggregate_fused_variant(csr, D);
-  if (variant == GNNRAG_WALK_L2_GATHER && (D & 3) == 0 && hub_dense_enabled() && csr->hub_q_off[0] && csr->hub_wbase[0]) {
+  if (variant == GNNRAG_WALK_L2_GATHER && (D & 3) == 0 && D <= 32 * kHubWaves && hub_dense_enabled() && csr->hub_q_off[0] &&
+      csr->hub_wbase[0]) {
     // dense hub form: boundary records and weight blocks live where the LDS walk keeps its prior pairs (unused by the
     // gather walk); whether the blocks fit is decided on the device (hub_dense_on)
     const size_t used = partial_bytes(csr, D, 1), avail = prior_bytes(csr);
@@ -1879,6 +1880,9 @@ int gnnrag::aggregate_fused_dirs(const gnnrag_csr* csr, const float* dist, const
       a.hub_w = (float*)((char*)workspace + used + bnd_bytes);
       const size_t cap = (avail - bnd_bytes) / sizeof(float);
       a.hub_w_cap = (long long)(cap < ((size_t)1 << 30) ? cap : ((size_t)1 << 30));
+      // about two workgroups per CU when one direction has hubs in every question (BASELINE config 5)
+      const int ks = 1024 / (2 * csr->B);
+      a.hub_ks = ks < 1 ? 1 : ks > 16 ? 16 : ks;
     }
   }
   switch (variant) {
