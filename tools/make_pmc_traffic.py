@@ -45,7 +45,7 @@ def main(fetch_db, write_db, out, workload="C2"):
            "kernel_sources_sha256": bench.kernel_sources_digest(),
            "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests at 64 B)"}
     f, w = group(lambda k: "k_walk_slice" in k or "k_fact_prior" in k or ("k_walk_light" in k and "ILi2E" in k)
-                 or ("k_heavy" in k and "ILi2E" in k))
+                 or ("k_heavy" in k and "ILi2E" in k) or "k_hub_" in k)
     res.update(aggregate_fused_fetch_bytes_raw=f, aggregate_fused_write_bytes=w,
                aggregate_fused_hbm_bytes_per_launch=2 * f + w)
     # the seed-prior (frontier) form of layer 0: frontier + table rows + neighbour sums of the frontier
