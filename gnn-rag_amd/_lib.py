@@ -27,7 +27,7 @@ class CsrStruct(C.Structure):
         ("n_heavy", C.c_void_p), ("n_chunks", C.c_void_p),
         ("heavy_cap", C.c_int32), ("max_chunks", C.c_int32),
         ("big_cnt", C.c_void_p), ("big_nodes", C.c_void_p),
-        ("big_deg", C.c_int32), ("reserved_", C.c_int32),
+        ("big_deg", C.c_int32), ("hub_sorted", C.c_int32),
         ("edge_l", C.c_void_p * 2), ("rel_off", C.c_void_p), ("rel_rows", C.c_void_p),
         ("rel_total", C.c_int32), ("rel_max", C.c_int32),
         ("edge_m", C.c_void_p), ("m_from", C.c_void_p), ("m_dst", C.c_void_p),

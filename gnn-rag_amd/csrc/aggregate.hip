@@ -1865,8 +1865,8 @@ int gnnrag::aggregate_fused_dirs(const gnnrag_csr* csr, const float* dist, const
     }
   }
   const int variant = gnnrag_aggregate_fused_variant(csr, D);
-  if (variant == GNNRAG_WALK_L2_GATHER && (D & 3) == 0 && D <= 32 * kHubWaves && hub_dense_enabled() && csr->hub_q_off[0] &&
-      csr->hub_wbase[0]) {
+  if (variant == GNNRAG_WALK_L2_GATHER && (D & 3) == 0 && D <= 32 * kHubWaves && hub_dense_enabled() && csr->hub_sorted &&
+      csr->hub_q_off[0] && csr->hub_wbase[0]) {
     // dense hub form: boundary records and weight blocks live where the LDS walk keeps its prior pairs (unused by the
     // gather walk); whether the blocks fit is decided on the device (hub_dense_on)
     const size_t used = partial_bytes(csr, D, 1), avail = prior_bytes(csr);

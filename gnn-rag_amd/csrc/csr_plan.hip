@@ -105,6 +105,11 @@ static size_t seg_sort_temp_bytes(int64_t F, int32_t segments, unsigned bits) {
   return bytes;
 }
 
+// A vocabulary of at most kHubSortMinR1 table rows always fits the LDS walk (aggregate.hip, slice_walk_fits: 2 (R1 + 1)
+// 64-byte rows + 4.5 KB <= 159 KB), so the hub rows of such a structure are never walked by the gather kernels: they keep
+// the fact order and the build skips the sort (0.4 ms of a 1.5 ms build at BASELINE config 2).
+constexpr int kHubSortMinR1 = 1024;
+
 struct HubSortScratch {
   size_t key_in, key_out, perm2, seg, temp, total;
 };
@@ -118,6 +123,10 @@ static HubSortScratch hub_sort_scratch(int64_t F, int32_t R1, int32_t heavy_cap)
     off = align_up(off + bytes, 256);
     return o;
   };
+  if (R1 <= kHubSortMinR1) {
+    H.key_in = H.key_out = H.perm2 = H.seg = H.temp = H.total = 0;
+    return H;
+  }
   H.key_in = take(Fp * sizeof(uint32_t));
   H.key_out = take(Fp * sizeof(uint32_t));
   H.perm2 = take(Fp * sizeof(int32_t));
@@ -785,6 +794,7 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
   out->B = B; out->N = N; out->R1 = R1; out->F = F;
   out->heavy_deg = kHeavyDeg;
   out->heavy_cap = L.heavy_cap;
+  out->hub_sorted = R1 > kHubSortMinR1 ? 1 : 0;
   for (int d = 0; d < 2; ++d) {
     out->row_ptr[d] = (int32_t*)(base + L.row_ptr[d]);
     out->edge[d] = (int32_t*)(base + L.edge[d]);
@@ -859,7 +869,7 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
                        out->row_ptr[d]);
     GNNRAG_LAUNCH_CHECK();
     GNNRAG_RC(hub_lists(out, d, (int32_t*)(base + L.hub_qcnt), stream));
-    if (F > 0) {
+    if (F > 0 && R1 > kHubSortMinR1) {
       // hub rows in relation order (see hub_sort_scratch): fact ids of the hub rows re-sorted by relation, stable
       const int nb = (int)((F + 255) / 256);
       uint32_t* key_in = (uint32_t*)(hub_base + H.key_in);
@@ -879,6 +889,9 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
                                                      (unsigned)L.heavy_cap, (const int32_t*)seg_begin,
                                                      (const int32_t*)seg_end, 0u, key_bits((size_t)R1), stream, false));
       GNNRAG_HIP(hipMemcpyAsync(out->perm[d], perm2, (size_t)F * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+    }
+    if (F > 0) {
+      const int nb = (int)((F + 255) / 256);
       hipLaunchKernelGGL(k_csr_fill, dim3(nb), dim3(256), 0, stream, out->perm[d], src, rels, w_gnn,
                          w_rel, F, g2l, (int64_t)B * R1, N, R1, (int2*)out->edge[d], (int2*)out->edge_l[d],
                          out->w_gnn[d], out->w_rel[d]);
@@ -964,6 +977,8 @@ extern "C" int gnnrag_csr_concat(const gnnrag_csr* const* parts, int32_t B, int3
   const CsrLayout L = csr_layout(F, B, N, R1, false, false);
   if (csr_bytes < L.total) return GNNRAG_E_WORKSPACE;
   csr_bind(out, (char*)csr_mem, L, F, B, N, R1, false, false);
+  out->hub_sorted = 1;
+  for (int b = 0; b < B; ++b) out->hub_sorted &= parts[b]->hub_sorted;
   GNNRAG_HIP(hipMemsetAsync(out->big_cnt, 0, (size_t)B * sizeof(int32_t), stream));
   GNNRAG_HIP(hipMemsetAsync(out->n_heavy, 0, 8 * sizeof(int32_t), stream));
   ConcatArgs a;

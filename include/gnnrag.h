@@ -73,7 +73,7 @@ typedef struct gnnrag_csr {
   int32_t* big_cnt;     /* [B]    nodes of each question with > big_deg facts in a direction */
   int32_t* big_nodes;   /* [B][N] their node ids (order irrelevant)                         */
   int32_t  big_deg;
-  int32_t  reserved_;
+  int32_t  hub_sorted;  /* 1: hub rows are in (relation, fact id) order (built with R1 > 1024), 0: fact order   */
   /* Per-question relation compaction (fused path).  A question's subgraph touches a small part of
    * the KB's relation vocabulary (hundreds of Freebase's ~6k relations), so its relation tables
    * are built over the relations it USES: compact row rel_off[b] + j  <->  (b, j-th smallest
