@@ -28,9 +28,10 @@ namespace gnnrag {
 
 constexpr int kFrThreads = 1024;
 constexpr int kFrSeedCap = 2048;          // seeds of one question kept in LDS; more -> the whole question is flagged
+constexpr int kFrAltSeeds = 32;           // up to this many seeds of a question are also listed (ascending) for the walk
 
 struct FrontierWs {                        // offsets into the caller's frontier workspace
-  size_t counts, row_flag, rows, tflag, trows, total;
+  size_t counts, row_flag, rows, tflag, trows, seeds, seedinfo, total;
 };
 
 static FrontierWs frontier_ws(const gnnrag_csr* csr) {
@@ -44,6 +45,8 @@ static FrontierWs frontier_ws(const gnnrag_csr* csr) {
   w.rows = take(BN * sizeof(int32_t));
   w.tflag = take(RT + 64);
   w.trows = take(RT * sizeof(int32_t));
+  w.seeds = take((size_t)csr->B * kFrAltSeeds * sizeof(int32_t));   // a question's seeds in ascending order ...
+  w.seedinfo = take((size_t)2 * csr->B * sizeof(int32_t));          // ... their number (-1: more than listed) and facts
   w.total = off;
   return w;
 }
@@ -53,8 +56,9 @@ __global__ __launch_bounds__(kFrThreads) void k_frontier_build(
     const float* __restrict__ dist, const int32_t* __restrict__ rp0, const int32_t* __restrict__ rp1,
     const int2* __restrict__ el0, const int2* __restrict__ el1, const int32_t* __restrict__ rel_off, int N,
     uint8_t* __restrict__ row_flag, int32_t* __restrict__ rows, uint8_t* __restrict__ tflag,
-    int32_t* __restrict__ trows, int32_t* __restrict__ counts, float* __restrict__ zero_a, long long zero_na,
-    float* __restrict__ zero_b, long long zero_nb) {
+    int32_t* __restrict__ trows, int32_t* __restrict__ counts, int32_t* __restrict__ seeds,
+    int32_t* __restrict__ seedinfo, float* __restrict__ zero_a, long long zero_na, float* __restrict__ zero_b,
+    long long zero_nb) {
   __shared__ int s_seed[kFrSeedCap];
   __shared__ int s_ns, s_wsum[kFrThreads / 64];
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -77,6 +81,28 @@ __global__ __launch_bounds__(kFrThreads) void k_frontier_build(
   }
   __syncthreads();
   const int ns = s_ns;
+  if (tid == 0) {
+    // the seeds in ascending order and the number of facts that touch them, for k_walk_frontier: a listed HUB finds its
+    // few facts from a seed in the seeds' short rows instead of scanning its own (the LDS list is in atomic order)
+    int cnt = -1, facts = 0;
+    if (ns <= kFrAltSeeds) {
+      cnt = ns;
+      for (int i = 1; i < ns; ++i) {
+        const int v = s_seed[i];
+        int j = i - 1;
+        for (; j >= 0 && s_seed[j] > v; --j) s_seed[j + 1] = s_seed[j];
+        s_seed[j + 1] = v;
+      }
+      for (int i = 0; i < ns; ++i) {
+        const int sn = s_seed[i];
+        seeds[g * kFrAltSeeds + i] = sn;
+        facts += (rp0[sn + 1] - rp0[sn]) + (rp1[sn + 1] - rp1[sn]);
+      }
+    }
+    seedinfo[2 * g] = cnt;
+    seedinfo[2 * g + 1] = facts;
+  }
+  __syncthreads();
   if (ns > kFrSeedCap) {                   // not a seed distribution: everything is frontier
     for (int i = tid; i < N; i += kFrThreads) row_flag[n0 + i] = 1;
     for (int i = tid; i < Rg; i += kFrThreads) tflag[roff + i] = 1;
@@ -234,6 +260,8 @@ struct WalkFrArgs {
   const int32_t* rows;        // listed nodes: question g's at rows[g * N ..]
   const int32_t* counts;      // [B][2]
   float* out;                 // [BN + 1, D]; only the listed rows are written
+  const int32_t* seeds;       // [B][kFrAltSeeds] a question's seeds, ascending
+  const int32_t* seedinfo;    // [B][2] their number (-1: not listed) and the facts that touch them
   int64_t F;
   int32_t N, D, rel_total, B;
 };
@@ -241,6 +269,7 @@ struct WalkFrArgs {
 constexpr int kWfThreads = 256;
 constexpr int kWfPer = 8;                  // records per thread and pass
 constexpr int kWfCap = kWfThreads * kWfPer;
+constexpr int kWfAltMin = 4096;            // rows longer than this may be resolved from the seeds' side
 
 // Work item = (question, k-th listed node): blocks (g, k), k, k + per_q, ... - no global list, no atomics.
 __global__ __launch_bounds__(kWfThreads) void k_walk_frontier(WalkFrArgs a, int per_q) {
@@ -260,7 +289,42 @@ __global__ __launch_bounds__(kWfThreads) void k_walk_frontier(WalkFrArgs a, int 
     const int beg = a.rp0[n] + a.rp1[n], end = a.rp0[n + 1] + a.rp1[n + 1];
     f32x4 acc = zero4;                     // every wave: its share of the live facts, columns 4 lane ..
     bool split = false;                    // workgroup-uniform: the live facts were shared out over the 4 waves
-    for (int c0 = beg; c0 < end; c0 += kWfCap) {
+    // A listed HUB (BASELINE config 5: rows of 88 000 facts, of which a handful start at a seed): the same facts are
+    // records of the SEEDS' rows with this node as the other end - a fact that arrives at a seed s from n in direction
+    // dq arrives at n from s in direction 1 - dq.  When the seeds' rows are much shorter than the node's own, wave 0
+    // scans those (seeds ascending, position order: a fixed order) instead of 43 passes over the hub's row.
+    const int nseed = a.seedinfo[2 * g];
+    const bool alt = nseed > 0 && end - beg > kWfAltMin && a.seedinfo[2 * g + 1] <= ((end - beg) >> 2);
+    if (alt && wave == 0) {
+      for (int si = 0; si < nseed; ++si) {
+        const int sn = a.seeds[g * kFrAltSeeds + si];
+        const float ps = a.dist[sn];
+        const int sb = a.rp0[sn] + a.rp1[sn], se = a.rp0[sn + 1] + a.rp1[sn + 1];
+        for (int c0 = sb; c0 < se; c0 += 64) {
+          const int j = c0 + lane;
+          const int2 e = j < se ? a.edge_m[j] : make_int2(-1, 0);
+          float p = 0.f;
+          if (e.x == n) {
+            p = ps;
+            if (a.w0) {
+              const int f = a.m_from[j];
+              p *= f < a.F ? a.w0[f] : a.w1[f - a.F];
+            }
+          }
+          unsigned long long m = __ballot(p != 0.f);
+          while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const float pl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), l));
+            const int rm = __builtin_amdgcn_readlane(e.y, l);
+            const int dq = rm > Rg ? 1 : 0;
+            const int rl = dq ? rm - (Rg + 1) : rm;
+            if (cok) acc += pl * *reinterpret_cast<const f32x4*>(a.P + ((size_t)(1 - dq) * a.rel_total + roff + rl) * D + col);
+          }
+        }
+      }
+    }
+    for (int c0 = beg; c0 < (alt ? beg : end); c0 += kWfCap) {
       // kWfPer rounds of 256 coalesced records (position = c0 + 256 u + tid), all loads issued before any is looked
       // at: two dependent round trips (records, then dist[src]) per pass of 2048 records
       int2 e[kWfPer];
@@ -365,7 +429,8 @@ int gnnrag::frontier_build_z(const gnnrag_csr* csr, const float* dist, void* fws
   hipLaunchKernelGGL(k_frontier_build, dim3(csr->B), dim3(kFrThreads), 0, stream, dist, csr->row_ptr[0], csr->row_ptr[1],
                      (const int2*)csr->edge_l[0], (const int2*)csr->edge_l[1], csr->rel_off, csr->N,
                      (uint8_t*)(base + w.row_flag), (int32_t*)(base + w.rows), (uint8_t*)(base + w.tflag),
-                     (int32_t*)(base + w.trows), (int32_t*)(base + w.counts), zero_a, (long long)zero_na, zero_b,
+                     (int32_t*)(base + w.trows), (int32_t*)(base + w.counts), (int32_t*)(base + w.seeds),
+                     (int32_t*)(base + w.seedinfo), zero_a, (long long)zero_na, zero_b,
                      (long long)zero_nb);
   GNNRAG_LAUNCH_CHECK();
   return 0;
@@ -416,6 +481,8 @@ extern "C" int gnnrag_aggregate_fused_frontier(const gnnrag_csr* csr, const void
   a.dist = dist; a.P = P; a.rel_off = csr->rel_off;
   a.rows = (const int32_t*)(base + w.rows);
   a.counts = (const int32_t*)(base + w.counts);
+  a.seeds = (const int32_t*)(base + w.seeds);
+  a.seedinfo = (const int32_t*)(base + w.seedinfo);
   a.out = out; a.F = csr->F; a.N = csr->N; a.D = D; a.rel_total = csr->rel_total; a.B = csr->B;
   // blocks per question: enough to give every listed node of a seed frontier its own block, bounded chip-wide
   // (about one block per listed node of a seed frontier - a dozen - not per possible node: empty workgroups cost

@@ -59,7 +59,7 @@ def _cfg(**kw):
 
 
 @pytest.mark.parametrize("case", ["one_seed", "three_seeds", "hub_seed", "dense_prior", "more_seeds_than_the_lds_list",
-                                  "weighted", "empty_question"])
+                                  "weighted", "empty_question", "listed_hub", "listed_hub_weighted"])
 def test_frontier_lists_tables_and_sums(dev, case):
     from gnnrag_amd import ops, synth
     import oracle.rearev_np64 as onp
@@ -70,6 +70,8 @@ def test_frontier_lists_tables_and_sums(dev, case):
         kw = dict(normalized_gnn=True)
     if case == "empty_question":
         kw = dict(n_real_min=0, B=7)
+    if case.startswith("listed_hub"):          # a hub of > 4096 facts ON the frontier of low-degree seeds: the walk
+        kw = dict(B=3, N=3000, E=40000, R=60, normalized_gnn=case.endswith("weighted"))   # resolves it from the seeds' rows
     cfg = _cfg(**kw)
     batch = synth.make_batch(cfg)
     feats = synth.make_features(cfg)
@@ -83,6 +85,18 @@ def test_frontier_lists_tables_and_sums(dev, case):
     elif case == "hub_seed":
         dist[:] = 0
         dist[:, 1] = 1.0                        # node 1 is the Zipf hub: thousands of facts start there
+    elif case.startswith("listed_hub"):
+        heads, _, tails = (np.asarray(x) for x in batch.edge_tuple[:3])
+        deg = np.bincount(heads, minlength=cfg.B * cfg.N) + np.bincount(tails, minlength=cfg.B * cfg.N)
+        dist[:] = 0
+        for b in range(cfg.B):
+            hub = b * cfg.N + int(np.argmax(deg[b * cfg.N:(b + 1) * cfg.N]))
+            assert deg[hub] > 4096
+            nb = np.concatenate([tails[heads == hub], heads[tails == hub]])            # the hub's neighbours
+            nb = nb[(nb != hub) & (deg[nb] < 64)]
+            pick = np.unique(nb)[:2]                                                     # two low-degree seeds next to it
+            assert len(pick) == 2
+            dist[b, pick - b * cfg.N] = 0.5
     elif case == "dense_prior":
         dist = rng.random((cfg.B, cfg.N)).astype(np.float32)
         dist /= dist.sum(1, keepdims=True)
