@@ -569,6 +569,10 @@ __global__ __launch_bounds__(256) void k_heavy_reduce(const WalkArgs a, int na) 
 #ifndef GNNRAG_HUB_DENSE
 #define GNNRAG_HUB_DENSE 1
 #endif
+#ifndef GNNRAG_HUB_KS_MAX
+#define GNNRAG_HUB_KS_MAX 8      // relation ranges per question (one k_hub_dense workgroup each) at batches of <= 32
+                                 // questions; C5 aggregation, us: 4: 781, 8: 725, 16: 756, 32: 784
+#endif
 
 __global__ __launch_bounds__(256) void k_hub_zero(const WalkArgs a) {
   if (!hub_dense_on(a)) return;
@@ -772,9 +776,11 @@ __global__ __launch_bounds__(64 * kHubWaves) void k_hub_dense(const WalkArgs a) 
 }
 
 // one workgroup per hub; its four 256-thread groups take a quarter of the hub's chunks each and are added in group order
+constexpr int kHubBndLds = 2048;   // boundary records of a hub staged in LDS (a hub of up to 524 288 facts)
 __global__ __launch_bounds__(1024) void k_hub_finish(const WalkArgs a) {
   if (!hub_dense_on(a)) return;
   __shared__ float s_q[3][256];
+  __shared__ int2 s_bnd[kHubBndLds];
   const int d = a.dir, D = a.D;
   const int grp = threadIdx.x >> 8, tx = threadIdx.x & 255;
   const int cnt = min(a.n_heavy[d], a.heavy_cap);
@@ -787,6 +793,17 @@ __global__ __launch_bounds__(1024) void k_hub_finish(const WalkArgs a) {
     const int per = (c1 - c0 + 3) >> 2;
     const int cb = min(c0 + grp * per, c1), ce = min(cb + per, c1);
     const float* Pq = a.T[d] + (size_t)a.rel_off[q] * D;
+    // the hub's boundary records: one coalesced load into LDS, a record without a relation becomes (row 0, weight 0) so
+    // that the table-row loads below need no branch (a guarded load makes the compiler wait behind every one of them)
+    const bool staged = c1 - c0 <= kHubBndLds;
+    if (staged) {
+      for (int i = threadIdx.x; i < c1 - c0; i += 1024) {
+        int2 b = bnd[c0 + i];
+        if (b.x < 0) b = make_int2(0, 0);
+        s_bnd[i] = b;
+      }
+    }
+    __syncthreads();
     for (int x0 = 0; x0 < D; x0 += 256) {
       const int x = x0 + tx;
       float s = 0.f, dense = 0.f;
@@ -795,19 +812,26 @@ __global__ __launch_bounds__(1024) void k_hub_finish(const WalkArgs a) {
       }
       if (x < D) {
         int c = cb;
-        for (; c + 8 <= ce; c += 8) {                // 8 boundary records and their table rows in flight, added in chunk order
-          int2 b[8];
-          float t[8];
+        if (staged) {
+          for (; c + 16 <= ce; c += 16) {            // 16 table rows in flight, added in chunk order
+            int2 b[16];
+            float t[16];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) b[u] = bnd[c + u];
+            for (int u = 0; u < 16; ++u) b[u] = s_bnd[c - c0 + u];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) t[u] = b[u].x >= 0 ? Pq[(size_t)b[u].x * D + x] : 0.f;
+            for (int u = 0; u < 16; ++u) t[u] = Pq[(size_t)b[u].x * D + x];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) s = fmaf(__int_as_float(b[u].y), t[u], s);
-        }
-        for (; c < ce; ++c) {
-          const int2 b = bnd[c];
-          if (b.x >= 0) s = fmaf(__int_as_float(b.y), Pq[(size_t)b.x * D + x], s);
+            for (int u = 0; u < 16; ++u) s = fmaf(__int_as_float(b[u].y), t[u], s);
+          }
+          for (; c < ce; ++c) {
+            const int2 b = s_bnd[c - c0];
+            s = fmaf(__int_as_float(b.y), Pq[(size_t)b.x * D + x], s);
+          }
+        } else {
+          for (; c < ce; ++c) {
+            const int2 b = bnd[c];
+            if (b.x >= 0) s = fmaf(__int_as_float(b.y), Pq[(size_t)b.x * D + x], s);
+          }
         }
       }
       if (grp > 0) s_q[grp - 1][tx] = s;
@@ -1881,8 +1905,8 @@ int gnnrag::aggregate_fused_dirs(const gnnrag_csr* csr, const float* dist, const
       const size_t cap = (avail - bnd_bytes) / sizeof(float);
       a.hub_w_cap = (long long)(cap < ((size_t)1 << 30) ? cap : ((size_t)1 << 30));
       // about two workgroups per CU when one direction has hubs in every question (BASELINE config 5)
-      const int ks = 1024 / (2 * csr->B);
-      a.hub_ks = ks < 1 ? 1 : ks > 16 ? 16 : ks;
+      const int ks = (64 * GNNRAG_HUB_KS_MAX) / (2 * csr->B);
+      a.hub_ks = ks < 1 ? 1 : ks > GNNRAG_HUB_KS_MAX ? GNNRAG_HUB_KS_MAX : ks;
     }
   }
   switch (variant) {
