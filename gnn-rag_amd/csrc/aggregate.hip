@@ -569,6 +569,9 @@ __global__ __launch_bounds__(256) void k_heavy_reduce(const WalkArgs a, int na) 
 #ifndef GNNRAG_HUB_DENSE
 #define GNNRAG_HUB_DENSE 1
 #endif
+#ifndef GNNRAG_HUB_W_GRID
+#define GNNRAG_HUB_W_GRID 2048   // workgroups (4 waves, a 256-fact chunk per wave and turn) of k_hub_weights per direction
+#endif
 #ifndef GNNRAG_HUB_KS_MAX
 #define GNNRAG_HUB_KS_MAX 8      // relation ranges per question (one k_hub_dense workgroup each) at batches of <= 32
                                  // questions; C5 aggregation, us: 4: 781, 8: 725, 16: 756, 32: 784
@@ -1613,7 +1616,7 @@ static int launch_one(WalkArgs a, hipStream_t stream) {
     if (a.hub_w) {      // dense hub form (returns at once on the device when the weight blocks do not fit)
       hipLaunchKernelGGL(k_hub_zero, dim3(1024), dim3(256), 0, stream, a);
       GNNRAG_LAUNCH_CHECK();
-      hipLaunchKernelGGL(k_hub_weights, dim3(2048, 2), dim3(256), 0, stream, a);
+      hipLaunchKernelGGL(k_hub_weights, dim3(GNNRAG_HUB_W_GRID, 2), dim3(256), 0, stream, a);
       GNNRAG_LAUNCH_CHECK();
       hipLaunchKernelGGL(k_hub_dense, dim3(a.hub_ks * a.B * 2), dim3(64 * kHubWaves), 0, stream, a);
       GNNRAG_LAUNCH_CHECK();
