@@ -191,3 +191,19 @@ def test_synth_edge_tuple_semantics():
     assert wl == [1.0 / hc[x] for x in h.tolist()]
     assert wrl == [1.0 / hrc[x] for x in zip(h.tolist(), r.tolist())]
     assert (f == np.arange(len(h))).all()
+
+
+def test_integration_stub_struct_matches_the_binding():
+    """The ctypes stub INTEGRATION.md shows to a maintainer lists the fields of ``struct gnnrag_csr`` in the order
+    and with the types of the binding the product uses (it went stale once: two ABI versions behind)."""
+    import re
+    from gnnrag_amd import _lib
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    block = text[text.index("class Csr(C.Structure)"):]
+    block = block[:block.index("]")]
+    got = [(n, getattr(ctypes, t), bool(a)) for n, t, a in re.findall(r'\("(\w+)", C\.(c_\w+)( \* 2)?\)', block)]
+    want = []
+    for name, ctype in _lib.CsrStruct._fields_:
+        arr = hasattr(ctype, "_length_")
+        want.append((name, ctype._type_ if arr else ctype, arr))
+    assert got == want
