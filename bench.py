@@ -459,12 +459,17 @@ def dry_run_cpu(args, world, rank):
 
 
 def kernel_sources_digest():
-    """sha256 over the HIP sources of the aggregation path (what profiles/pmc_traffic.json is valid for)."""
+    """sha256 over the CODE of the aggregation path's HIP sources (what profiles/pmc_traffic.json is valid for):
+    comments and whitespace do not count, so that editing a comment does not declare a measurement stale."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for f in ("aggregate.hip", "csr_plan.hip", "frontier.hip", "gnnrag_common.h"):
-        with open(os.path.join(REPO, "gnn-rag_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
+        with open(os.path.join(REPO, "gnn-rag_amd", "csrc", f), "r") as fh:
+            src = fh.read()
+        src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+        src = re.sub(r"//[^\n]*", " ", src)
+        h.update(" ".join(src.split()).encode())
     return h.hexdigest()
 
 

@@ -13,7 +13,8 @@
 // table (gemm_f32.hip), so the walk emits the [D] contribution to e2e_linear directly instead of
 // the [2I*D] concat operand.  TYPE = TypeLayer.forward (gnn/modules/layer_init.py:25-62).
 // No [F,D] temporary ever exists and there are no floating-point atomics: every destination node
-// is summed in ascending fact id by one owner, in registers.
+// is summed in its stored order (ascending fact id; hub rows of large vocabularies by relation, then
+// fact id) by one owner, in registers.
 //
 // Mapping to CDNA4 (wave64):
 //  * a group of LPN lanes (16/32/64, from D) owns one node; lane `sub` holds the VEC-wide column
@@ -24,13 +25,15 @@
 //  * facts whose prior is exactly 0 are skipped (they contribute exact zeros): on the first layer
 //    of every iteration dist is the seed distribution and only the seeds' facts are live;
 //  * live facts are consumed U at a time: U table rows (D*4 contiguous bytes each, L2 resident)
-//    are requested back to back, then combined in fact order - the kernel is bound by gather
-//    latency, not by arithmetic, so memory-level parallelism per wave is what matters;
+//    are requested back to back, then combined in fact order - the kernel is bound by the CU's
+//    vector-memory path (64 B / clk: measured by ablation, round 3), not by arithmetic or misses;
 //  * one wave writes the complete output row of its node (3200 B at D=200, I=2) -> full 128-byte
 //    lines; this write stream is the kernel's compulsory HBM traffic;
 //  * destination nodes with more than kHeavyDeg facts (Freebase hubs) are cut into 256-fact
-//    chunks, one wave per chunk (k_heavy_partial), and reduced in chunk order (k_heavy_reduce):
-//    deterministic, no atomics, scales to hubs with 10^5 facts.
+//    chunks, one wave per chunk (k_heavy_partial; a run of equal relations = one table row), and
+//    reduced in chunk order (k_heavy_reduce): deterministic, no atomics, scales to hubs with 10^5
+//    facts.  The FUSED walk takes them as a dense hub-by-relation product instead when the hub rows
+//    are in relation order (k_hub_weights / k_hub_dense / k_hub_finish below).
 #include <cstdlib>
 #include <type_traits>
 

@@ -6,11 +6,14 @@
 //
 //   key = destination node (tail for the forward direction, head for the inverse one),
 //   value = fact id, stable LSD radix sort over ceil(log2(B*N)) bits  ->  facts of one
-//   destination are contiguous and in ascending fact id (one fixed summation order).
+//   destination are contiguous and in ascending fact id (one fixed summation order); hub rows
+//   (> kHeavyDeg facts) of large vocabularies are then put in (relation, fact id) order by a
+//   segmented sort over those rows (see hub_sort_scratch) - also one fixed order.
 //
-// The sort itself is rocPRIM's device radix sort (a plain library op); everything around it
-// (record gather, row pointers, heavy-row list) is hand written.  All of it is HBM-bound
-// integer work: coalesced 4/8-byte streams, no atomics except the heavy-row append.
+// The sorts are rocPRIM's device radix sorts (plain library ops); everything around them
+// (record gather, row pointers, ordered hub lists, relation compaction, merged stream) is hand
+// written.  All of it is HBM-bound integer work: coalesced 4/8-byte streams; the only atomics are
+// the per-question appends of the LDS walk's big-node lists (order irrelevant).
 #include <thread>
 #include <vector>
 
