@@ -207,3 +207,23 @@ def test_integration_stub_struct_matches_the_binding():
         arr = hasattr(ctype, "_length_")
         want.append((name, ctype._type_ if arr else ctype, arr))
     assert got == want
+
+
+def test_pmc_source_digest_ignores_comments_and_whitespace(tmp_path, monkeypatch):
+    """bench.kernel_sources_digest stamps profiles/pmc_traffic.json: a comment edit must not declare the measured
+    traffic stale, a code edit must."""
+    import shutil
+    import bench
+    src = os.path.join(REPO, "gnn-rag_amd", "csrc")
+    dst = tmp_path / "gnn-rag_amd" / "csrc"
+    dst.mkdir(parents=True)
+    for f in ("aggregate.hip", "csr_plan.hip", "frontier.hip", "gnnrag_common.h"):
+        shutil.copy(os.path.join(src, f), dst / f)
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    base = bench.kernel_sources_digest()
+    p = dst / "frontier.hip"
+    text = p.read_text()
+    p.write_text("// a new remark\n" + text.replace("\n", "\n   \n", 3) + "/* and a block\n comment */\n")
+    assert bench.kernel_sources_digest() == base
+    p.write_text(text.replace("kFrAltSeeds = 32", "kFrAltSeeds = 16"))
+    assert bench.kernel_sources_digest() != base
