@@ -68,6 +68,7 @@ SIGNATURES = {
                                    _VP, C.c_size_t, _VP]),
     "gnnrag_aggregate_fused": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, C.c_int32, _VP, C.c_size_t, _VP]),
     "gnnrag_aggregate_fused_variant": (C.c_int, [C.POINTER(CsrStruct), C.c_int32]),
+    "gnnrag_aggregate_fused_hub_form": (C.c_int, [C.POINTER(CsrStruct), C.c_int32, _VP, C.c_size_t, _VP, _VP]),
     "gnnrag_relorder_bytes": (C.c_size_t, [C.POINTER(CsrStruct), C.c_int]),
     "gnnrag_relorder_scratch_bytes": (C.c_size_t, [C.POINTER(CsrStruct)]),
     "gnnrag_relorder_build": (C.c_int, [C.POINTER(CsrStruct), _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP, C.c_size_t,
@@ -120,7 +121,7 @@ SIGNATURES = {
     "gnnrag_error_string": (C.c_char_p, [C.c_int]),
 }
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 PATH_AUTO, PATH_UNFUSED, PATH_FUSED = 0, 1, 2
 PATH_ONLY_FWD, PATH_ONLY_INV = 0x10, 0x20        # OR-ed into the path: one-direction layers (NSM)
 PATH_SEED_PRIOR = 0x40                           # OR-ed into the path: the (first layer's) prior is a seed distribution

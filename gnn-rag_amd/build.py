@@ -54,7 +54,8 @@ def build_variant(name: str, defines: dict, verbose: bool = False) -> str:
     hipcc = _hipcc()
     objdir = os.path.join(LIBDIR, "obj_" + name)
     os.makedirs(objdir, exist_ok=True)
-    extra = ["-D%s=%s" % kv for kv in defines.items()]
+    # "__flags__": extra compiler flags of the variant (e.g. ["-fno-slp-vectorize"]); everything else is a -D switch
+    extra = list(defines.get("__flags__", [])) + ["-D%s=%s" % kv for kv in defines.items() if kv[0] != "__flags__"]
 
     def cc(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))

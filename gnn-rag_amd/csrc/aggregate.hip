@@ -1864,10 +1864,10 @@ extern "C" int gnnrag_aggregate_fused(const gnnrag_csr* csr, const float* dist, 
 
 // skip_dir: 0 both directions, 1 + d = leave direction d out (its tables are not read; LDS walk only - the gather walk
 // walks both, the caller's tables for the other direction must then be zero)
-int gnnrag::aggregate_fused_dirs(const gnnrag_csr* csr, const float* dist, const float* P, float* out, int32_t D,
-                                 int32_t skip_dir, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  if (!csr || !dist || !P || !out || D <= 0 || csr->rel_total < 0 || skip_dir < 0 || skip_dir > 2) return GNNRAG_E_BADARG;
-  WalkArgs a;
+// The kernel arguments of a fused aggregation call, incl. whether the hub kernels of the dense form are part of it
+// (a.hub_w); shared by the call itself and by gnnrag_aggregate_fused_hub_form, which reports what the call decides.
+static int prepare_fused(WalkArgs& a, const gnnrag_csr* csr, const float* dist, const float* P, float* out, int32_t D,
+                         int32_t skip_dir, void* workspace, size_t workspace_bytes, int* variant_out) {
   memset(&a, 0, sizeof(a));
   const int rc = fill_common(a, csr, D, workspace, workspace_bytes, 1);
   if (rc) return rc;
@@ -1915,6 +1915,17 @@ int gnnrag::aggregate_fused_dirs(const gnnrag_csr* csr, const float* dist, const
       a.hub_ks = ks < 1 ? 1 : ks > GNNRAG_HUB_KS_MAX ? GNNRAG_HUB_KS_MAX : ks;
     }
   }
+  *variant_out = variant;
+  return 0;
+}
+
+int gnnrag::aggregate_fused_dirs(const gnnrag_csr* csr, const float* dist, const float* P, float* out, int32_t D,
+                                 int32_t skip_dir, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (!csr || !dist || !P || !out || D <= 0 || csr->rel_total < 0 || skip_dir < 0 || skip_dir > 2) return GNNRAG_E_BADARG;
+  WalkArgs a;
+  int variant = 0;
+  const int rc = prepare_fused(a, csr, dist, P, out, D, skip_dir, workspace, workspace_bytes, &variant);
+  if (rc) return rc;
   switch (variant) {
     case GNNRAG_WALK_L2_GATHER: return launch_walk<MODE_FUSED>(a, 1, stream);   // tables too big for LDS
     // 32-column slices when two of them still fit a CU's LDS (questions that use up to ~300 relations): half
@@ -1922,6 +1933,28 @@ int gnnrag::aggregate_fused_dirs(const gnnrag_csr* csr, const float* dist, const
     case GNNRAG_WALK_LDS_32: return launch_slice<MODE_FUSED, 2>(a, csr, workspace, workspace_bytes, 1, stream);
     default: return launch_slice<MODE_FUSED, 1>(a, csr, workspace, workspace_bytes, 1, stream);
   }
+}
+
+// one thread: the predicate every hub kernel of the call evaluates, on the call's own arguments
+__global__ void k_hub_form_report(const WalkArgs a, int32_t* form) {
+  form[0] = a.hub_w == nullptr ? GNNRAG_HUB_FORM_NONE : hub_dense_on(a) ? GNNRAG_HUB_FORM_DENSE : GNNRAG_HUB_FORM_CHUNKED;
+  form[1] = min(a.n_heavy[0], a.heavy_cap);
+  form[2] = min(a.n_heavy[1], a.heavy_cap);
+  form[3] = a.hub_ks;
+}
+
+extern "C" int gnnrag_aggregate_fused_hub_form(const gnnrag_csr* csr, int32_t D, void* workspace, size_t workspace_bytes,
+                                               int32_t* form_dev, gnnrag_stream_t stream) {
+  if (!csr || !workspace || !form_dev || D <= 0 || csr->rel_total < 0) return GNNRAG_E_BADARG;
+  WalkArgs a;
+  int variant = 0;
+  // dist / P / out are not dereferenced by the report kernel; any non-null value passes prepare_fused
+  const int rc = prepare_fused(a, csr, (const float*)workspace, (const float*)workspace, (float*)workspace, D, 0, workspace,
+                               workspace_bytes, &variant);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_hub_form_report, dim3(1), dim3(1), 0, (hipStream_t)stream, a, form_dev);
+  GNNRAG_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int gnnrag_aggregate_fused_variant(const gnnrag_csr* csr, int32_t D) {

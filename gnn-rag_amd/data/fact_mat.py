@@ -19,6 +19,8 @@ from __future__ import annotations
 
 import types
 
+import os
+
 import numpy as np
 
 
@@ -242,14 +244,30 @@ class DeviceFactCache(FactCache):
 
 class DeviceStructureCache(DeviceFactCache):
     """:class:`DeviceFactCache` that also keeps every question's destination-sorted STRUCTURE on the GPU (a
-    single-question ``ops.CsrPlan``: built the first time the question is used, ~64 B per fact): a batch is then the
+    single-question ``ops.CsrPlan``, built the first time the question is used): a batch is then the
     concatenation of its questions' structures (``ops.CsrPlan.concat`` -> ``gnnrag_csr_concat``: copies with offsets, no
     upload, no sort, no wait for the stream) - SURVEY.md section 8 f-1 as written ("cached per-question int32 CSR built
-    once at load time, batch = concatenation with offsets")."""
+    once at load time, batch = concatenation with offsets").
 
-    def __init__(self, loader, device, max_questions: int = 200000):
+    Memory: a cached structure is the whole single-question layout - ~76 B per fact (record arrays of both directions,
+    the merged stream, the id block) PLUS per-node arrays of the PADDED width (two row-pointer arrays, the big-node
+    list; ~20 B per node slot, 256-byte aligned pieces): at N = 2000 that is ~50 KB per question before the first
+    fact.  The cache is bounded by ``max_questions`` AND by a byte budget (``max_bytes``; default 16 GiB, environment
+    ``GNNRAG_STRUCTURE_CACHE_MB``), least recently used questions are dropped first; a dropped question is simply
+    rebuilt when it comes up again."""
+
+    def __init__(self, loader, device, max_questions: int = 200000, max_bytes: int = None):
+        import collections
         super().__init__(loader, device, max_questions)
-        self._plans = {}
+        self._plans = collections.OrderedDict()
+        if max_bytes is None:
+            max_bytes = int(os.environ.get("GNNRAG_STRUCTURE_CACHE_MB", "16384")) << 20
+        self.max_bytes = int(max_bytes)
+        self.cached_bytes = 0
+
+    @staticmethod
+    def _plan_bytes(pl) -> int:
+        return int(pl._mem.numel()) + int(pl._hrt.numel()) * 4
 
     def batch(self, sample_ids):
         import torch
@@ -264,11 +282,16 @@ class DeviceStructureCache(DeviceFactCache):
             if pl is None:
                 blk = torch.from_numpy(np.ascontiguousarray(q[0])).to(self.device)
                 pl = ops.CsrPlan(None, None, None, 1, N, R1, self.device, hrt_device=blk)
-                if len(self._plans) < self.max_questions:
-                    self._plans[s_] = pl
-                self._dev[s_] = blk
+                self._plans[s_] = pl
+                self.cached_bytes += self._plan_bytes(pl)
+            else:
+                self._plans.move_to_end(s_)
             parts.append(q)
             plans.append(pl)
+        # bounds: questions of THIS batch stay alive through `plans` whatever is dropped from the cache
+        while self._plans and (len(self._plans) > self.max_questions or self.cached_bytes > self.max_bytes):
+            _, old = self._plans.popitem(last=False)
+            self.cached_bytes -= self._plan_bytes(old)
         sizes = np.array([p[0].shape[1] for p in parts], dtype=np.int64)
         return BatchFacts(None, sizes, parts, N, plans=plans,
                           make_hrt=lambda: _cat_blocks([p._hrt[:, : p.F] for p in plans], sizes, N).to(self.device))

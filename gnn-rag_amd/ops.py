@@ -492,6 +492,23 @@ def aggregate_fused_variant(plan: CsrPlan, D: int) -> int:
     return v
 
 
+HUB_FORM_NONE, HUB_FORM_DENSE, HUB_FORM_CHUNKED = 0, 1, 2
+
+
+def aggregate_fused_hub_form(plan: CsrPlan, D: int, I: int = 1) -> dict:
+    """What the hub rows of a fused aggregation call do for this structure: the device-side decision of the gather walk
+    (dense product or chunked fallback), read back.  ``I`` sizes the workspace as the layer call does
+    (``gnnrag_aggregate_workspace_bytes(csr, D, I)``, softmax_layer.hip layer_ws)."""
+    lib = _lib.load()
+    ws = plan.walk_workspace(D, I)
+    form = torch.zeros(4, dtype=torch.int32, device=ws.device)
+    with torch.cuda.device(ws.device):
+        _lib.check(lib.gnnrag_aggregate_fused_hub_form(C.byref(plan.c), int(D), ws.data_ptr(), ws.numel(), form.data_ptr(),
+                                                       _stream()), "gnnrag_aggregate_fused_hub_form")
+    f = form.cpu().tolist()
+    return {"form": f[0], "hubs": (f[1], f[2]), "relation_ranges": f[3]}
+
+
 def aggregate_fused(plan: CsrPlan, dist: torch.Tensor, P: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     B, N = plan.B, plan.N

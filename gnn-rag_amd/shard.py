@@ -65,7 +65,8 @@ def shard_edge_tuple(edge_tuple, N: int, lo: int, hi: int):
     """Facts of questions [lo, hi), re-based so the shard is a self-contained batch.
     Facts of one question are contiguous and ``batch_ids`` is non-decreasing
     (``_build_fact_mat``, dataset_load.py:481-506)."""
-    if hasattr(edge_tuple, "hrt_device"):          # data/fact_mat.BatchFacts: the id arrays live on the GPU
+    if hasattr(type(edge_tuple), "shard"):         # data/fact_mat.BatchFacts: the id arrays live on the GPU (the type is
+                                                   # asked, not the lazy `hrt_device` property, which would build the block)
         return edge_tuple.shard(lo, hi)
     heads, rels, tails, bids, _, wl, wrl = edge_tuple
     bids = np.asarray(bids)

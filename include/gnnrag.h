@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GNNRAG_ABI_VERSION 11
+#define GNNRAG_ABI_VERSION 12
 
 #define GNNRAG_E_BADARG      (-1)  /* null pointer / negative size / inconsistent sizes   */
 #define GNNRAG_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set (see DESIGN)  */
@@ -196,6 +196,17 @@ int gnnrag_aggregate_fused(const gnnrag_csr* csr, const float* dist, const float
 #define GNNRAG_WALK_LDS_16    1  /* k_walk_slice<FUSED,1>: 16-column table slices in LDS                      */
 #define GNNRAG_WALK_LDS_32    2  /* k_walk_slice<FUSED,2>: 32-column slices (small per-question tables)       */
 int gnnrag_aggregate_fused_variant(const gnnrag_csr* csr, int32_t D);
+
+/* Which form the HUB ROWS of the gather walk take in a gnnrag_aggregate_fused call with this structure, hidden size and
+ * workspace (the sizes of the hub-by-relation weight blocks live on the device, so the kernels decide; this entry runs
+ * the same predicate on the same kernel arguments in a one-thread launch).  form_dev: 4 device int32 -
+ * [0] GNNRAG_HUB_FORM_*, [1] / [2] hub rows of direction 0 / 1, [3] relation ranges per question.  Diagnostics for
+ * tests and bench.py ("which kernel ran"); nothing on the product path calls it. */
+#define GNNRAG_HUB_FORM_NONE    0  /* the call has no dense hub kernels (LDS walk, or the form is switched off)   */
+#define GNNRAG_HUB_FORM_DENSE   1  /* k_hub_weights / k_hub_dense / k_hub_finish                                   */
+#define GNNRAG_HUB_FORM_CHUNKED 2  /* weight blocks do not fit the workspace: k_heavy_partial / k_heavy_reduce     */
+int gnnrag_aggregate_fused_hub_form(const gnnrag_csr* csr, int32_t D, void* workspace, size_t workspace_bytes,
+                                    int32_t* form_dev, gnnrag_stream_t stream);
 
 /* h_out = relu(e2e_linear(cat(h, agg)))            (reasongnn.py:161-163)
  * score = score_func(h_out) + (1 - mask) * -1e11   (reasongnn.py:165-168), mask add in fp32.

@@ -34,10 +34,28 @@ DATA = os.path.join(DST, "data", "synth") + "/"
 CKPT = os.path.join(DST, "ckpt") + "/"
 EXP = "synth"
 
-# main.py's own flags for this dataset (released-checkpoint dims: gnn/README.md:19)
-MODEL_ARGV = ["ReaRev", "--data_folder", DATA, "--lm", "lstm", "--relation_word_emb", "False",
-              "--entity_dim", "50", "--kg_dim", "25", "--num_iter", "3", "--num_ins", "2", "--num_gnn", "3",
-              "--batch_size", "16", "--test_batch_size", "16", "--name", "synth"]
+# main.py's own flags per staged variant (released-checkpoint dims: gnn/README.md:19 for d50; the benchmark's hidden
+# size for d200; "cwq" = the same d50 checkpoint evaluated with --name cwq, where the seed KEEPS its candidate slot,
+# dataset_load.py:249-257)
+COMMON_ARGV = ["ReaRev", "--data_folder", DATA, "--lm", "lstm", "--relation_word_emb", "False",
+               "--num_iter", "3", "--num_ins", "2", "--num_gnn", "3", "--batch_size", "16", "--test_batch_size", "16"]
+VARIANTS = {
+    "d50": {"argv": ["--entity_dim", "50", "--kg_dim", "25", "--name", "synth"], "train": "synth", "epochs": 8},
+    "d200": {"argv": ["--entity_dim", "200", "--kg_dim", "100", "--name", "synth"], "train": "synth200", "epochs": 6},
+    "cwq": {"argv": ["--entity_dim", "50", "--kg_dim", "25", "--name", "cwq"], "train": "synth", "epochs": 0},
+}
+DATASET_VERSION = "r4-learnable-2"
+
+
+def variant_argv(v):
+    return COMMON_ARGV + VARIANTS[v]["argv"]
+
+
+def ckpt_name(v):
+    return VARIANTS[v]["train"] + "-final.ckpt"
+
+
+MODEL_ARGV = variant_argv("d50")                 # kept for callers of round 3
 
 
 def shim_reference_startup_bugs():
@@ -57,9 +75,70 @@ def shim_reference_startup_bugs():
         base_encoder.BaseInstruction.__init__ = _init
 
 
-def write_dataset(folder, seed=314, n_ent=6000, n_rel=48, n_q=48, n_min=40, n_max=400):
-    """Freebase-shaped question subgraphs on disk: per question a seed entity, 40..400 subgraph entities, 3-6 typed
-    edges per entity with Zipf-distributed heads (hubs), one or two answers among the seed's 2-hop neighbourhood."""
+def _question(rng, n_ent, n_rel, words_of_rel, fillers, size_class):
+    """One question whose ANSWER IS DETERMINED BY A RELATION PATH FROM THE SEED: the question text names one relation
+    (1 hop: the answers are the tails of the seed's facts of that relation) or two (2 hops: tails of the named second
+    relation out of the tails of the first).  Around that: distractor relations out of the seed and out of the 1-hop
+    nodes, uniform noise facts, and - for the "hub" size classes - a node that thousands of filler nodes point at with
+    several relations each (more than 4096 facts arrive at one row, the kernels' largest degree class)."""
+    if size_class == "small":
+        n_sub = int(rng.integers(140, 320))
+    elif size_class == "medium":
+        n_sub = int(rng.integers(400, 1000))
+    else:                                                   # "hub": WebQSP's padded width, one very heavy row
+        n_sub = int(rng.integers(1700, 2001))
+    ents = rng.choice(n_ent, size=n_sub, replace=False)
+    seed_e, rest = int(ents[0]), [int(e) for e in ents[1:]]
+    rng.shuffle(rest)
+    take = iter(rest)
+    tuples = []
+    k1 = int(rng.integers(3, 7))
+    rels1 = [int(r) for r in rng.choice(n_rel, size=k1, replace=False)]
+    hop1 = {}
+    for r in rels1:
+        hop1[r] = [next(take) for _ in range(int(rng.integers(1, 4)))]
+        tuples += [[seed_e, r, t] for t in hop1[r]]
+    hop2 = {}
+    for r, mids in hop1.items():
+        for m in mids:
+            for r2 in (int(x) for x in rng.choice(n_rel, size=int(rng.integers(1, 4)), replace=False)):
+                tails = [next(take) for _ in range(int(rng.integers(1, 3)))]
+                hop2.setdefault((r, r2), []).extend(tails)
+                tuples += [[m, r2, t] for t in tails]
+    two_hop = rng.random() < 0.4
+    if two_hop:
+        (r1, r2) = list(hop2)[int(rng.integers(0, len(hop2)))]
+        answers = sorted(set(hop2[(r1, r2)]))
+        q_words = [fillers[int(rng.integers(0, len(fillers)))], words_of_rel[r2], "of", words_of_rel[r1]]
+    else:
+        r1 = rels1[int(rng.integers(0, k1))]
+        answers = sorted(set(hop1[r1]))
+        q_words = [fillers[int(rng.integers(0, len(fillers)))], "is", words_of_rel[r1]]
+    # noise facts between random nodes of the subgraph (never out of the seed: the seed's relations stay unambiguous)
+    others = np.asarray(rest)
+    n_noise = int(rng.integers(2 * n_sub, 4 * n_sub))
+    h = others[(rng.zipf(1.6, size=n_noise) - 1) % len(others)]
+    t = others[rng.integers(0, len(others), size=n_noise)]
+    r = rng.integers(0, n_rel, size=n_noise)
+    tuples += [[int(a), int(b), int(c)] for a, b, c in zip(h, r, t)]
+    if size_class == "hub":
+        hub = int(others[int(rng.integers(0, len(others)))])
+        fan = others[others != hub]
+        for rr in (int(x) for x in rng.choice(n_rel, size=3, replace=False)):
+            tuples += [[int(a), rr, hub] for a in fan]          # 3 x ~1900 facts arrive at the hub: > 4096
+    order = rng.permutation(len(tuples))
+    tuples = [tuples[int(i)] for i in order]
+    sub_ents = [int(e) for e in ents[rng.permutation(n_sub)]]
+    return {"question": " ".join(q_words), "entities": [seed_e],
+            "answers": [{"kb_id": "m.%05d" % a, "text": "a"} for a in answers],
+            "subgraph": {"tuples": tuples, "entities": sub_ents}}
+
+
+def write_dataset(folder, seed=314, n_ent=20000, n_rel=24, n_train=1200, n_dev=160, n_test=520):
+    """A LEARNABLE synthetic KBQA dataset in the reference's on-disk format (dataset_load.py:45-55,228-238,565-575).
+    train: small subgraphs only (the CPU trainer's cost); dev: small + medium; test: small + medium + 16 questions of
+    1700-2000 entities with a hub row of more than 4096 facts (so the test split is padded to WebQSP's 2000 slots)."""
+    global np
     import numpy as np
     rng = np.random.default_rng(seed)
     os.makedirs(folder, exist_ok=True)
@@ -69,30 +148,40 @@ def write_dataset(folder, seed=314, n_ent=6000, n_rel=48, n_q=48, n_min=40, n_ma
     with open(os.path.join(folder, "relations.txt"), "w") as f:
         for i in range(n_rel):
             f.write("dom%d.type%d.rel%d\n" % (i % 5, i % 11, i))
-    words = ["what", "is", "the", "name", "of", "who", "where", "film", "city", "born", "wrote", "plays", "in", "team"]
+    fillers = ["what", "who", "where", "which", "name"]
+    words_of_rel = ["rel%d" % i for i in range(n_rel)]
+    words = fillers + ["is", "of"] + words_of_rel
     with open(os.path.join(folder, "vocab.txt"), "w") as f:
         for w in words:
             f.write(w + "\n")
-    np.save(os.path.join(folder, "word_emb.npy"), (0.3 * rng.standard_normal((len(words), 24))).astype(np.float32))
-    for split in ("train", "dev", "test"):
+    np.save(os.path.join(folder, "word_emb.npy"), rng.standard_normal((len(words), 32)).astype(np.float32))
+    plan = {"train": ["small"] * n_train,
+            "dev": ["small"] * (n_dev - 24) + ["medium"] * 24,
+            "test": ["small"] * (n_test - 96) + ["medium"] * 80 + ["hub"] * 16}
+    stats = {}
+    for split, classes in plan.items():
+        classes = [classes[int(i)] for i in rng.permutation(len(classes))]
+        nf = []
         with open(os.path.join(folder, split + ".json"), "w") as f:
-            for qi in range(n_q):
-                n_sub = int(rng.integers(n_min, n_max + 1))
-                ents = rng.choice(n_ent, size=n_sub, replace=False)
-                n_edge = int(rng.integers(3 * n_sub, 6 * n_sub))
-                h = ents[(rng.zipf(1.6, size=n_edge) - 1) % n_sub]
-                t = ents[rng.integers(0, n_sub, size=n_edge)]
-                r = rng.integers(0, n_rel, size=n_edge)
-                tuples = [[int(a), int(b), int(c)] for a, b, c in zip(h, r, t)]
-                seed_e = int(ents[0])                             # the hub: most facts start here
-                hop1 = {int(c) for a, _, c in tuples if a == seed_e and c != seed_e}
-                pool = sorted(hop1) or [int(e) for e in ents[1:]]
-                ans = [pool[int(i)] for i in rng.choice(len(pool), size=min(len(pool), int(rng.integers(1, 3))), replace=False)]
-                q = " ".join(rng.choice(words, size=int(rng.integers(3, 8))).tolist())
-                f.write(json.dumps({
-                    "id": "%s-%d" % (split, qi), "question": q, "entities": [seed_e],
-                    "answers": [{"kb_id": "m.%05d" % a, "text": "a"} for a in ans],
-                    "subgraph": {"tuples": tuples, "entities": [int(e) for e in ents]}}) + "\n")
+            for qi, cls in enumerate(classes):
+                q = _question(rng, n_ent, n_rel, words_of_rel, fillers, cls)
+                q["id"] = "%s-%d" % (split, qi)
+                nf.append(len(q["subgraph"]["tuples"]))
+                f.write(json.dumps(q) + "\n")
+        stats[split] = {"questions": len(classes), "facts_max": max(nf), "facts_mean": sum(nf) / len(nf)}
+    # a bounded sample of the test split for CPU timings of the reference's own entry point (bench.py's e2e block):
+    # the first 32 test questions, as their own data folder sharing the vocabulary files
+    small = os.path.join(os.path.dirname(folder.rstrip("/")), "synth_sample") + "/"
+    os.makedirs(small, exist_ok=True)
+    for name in ("entities.txt", "relations.txt", "vocab.txt", "word_emb.npy"):
+        shutil.copyfile(os.path.join(folder, name), os.path.join(small, name))
+    lines = open(os.path.join(folder, "test.json")).read().splitlines()
+    for split, part in (("dev", lines[:8]), ("test", lines[:32]), ("train", lines[:8])):
+        with open(os.path.join(small, split + ".json"), "w") as f:
+            f.write("\n".join(part) + "\n")
+    with open(os.path.join(folder, "VERSION"), "w") as f:
+        f.write(DATASET_VERSION + "\n" + json.dumps(stats) + "\n")
+    return stats
 
 
 def stage_sources():
@@ -103,11 +192,10 @@ def stage_sources():
     shutil.copytree(SRC, GNN, ignore=shutil.ignore_patterns("__pycache__", "*.pyc"))
 
 
-def make_checkpoint():
-    """The reference's own trainer on CPU: three epochs over the synthetic train split, then save_ckpt('final').
-    The synthetic relations carry no signal, so the trained distributions stay near-uniform; a trained model's are peaked.
-    score_func is therefore sharpened (x30, as tests/golden/make_golden_e2e.py does) so that the Evaluator's threshold and
-    top-p cut have something to decide."""
+def make_checkpoint(variant="d50"):
+    """The reference's own trainer on CPU (Trainer_KBQA.train_epoch, train_model.py:209-233) over the train split,
+    then save_ckpt('final').  Nothing is sharpened or edited afterwards: the dataset carries a relation-path signal and
+    the trained model's distributions are peaked by themselves."""
     import argparse
     import numpy as np
     import torch
@@ -116,7 +204,8 @@ def make_checkpoint():
     import parsing
     parser = argparse.ArgumentParser()
     parsing.add_parse_args(parser)
-    args = parser.parse_args(MODEL_ARGV + ["--checkpoint_dir", CKPT, "--experiment_name", EXP, "--lr", "0.005"])
+    exp = VARIANTS[variant]["train"]
+    args = parser.parse_args(variant_argv(variant) + ["--checkpoint_dir", CKPT, "--experiment_name", exp, "--lr", "0.005"])
     args.use_cuda = False
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)
@@ -124,29 +213,42 @@ def make_checkpoint():
     from train_model import Trainer_KBQA
     from utils import create_logger
     trainer = Trainer_KBQA(args=vars(args), model_name=args.model_name, logger=create_logger(args))
-    for epoch in range(3):
+    for epoch in range(VARIANTS[variant]["epochs"]):
         loss, _, h1, f1 = trainer.train_epoch()
-        print("stage_ref: epoch %d loss %.4f train h1 %.3f f1 %.3f" % (epoch + 1, loss, np.mean(h1), np.mean(f1)))
-    with torch.no_grad():
-        trainer.model.reasoning.score_func.weight.mul_(30.0)
+        print("stage_ref[%s]: epoch %d loss %.4f train h1 %.3f f1 %.3f" % (variant, epoch + 1, loss, np.mean(h1), np.mean(f1)),
+              flush=True)
     trainer.save_ckpt("final")
 
 
-def reference_eval_cpu():
-    """main.py --is_eval of the pure reference on CPU (own process: main.py parses sys.argv and builds loggers)."""
+def reference_eval_cpu(variant="d50", data=None, batch=None, tag=None):
+    """main.py --is_eval of the pure reference on CPU (own process: main.py parses sys.argv and builds loggers).
+    Returns the logged metrics and the wall-clock seconds of the process."""
+    import time
+    argv = variant_argv(variant)
+    if data is not None:
+        argv = [data if a == DATA else a for a in argv]
+    if batch is not None:
+        argv = argv[:argv.index("--test_batch_size") + 1] + [str(batch)] + argv[argv.index("--test_batch_size") + 2:]
+    tag = tag or variant
     code = ("import sys, runpy; sys.path.insert(0, %r); sys.path.insert(0, %r); import stage_ref; "
             "stage_ref.shim_reference_startup_bugs(); sys.argv = ['main.py'] + %r; "
             "runpy.run_path(%r, run_name='__main__')") % (
-        GNN, HERE, MODEL_ARGV + ["--is_eval", "--load_experiment", EXP + "-final.ckpt", "--checkpoint_dir", CKPT,
-                                 "--experiment_name", EXP + "_cpu"], os.path.join(GNN, "main.py"))
+        GNN, HERE, argv + ["--is_eval", "--load_experiment", ckpt_name(variant), "--checkpoint_dir", CKPT,
+                           "--experiment_name", tag + "_cpu"], os.path.join(GNN, "main.py"))
     env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    t0 = time.time()
     r = subprocess.run([sys.executable, "-c", code], cwd=GNN, env=env, capture_output=True, text=True)
+    wall = time.time() - t0
     if r.returncode != 0:
         raise SystemExit("reference evaluation failed:\n" + r.stdout[-3000:] + r.stderr[-3000:])
-    out = r.stdout + r.stderr
-    metrics = parse_metrics(out)
-    shutil.copyfile(os.path.join(CKPT, EXP + "_cpu_test.info"), os.path.join(CKPT, "expected_test.info"))
-    with open(os.path.join(CKPT, "expected.json"), "w") as f:
+    return parse_metrics(r.stdout + r.stderr), wall
+
+
+def expect(variant):
+    metrics, wall = reference_eval_cpu(variant)
+    shutil.copyfile(os.path.join(CKPT, variant + "_cpu_test.info"), os.path.join(CKPT, "expected_%s_test.info" % variant))
+    metrics["cpu_wall_s"] = round(wall, 1)
+    with open(os.path.join(CKPT, "expected_%s.json" % variant), "w") as f:
         json.dump(metrics, f, indent=1)
     return metrics
 
@@ -163,9 +265,23 @@ def parse_metrics(log_text):
 
 
 def staged() -> bool:
-    return all(os.path.exists(p) for p in (os.path.join(GNN, "main.py"), os.path.join(DATA, "test.json"),
-                                           os.path.join(CKPT, EXP + "-final.ckpt"), os.path.join(CKPT, "expected_test.info"),
-                                           os.path.join(CKPT, "expected.json")))
+    need = [os.path.join(GNN, "main.py"), os.path.join(DATA, "test.json"), os.path.join(DATA, "VERSION")]
+    for v in VARIANTS:
+        need += [os.path.join(CKPT, ckpt_name(v)), os.path.join(CKPT, "expected_%s_test.info" % v),
+                 os.path.join(CKPT, "expected_%s.json" % v)]
+    if not all(os.path.exists(p) for p in need):
+        return False
+    return open(os.path.join(DATA, "VERSION")).readline().strip() == DATASET_VERSION
+
+
+def _train_in_subprocess(variant):
+    # own process: the reference's modules must not leak into the caller's sys.modules / logging setup
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import stage_ref; stage_ref.make_checkpoint(%r)"
+                        % (HERE, variant)],
+                       cwd=GNN, env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""), capture_output=True, text=True)
+    if r.returncode != 0:
+        raise SystemExit("checkpoint creation failed:\n" + r.stdout[-3000:] + r.stderr[-3000:])
+    print("\n".join(l for l in r.stdout.splitlines() if l.startswith("stage_ref")), flush=True)
 
 
 def main(force=False):
@@ -173,18 +289,21 @@ def main(force=False):
         print("oracle/_ref already staged")
         return
     stage_sources()
-    write_dataset(DATA)
-    # own process: the reference's modules must not leak into the caller's sys.modules / logging setup
-    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import stage_ref; stage_ref.make_checkpoint()" % HERE],
-                       cwd=GNN, env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""), capture_output=True, text=True)
-    if r.returncode != 0:
-        raise SystemExit("checkpoint creation failed:\n" + r.stdout[-3000:] + r.stderr[-3000:])
-    print("\n".join(l for l in r.stdout.splitlines() if l.startswith("stage_ref:")))
-    metrics = reference_eval_cpu()
-    lines = open(os.path.join(CKPT, "expected_test.info")).read().splitlines()
-    ncand = [len(json.loads(l)["cand"]) for l in lines]
-    print("oracle/_ref staged: CPU reference metrics %s; candidates per test question: min %d max %d" %
-          (metrics, min(ncand), max(ncand)))
+    if os.path.isdir(CKPT):
+        shutil.rmtree(CKPT)
+    stats = write_dataset(DATA)
+    print("stage_ref: dataset %s" % json.dumps(stats), flush=True)
+    for v in VARIANTS:
+        if VARIANTS[v]["epochs"]:
+            _train_in_subprocess(v)
+    summary = {}
+    for v in VARIANTS:
+        summary[v] = expect(v)
+        lines = open(os.path.join(CKPT, "expected_%s_test.info" % v)).read().splitlines()
+        ncand = [len(json.loads(l)["cand"]) for l in lines]
+        print("stage_ref[%s]: CPU reference metrics %s; candidates per test question: min %d max %d" %
+              (v, summary[v], min(ncand), max(ncand)), flush=True)
+    print("oracle/_ref staged: " + json.dumps({v: m["test"] for v, m in summary.items()}))
 
 
 if __name__ == "__main__":

@@ -185,3 +185,57 @@ def test_c2_full_batch_against_oracle_slices(dev, path, math_mode):
         want = otorch.run_stack(sub, sfe, params)
         part = {k: [x[lo:hi] for x in got[k]] for k in ("h", "dist")}
         _check_stack(part, want, cfg.T * cfg.L, what="C2 questions %d:%d path %d" % (lo, hi, path))
+
+
+def _full_batch_vs_oracle_slices(cfg, dev, path, slices, what):
+    """The FULL batch of a config on the GPU (only the listed question slices are copied back per layer call) against
+    the torch-CPU oracle on those slices of the same batch.  Returns the layer's structure."""
+    import oracle.rearev_torch_cpu as otorch
+    from gnnrag_amd import stack, synth
+    batch = synth.make_batch(cfg)
+    feats = synth.make_features(cfg)
+    params = synth.make_layer_params(cfg)
+    dvi = stack.DeviceInputs(batch, feats, dev)
+    layer = stack.build_layer(cfg, batch, params, dev, path)
+    stack.init_reason(layer, batch, dvi, dvi.h0)
+    got = {sl: {"h": [], "dist": []} for sl in slices}
+    with torch.no_grad():
+        for t in range(cfg.T):
+            dist = dvi.seed_dist
+            for j in range(cfg.L):
+                _, dist = layer(dist, dvi.ins[t], step=j, return_score=True)
+                for lo, hi in slices:
+                    got[(lo, hi)]["h"].append(layer.local_entity_emb[lo:hi].cpu().numpy())
+                    got[(lo, hi)]["dist"].append(dist[lo:hi].cpu().numpy())
+    for lo, hi in slices:
+        sub, sfe = _slice_questions(batch, feats, lo, hi)
+        want = otorch.run_stack(sub, sfe, params)
+        _check_stack(got[(lo, hi)], want, cfg.T * cfg.L, what="%s questions %d:%d path %d" % (what, lo, hi, path))
+    return layer.plan
+
+
+def test_c5_full_batch_dense_hub_form_against_oracle_slices(dev):
+    """BASELINE config 5 at its FULL per-GPU batch (32 questions x 20 000 nodes, 7.04 M facts, every question uses all
+    6001 relation rows): the gather walk with the XCD-aware mapping and - asserted by reading the kernels' own
+    decision back from the device - the DENSE hub form (weight blocks sized on the device fit the workspace at B = 32,
+    8 relation ranges per question: the path bench.py --workload C5 times).  Oracle: first and last question."""
+    from gnnrag_amd import ops, synth
+    cfg = synth.CONFIGS["C5"]
+    assert cfg.B == 32
+    plan = _full_batch_vs_oracle_slices(cfg, dev, 2, [(0, 1), (cfg.B - 1, cfg.B)], "C5 full")
+    assert ops.aggregate_fused_variant(plan, cfg.D) == ops.WALK_L2_GATHER
+    form = ops.aggregate_fused_hub_form(plan, cfg.D, cfg.I)
+    assert form["form"] == ops.HUB_FORM_DENSE, form
+    assert form["hubs"][1] >= cfg.B and form["relation_ranges"] == 8, form     # Zipf heads: hubs in the inverse direction
+
+
+def test_c4_full_batch_against_oracle_slices(dev):
+    """BASELINE config 4 at its FULL batch (32 questions x 5000 nodes, 30 000 typed edges, 3 instructions, 4 layers):
+    the 16-column LDS walk (no dense hub kernels in that dispatch - asserted) and the three-instruction tables."""
+    from gnnrag_amd import ops, synth
+    cfg = synth.CONFIGS["C4"]
+    assert cfg.B == 32
+    for path in (2, 1):
+        plan = _full_batch_vs_oracle_slices(cfg, dev, path, [(0, 2), (cfg.B - 2, cfg.B)], "C4 full")
+    assert ops.aggregate_fused_variant(plan, cfg.D) == ops.WALK_LDS_16
+    assert ops.aggregate_fused_hub_form(plan, cfg.D, cfg.I)["form"] == ops.HUB_FORM_NONE

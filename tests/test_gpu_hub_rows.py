@@ -46,14 +46,36 @@ def _graph(seed=3):
     return B, N, R, h[p], r[p], t[p]
 
 
-def _run(dev):
+def _graph_blocks_do_not_fit(seed=4):
+    """Many hubs of few facts over a large relation vocabulary: the hub-by-relation weight blocks (hubs x relations x
+    4 B) outgrow the workspace region they live in (16 B per fact), so the device-side decision must be the chunked
+    fallback."""
+    rng = np.random.default_rng(seed)
+    B, N, R = 2, 3000, 2200
+    H, Rl, T = [], [], []
+    for q in range(B):
+        H.append(np.arange(100, 100 + R) + q * N); Rl.append(np.arange(R)); T.append(rng.integers(100, N, R) + q * N)
+        for hub in range(90):                                 # 90 hubs x 260 facts each, as heads (direction 1)
+            H.append(np.full(260, hub) + q * N); Rl.append(rng.integers(0, R, 260)); T.append(rng.integers(100, N, 260) + q * N)
+    h, r, t = (np.concatenate(x).astype(np.int64) for x in (H, Rl, T))
+    p = rng.permutation(len(h))
+    return B, N, R, h[p], r[p], t[p]
+
+
+def _run(dev, graph=None, want_form=None):
     from gnnrag_amd import ops
-    B, N, R, h, r, t = _graph()
+    B, N, R, h, r, t = (graph or _graph)()
     D = 200
     plan = ops.CsrPlan(h, r, t, B, N, R, dev)
     assert ops.aggregate_fused_variant(plan, D) == ops.WALK_L2_GATHER
     got_plan = plan.to_host()
-    assert got_plan["n_heavy"][0] >= 1 and got_plan["n_heavy"][1] >= 3
+    if graph is None:
+        assert got_plan["n_heavy"][0] >= 1 and got_plan["n_heavy"][1] >= 3
+    # which hub form THIS call takes: the kernels' own predicate on the call's arguments, read back from the device
+    form = ops.aggregate_fused_hub_form(plan, D, 1)
+    if want_form is None:
+        want_form = ops.HUB_FORM_NONE if os.environ.get("GNNRAG_HUB_DENSE") == "0" else ops.HUB_FORM_DENSE
+    assert form["form"] == want_form and form["hubs"] == (got_plan["n_heavy"][0], got_plan["n_heavy"][1]), form
     rng = np.random.default_rng(9)
     dist = rng.random((B, N)).astype(np.float32)
     dist[:, ::3] = 0.0
@@ -77,8 +99,18 @@ def _run(dev):
 def test_hub_rows_dense_form():
     import gnnrag_amd  # noqa: F401
     dev = torch.device("cuda", 0)
-    assert os.environ.get("GNNRAG_HUB_DENSE", "1") != "0"
-    out, want, scale, _ = _run(dev)
+    out, want, scale, _ = _run(dev)         # asserts HUB_FORM_DENSE as read back from the device
+    assert np.abs(out - want).max() <= 2e-5 * scale, np.abs(out - want).max() / scale
+
+
+def test_hub_rows_device_side_fallback_when_the_weight_blocks_do_not_fit():
+    """The silent device-side fallback, made visible: same entry point, dense form compiled in and enabled, but the
+    weight blocks exceed the workspace - the read-back says CHUNKED and the result still matches float64."""
+    import gnnrag_amd  # noqa: F401
+    from gnnrag_amd import ops
+    if os.environ.get("GNNRAG_HUB_DENSE") == "0":
+        pytest.skip("dense hub form switched off in this process")
+    out, want, scale, _ = _run(torch.device("cuda", 0), _graph_blocks_do_not_fit, ops.HUB_FORM_CHUNKED)
     assert np.abs(out - want).max() <= 2e-5 * scale, np.abs(out - want).max() / scale
 
 

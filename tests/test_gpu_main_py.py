@@ -1,7 +1,7 @@
 """The UNMODIFIED reference entry point on the MI355X ("Next round" item 2; north_star: "drops into
 main.py/evaluate.py unchanged ... Hits@1 identical"):
 
-    python tools/run_reference.py oracle/_ref/gnn ReaRev --is_eval --load_experiment synth-final.ckpt ...
+    python tools/run_reference.py oracle/_ref/gnn ReaRev --is_eval --load_experiment synth-final.ckpt ...   (per staged variant)
 
 i.e. gnn/main.py -> Trainer_KBQA -> load_data -> ReaRev (built from the reference's own models/ReaRev/rearev.py, whose
 imports resolve to this package's modules) -> load_ckpt of a checkpoint the reference's trainer wrote on CPU ->
@@ -32,30 +32,26 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF = os.path.join(REPO, "oracle", "_ref")
-GNN = os.path.join(REF, "gnn")
-CKPT = os.path.join(REF, "ckpt")
-DATA = os.path.join(REF, "data", "synth") + "/"
-STAGED = all(os.path.exists(p) for p in (os.path.join(GNN, "main.py"), os.path.join(CKPT, "synth-final.ckpt"),
-                                          os.path.join(CKPT, "expected_test.info"), os.path.join(CKPT, "expected.json")))
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+import stage_ref  # noqa: E402  (paths, per-variant argv; test infrastructure)
+
+GNN, CKPT = stage_ref.GNN, stage_ref.CKPT
+STAGED = stage_ref.staged()
 
 TOL = 1e-4
 
 
-def _run_main_py(tmp_path, extra_env):
+def _run_main_py(tmp_path, variant, extra_env, tag):
     ck = str(tmp_path) + "/"
-    shutil.copyfile(os.path.join(CKPT, "synth-final.ckpt"), os.path.join(ck, "synth-final.ckpt"))
-    argv = [sys.executable, os.path.join(REPO, "tools", "run_reference.py"), GNN,
-            "ReaRev", "--data_folder", DATA, "--lm", "lstm", "--relation_word_emb", "False",
-            "--entity_dim", "50", "--kg_dim", "25", "--num_iter", "3", "--num_ins", "2", "--num_gnn", "3",
-            "--batch_size", "16", "--test_batch_size", "16", "--name", "synth",
-            "--is_eval", "--load_experiment", "synth-final.ckpt", "--checkpoint_dir", ck, "--experiment_name", "gpu"]
+    shutil.copyfile(os.path.join(CKPT, stage_ref.ckpt_name(variant)), os.path.join(ck, stage_ref.ckpt_name(variant)))
+    argv = [sys.executable, os.path.join(REPO, "tools", "run_reference.py"), GNN] + stage_ref.variant_argv(variant) + [
+        "--is_eval", "--load_experiment", stage_ref.ckpt_name(variant), "--checkpoint_dir", ck, "--experiment_name", "gpu"]
     import socket
     with socket.socket() as sk:                       # a free rendezvous port for the forced process group
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ, GNNRAG_DEVICE_FACTS="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **extra_env)
-    r = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=900)
     log = r.stdout + r.stderr
     assert r.returncode == 0, log[-4000:]
     metrics = {}
@@ -66,22 +62,33 @@ def _run_main_py(tmp_path, extra_env):
     lines = open(os.path.join(ck, "gpu_test.info")).read().splitlines()
     out_dir = os.path.join(REPO, "gpurun_out", "main_py")
     os.makedirs(out_dir, exist_ok=True)
-    tag = "dist" if "GNNRAG_FORCE_DIST" in extra_env else "structures" if extra_env else "single"
     with open(os.path.join(out_dir, "run_%s.log" % tag), "w") as f:
         f.write(log[-20000:])
     shutil.copyfile(os.path.join(ck, "gpu_test.info"), os.path.join(out_dir, "gpu_test_%s.info" % tag))
     return metrics, [json.loads(l) for l in lines], log
 
 
+CASES = [("d50", "single"), ("d50", "force_dist"), ("d50", "structure_cache"), ("d200", "single"), ("d200", "structure_cache"),
+         ("cwq", "single")]
+
+
 @pytest.mark.skipif(not STAGED, reason="oracle/_ref not staged (python oracle/stage_ref.py in the build container)")
-@pytest.mark.parametrize("mode", ["single", "force_dist", "structure_cache"])
-def test_unmodified_main_py_eval_matches_cpu_reference(tmp_path, mode):
-    want_metrics = json.load(open(os.path.join(CKPT, "expected.json")))
-    want = [json.loads(l) for l in open(os.path.join(CKPT, "expected_test.info")).read().splitlines()]
+@pytest.mark.parametrize("variant,mode", CASES, ids=["%s-%s" % c for c in CASES])
+def test_unmodified_main_py_eval_matches_cpu_reference(tmp_path, variant, mode):
+    """520 test + 160 dev questions of the LEARNABLE staged dataset (a relation path from the seed determines the answer;
+    subgraphs up to 2000 entities, 16 test questions with a hub row of > 4096 facts), checkpoints trained by the
+    reference's own trainer on CPU: d50 (released-checkpoint dims), d200 (the benchmark's hidden size), cwq (--name cwq:
+    the seed keeps its candidate slot, dataset_load.py:249-257)."""
+    want_metrics = json.load(open(os.path.join(CKPT, "expected_%s.json" % variant)))
+    want = [json.loads(l) for l in open(os.path.join(CKPT, "expected_%s_test.info" % variant)).read().splitlines()]
+    # the comparison is only worth something when the reference itself answers a good part of the questions
+    assert 0.3 <= want_metrics["test"][1] <= 0.9 and 0.3 <= want_metrics["eval"][1] <= 0.95, want_metrics
+    assert len(want) >= 500
     env = {"force_dist": {"GNNRAG_FORCE_DIST": "1"}, "structure_cache": {"GNNRAG_DEVICE_STRUCTURES": "1"}}.get(mode, {})
-    metrics, got, log = _run_main_py(tmp_path, env)
+    metrics, got, log = _run_main_py(tmp_path, variant, env, "%s_%s" % (variant, mode))
     assert "gnnrag_amd: native library mapped" in log, log[-2000:]        # the child ran on libgnnrag_hip.so
-    assert metrics == want_metrics, (metrics, want_metrics)               # logged with 4 decimals by the reference
+    for split in ("eval", "test"):                                        # logged with 4 decimals by the reference
+        assert metrics[split] == want_metrics[split], (split, metrics, want_metrics)
     assert len(got) == len(want) and len(got) > 0
     worst = 0.0
     for g, w in zip(got, want):
@@ -92,5 +99,5 @@ def test_unmodified_main_py_eval_matches_cpu_reference(tmp_path, mode):
         for (_, pg), (_, pw) in zip(g["cand"], w["cand"]):
             worst = max(worst, abs(pg - pw))
     assert worst <= TOL, worst
-    print("main.py on the MI355X (%s): %d questions, metrics %s, max |candidate probability - CPU reference| = %.3g"
-          % (mode, len(got), metrics, worst))
+    print("main.py on the MI355X (%s, %s): %d questions, H@1 %.4f (dev %.4f), max |candidate probability - CPU reference| = %.3g"
+          % (variant, mode, len(got), metrics["test"][1], metrics["eval"][1], worst))

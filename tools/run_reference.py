@@ -99,7 +99,7 @@ def main():
     import evaluate
     if not os.environ.get("GNNRAG_NO_EVAL_PATCH"):
         from gnnrag_amd import eval_tail
-        evaluate.Evaluator.evaluate = eval_tail.evaluate
+        eval_tail.patch_evaluator_class(evaluate.Evaluator)
     if world > 1 or force_dist:
         from gnnrag_amd import shard
         _ev_init = evaluate.Evaluator.__init__

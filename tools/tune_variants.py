@@ -54,6 +54,8 @@ VARIANTS = {
     "heavy_grid512": {"GNNRAG_HEAVY_GRID": 512}, "heavy_grid2048": {"GNNRAG_HEAVY_GRID": 2048},
     "light_nogather": {"GNNRAG_LIGHT_ABL": 1}, "light_nostore": {"GNNRAG_LIGHT_ABL": 2}, "light_l2hit": {"GNNRAG_LIGHT_ABL": 4},
     "light_nomem": {"GNNRAG_LIGHT_ABL": 3}, "hub_ks32": {"GNNRAG_HUB_KS_MAX": 32}, "hub_ks8": {"GNNRAG_HUB_KS_MAX": 8}, "hub_ks4": {"GNNRAG_HUB_KS_MAX": 4}, "hub_wg8192": {"GNNRAG_HUB_W_GRID": 8192}, "hub_wg512": {"GNNRAG_HUB_W_GRID": 512},
+    # round 4: the compiler SLP-packs the split's subtractions into v_pk_add_f32, which is expensive beside MFMAs
+    "noslp": {"__flags__": ["-fno-slp-vectorize"]},
     "split_trunc": {"GNNRAG_SPLIT_RN": 0},      # the truncation form of the exact 3-way bf16 split (rounds 1-2)
     "vq_nolds": {"GNNRAG_VQ_ABL": 1}, "vq_noa": {"GNNRAG_VQ_ABL": 2}, "vq_nostage": {"GNNRAG_VQ_ABL": 4},
     "upd_nolds": {"GNNRAG_UPD_ABL": 1}, "upd_noa": {"GNNRAG_UPD_ABL": 2}, "upd_noadd": {"GNNRAG_UPD_ABL": 4},
