@@ -77,7 +77,10 @@ def main():
     ap.add_argument("--launch", choices=["eager", "graph"], default="eager",
                     help="eager: one gnnrag_reason_stack call per step; graph: the step captured once as a hipGraph "
                          "(gnnrag_reason_stack_capture) and replayed")
-    ap.add_argument("--cpu-sample-b", type=int, default=8)
+    ap.add_argument("--cpu-sample-b", type=int, default=16,
+                    help="questions of the CPU-baseline sample (the reference's own layer on the host cores; 64 = the full C2 batch)")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the end-to-end block (unmodified main.py --is_eval on the staged dataset, GPU and CPU)")
     ap.add_argument("--clock-ramp-ms", type=float, default=600.0,
                     help="keep the chip busy with HBM copy kernels for this long before the warm-up steps (clock ramp of an "
                          "idle chip); 0 = off")
@@ -325,6 +328,11 @@ def main():
         out.update(roofline_leg(cfg, layer, devin, ops, F_g, args.steps))
         if not args.no_cpu_baseline and world == 1:     # rank 0 at N = 1 only (the other ranks would idle)
             out["cpu_baseline"] = cpu_baseline_leg(cfg, args.cpu_sample_b)
+        if not args.no_e2e and not args.no_cpu_baseline and world == 1:
+            try:
+                out["e2e"] = e2e_leg()
+            except Exception as e:               # the staged reference is test infrastructure: never fail the bench on it
+                out["e2e"] = {"error": repr(e)[:400]}
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
@@ -675,6 +683,14 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
             o["frac_of_fp32_mfma_peak"] = ach / FP32_MFMA_PEAK_TFLOPS
         return o
 
+    # the relation-table launch exists only because e2e_linear was pushed into per-question
+    # tables - charge it to the aggregation next to `frac`
+    if fused and "relation_tables" in ms:
+        t_all = ms["aggregate_fused_dense"] + ms["relation_tables"]
+        r_fused["frac_incl_tables"] = ba / (t_all * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        r_fused["frac_incl_tables_note"] = ("pinned algorithmic bytes / (dense-prior walk %.1f us + relation-table launch %.1f us)"
+                                            % (ms["aggregate_fused_dense"] * 1e3, ms["relation_tables"] * 1e3))
+        r_fused["guide_copy_ceiling_GBps"] = 6290.0          # MI355X_MICROARCH.md: float4 copy, 79 % of 8 TB/s
     out = {
         "path": "fused" if fused else "unfused",
         "roofline": r_fused if fused else r_unf,
@@ -697,6 +713,91 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
         },
         "kernel_ms": ms,
     }
+    # the self-block update streams h, nbr and h' (3 x BN x D x 4 B): it sits nearer its HBM roof than its MFMA roof -
+    # both fractions are reported
+    upd = out["roofline_dense"]["update_score_fused"]
+    upd_bytes = 3.0 * B * N * D * 4 + B * N * 8 + D * D * 4
+    upd["hbm"] = {"algorithmic_bytes_per_launch": upd_bytes,
+                  "achieved_GBps": upd_bytes / (ms["update_score_fused"] * 1e-3) / 1e9,
+                  "frac": upd_bytes / (ms["update_score_fused"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                  "traffic": pmc.get("update_score_fused_hbm_bytes_per_launch"),
+                  "note": "h read + nbr read + h' write; `frac` of 8 TB/s"}
+    upd["frac_mfma"] = upd["frac"]
+    upd["frac_hbm"] = upd["hbm"]["frac"]
+    return out
+
+
+def e2e_leg():
+    """End to end through the reference's OWN entry point (SURVEY 8d "for C1 use the real entry"):
+    the unmodified ``gnn/main.py --is_eval`` (staged by oracle/stage_ref.py into the git-ignored oracle/_ref/, which travels
+    to the GPU box) on the staged synthetic dataset, driven by tools/run_reference.py -
+      * on the MI355X with this package's modules underneath (all 160 dev + 520 test questions), with the per-stage split
+        get_batch / structure build / forward / Evaluator tail (device-synchronised timers at the reference's seams);
+      * the PURE reference on the host cores (GNNRAG_PURE_REFERENCE=1, no substitution) on a bounded sample: the first 32
+        test questions (data/synth_sample), same checkpoint, same flags;
+      * BASELINE config 1 as SURVEY 8d words it: ``Evaluator.evaluate`` with ``test_batch_size=1`` and the
+        released-checkpoint dims (variant d50), GPU on the full splits, CPU on the sample.
+    Questions/s = questions of the TEST split / wall time of its ``Evaluator.evaluate`` call (get_batch, forward,
+    candidate selection, metrics, .info writing - everything the reference does per batch; model construction, checkpoint
+    and dataset loading are not in it)."""
+    import shutil
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import stage_ref
+    if not stage_ref.staged():
+        return {"skipped": "oracle/_ref not staged (python oracle/stage_ref.py in the build container)"}
+    sample = os.path.join(stage_ref.DST, "data", "synth_sample") + "/"
+    ncpu = os.cpu_count() or 1
+    cpu_threads = min(32, ncpu)
+
+    def run(variant, pure, batch, data=None):
+        argv = list(stage_ref.variant_argv(variant))
+        if data:
+            argv = [data if a == stage_ref.DATA else a for a in argv]
+        i = argv.index("--test_batch_size")
+        argv[i + 1] = str(batch)
+        ck = tempfile.mkdtemp(prefix="gnnrag_e2e_") + "/"
+        shutil.copyfile(os.path.join(stage_ref.CKPT, stage_ref.ckpt_name(variant)), ck + stage_ref.ckpt_name(variant))
+        cmd = [sys.executable, os.path.join(REPO, "tools", "run_reference.py"), stage_ref.GNN] + argv + [
+            "--is_eval", "--load_experiment", stage_ref.ckpt_name(variant), "--checkpoint_dir", ck, "--experiment_name", "e2e"]
+        env = dict(os.environ, GNNRAG_E2E_TIMES="1")
+        if pure:
+            env.update(GNNRAG_PURE_REFERENCE="1", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(cpu_threads),
+                       MKL_NUM_THREADS=str(cpu_threads))
+        else:
+            env.update(GNNRAG_DEVICE_FACTS="1")
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        wall = time.perf_counter() - t0
+        shutil.rmtree(ck, ignore_errors=True)
+        log = r.stdout + r.stderr
+        line = [l for l in log.splitlines() if l.startswith("GNNRAG_E2E ")]
+        if r.returncode != 0 or not line:
+            return {"error": log[-600:]}
+        T = json.loads(line[-1][len("GNNRAG_E2E "):])
+        test = T["evaluate_calls"][-1]                    # evaluate_single: valid split first, test split last
+        import re
+        h1 = re.findall(r"TEST F1: ([0-9.]+), H1: ([0-9.]+)", log)
+        nb = max(test["batches"], 1)
+        fwd = test["forward_s"] - test["structure_s"]
+        tail = test["seconds"] - test["get_batch_s"] - test["forward_s"]
+        return {"questions": test["questions"], "seconds": test["seconds"], "questions_per_s": test["questions"] / test["seconds"],
+                "test_batch_size": batch, "batches": test["batches"], "padded_nodes_per_question": test["max_local_entity"],
+                "stages_ms_per_batch": {"get_batch": 1e3 * test["get_batch_s"] / nb, "structure_build": 1e3 * test["structure_s"] / nb,
+                                        "forward_without_structure": 1e3 * fwd / nb, "evaluator_tail": 1e3 * tail / nb},
+                "test_f1_h1": [float(x) for x in h1[-1]] if h1 else None, "process_wall_s": wall,
+                "threads": T.get("threads") if pure else None}
+
+    out = {"entry": "unmodified gnn/main.py --is_eval via tools/run_reference.py; staged synthetic dataset (oracle/stage_ref.py: "
+                    "a relation path from the seed determines the answer; 520 test questions, subgraphs up to 2000 entities)",
+           "host_cores": ncpu}
+    out["d200_batch16"] = {"gpu": run("d200", False, 16), "cpu_reference_sample32": run("d200", True, 16, sample)}
+    out["c1_d50_batch1"] = {"gpu": run("d50", False, 1), "cpu_reference_sample32": run("d50", True, 1, sample)}
+    for k in ("d200_batch16", "c1_d50_batch1"):
+        g, c = out[k]["gpu"], out[k]["cpu_reference_sample32"]
+        if "questions_per_s" in g and "questions_per_s" in c:
+            out[k]["gpu_over_cpu_questions_per_s"] = g["questions_per_s"] / c["questions_per_s"]
     return out
 
 
@@ -747,13 +848,19 @@ def reference_cpu_leg(cfg, sample_b):
         if best is None or dt < best[0]:
             best = (dt, nt)
     torch.set_num_threads(best[1])
-    runs = [one_pass() for _ in range(2)]
+    one_pass()                                   # SURVEY 8d protocol: 1 warm-up + 5 timed passes, median
+    runs = [one_pass() for _ in range(5)]
     t = float(np.median([r[1] for r in runs]))
     return {"value": sub.B * sub.E * sub.L / t, "unit": "typed-edge*layers/s", "cores": best[1], "kind": "reference",
             "sample": "%d questions of the same %s shape (N=%d, E=%d, D=%d, I=%d, L=%d) through the reference's own "
                       "ReasonGNNLayer (sources staged by oracle/stage_ref.py), torch CPU, thread count chosen by a probe, "
-                      "2 timed passes, median %.2f s/pass; build_matrix %.2f s per batch on top"
-                      % (sub.B, cfg.name, sub.N, sub.E, sub.D, sub.I, sub.L, t, float(np.median([r[0] for r in runs]))),
+                      "1 warm-up + 5 timed passes, median %.2f s/pass (min %.2f, max %.2f); build_matrix %.2f s per batch on top"
+                      % (sub.B, cfg.name, sub.N, sub.E, sub.D, sub.I, sub.L, t, min(r[1] for r in runs), max(r[1] for r in runs),
+                         float(np.median([r[0] for r in runs]))),
+            "scaling_assumption": "rate of the %d-question sample taken as the rate of the %d-question batch: questions are "
+                                  "independent subgraphs and every reference op is linear in the number of facts / node "
+                                  "slots (the survey's full-batch run, 11.7 s per pass on 8 vCPUs, is quoted beside it); "
+                                  "--cpu-sample-b %d times the whole batch" % (sub.B, cfg.B, cfg.B),
             "seconds_per_pass": t, "build_matrix_seconds": float(np.median([r[0] for r in runs]))}
 
 

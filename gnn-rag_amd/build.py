@@ -19,7 +19,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libgnnrag_hip.so")
 ARCH = "gfx950"
-SOURCES = ["csr_plan.hip", "aggregate.hip", "aggregate_bwd.hip", "gemm_f32.hip", "tables_b3.hip", "softmax_layer.hip", "rel_transform.hip", "gemm_tn.hip", "eval_tail.hip", "query_update.hip", "frontier.hip"]
+SOURCES = ["csr_plan.hip", "aggregate.hip", "aggregate_bwd.hip", "gemm_f32.hip", "tables_b3.hip", "update_wr.hip", "softmax_layer.hip", "rel_transform.hip", "gemm_tn.hip", "eval_tail.hip", "query_update.hip", "frontier.hip"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(REPO, "include"),
          "-I" + CSRC, "-Wno-unused-result"]
 
@@ -55,7 +55,7 @@ def build_variant(name: str, defines: dict, verbose: bool = False) -> str:
     objdir = os.path.join(LIBDIR, "obj_" + name)
     os.makedirs(objdir, exist_ok=True)
     # "__flags__": extra compiler flags of the variant (e.g. ["-fno-slp-vectorize"]); everything else is a -D switch
-    extra = list(defines.get("__flags__", [])) + ["-D%s=%s" % kv for kv in defines.items() if kv[0] != "__flags__"]
+    extra = list(defines.get("__flags__", [])) + ["-D%s=%s" % kv for kv in defines.items() if not kv[0].startswith("__")]
 
     def cc(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))

@@ -16,7 +16,9 @@ int update_b3_launch_z(const float* h, const float* nbr, const float* W, const f
 
 // Row-gated form of the self-block update: `nbr` holds valid data only in the rows whose byte in add_flag is non-zero,
 // every other row reads the ZERO ROW behind the buffer (row index BN), so the unflagged rows of nbr are never
-// touched (frontier layers: frontier.hip).  add_flag: [BN + 4 bytes of padding], 4-byte aligned.
+// touched (frontier layers: frontier.hip).  add_flag: [BN + at least 16 bytes of readable padding] (the kernels
+// read a lane's four row gates as one dword at tile granularity: up to 15 bytes past BN when BN % 16 != 0; the frontier
+// workspace pads by 64), 4-byte aligned.
 // Returns GNNRAG_E_UNSUPPORTED (nothing launched) when the kernel the shape would take has no gated form.
 int update_score_fused_rows(const float* h, const float* nbr, const uint8_t* add_flag, const float* W, const float* b,
                             const float* w_s, const float* b_s, const float* mask, float* h_out, float* score,
@@ -29,6 +31,10 @@ int update_b3_launch_f(const float* h, const float* nbr, const uint8_t* add_flag
 bool update_rows_supported(const float* h, const float* nbr, const float* W, const float* h_out, int64_t BN, int32_t D,
                            int32_t I, int32_t math);
 bool update_b3_shape_ok(int64_t BN, int32_t D, int32_t ldw);
+// update_wr.hip: the same update with the weight planes in registers (hidden size 200); GNNRAG_E_UNSUPPORTED otherwise
+int update_wr_launch_f(const float* h, const float* nbr, const uint8_t* add_flag, const float* W, const float* b,
+                       const float* w_s, const float* b_s, const float* mask, float* h_out, float* score, int64_t BN,
+                       int32_t D, int32_t ldw, hipStream_t stream);
 
 // frontier.hip: relation tables of small batches on the one-workgroup-per-tile, split-k kernel (exact fp32)
 int tables_small_launch(const gnnrag_csr* csr, const float* T_fwd, const float* T_inv, const float* ins, const float* W,
@@ -43,5 +49,9 @@ const uint8_t* frontier_row_flags(const gnnrag_csr* csr, const void* fws);
 int update_score_fused_z(const float* h, const float* nbr, const float* W, const float* b, const float* w_s,
                          const float* b_s, const float* mask, float* h_out, float* score, int64_t BN, int32_t D,
                          int32_t I, int32_t math, hipStream_t stream, bool score_zeroed);
+
+// rel_transform.hip: whether gnnrag_rel_transform takes these operands (then, and only then, it writes T and the planes)
+bool rel_transform_accepts(const float* relfeat_fwd, const float* relfeat_inv, int64_t R1, int32_t D, int32_t L,
+                           const gnnrag_layer_params* layers, int32_t pos_rows, const float* T_out, const void* planes_out);
 
 }  // namespace gnnrag

@@ -445,11 +445,18 @@ const uint8_t* gnnrag::frontier_row_flags(const gnnrag_csr* csr, const void* fws
   return (const uint8_t*)fws + frontier_ws(csr).row_flag;
 }
 
+// (the two frontier entry points below issue 16-byte accesses: misaligned operands are refused here, the layer driver
+// then takes the regular fused path)
+static bool fr_aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr,
+                         const void* e = nullptr) {
+  return ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e) & 15) == 0);
+}
+
 extern "C" int gnnrag_relation_tables_frontier(const gnnrag_csr* csr, const void* fws, const float* T_fwd,
                                                const float* T_inv, const float* ins, const float* W, float* P,
                                                int32_t D, int32_t I, gnnrag_stream_t stream) {
   if (!csr || !fws || !T_fwd || !T_inv || !ins || !W || !P || I <= 0) return GNNRAG_E_BADARG;
-  if (!gnnrag_frontier_supported(csr, D)) return GNNRAG_E_UNSUPPORTED;
+  if (!gnnrag_frontier_supported(csr, D) || !fr_aligned16(T_fwd, T_inv, ins, W, P)) return GNNRAG_E_UNSUPPORTED;
   if (csr->rel_total == 0) return 0;
   const FrontierWs w = frontier_ws(csr);
   const char* base = (const char*)fws;
@@ -471,7 +478,7 @@ extern "C" int gnnrag_relation_tables_frontier(const gnnrag_csr* csr, const void
 extern "C" int gnnrag_aggregate_fused_frontier(const gnnrag_csr* csr, const void* fws, const float* dist,
                                                const float* P, float* out, int32_t D, gnnrag_stream_t stream) {
   if (!csr || !fws || !dist || !P || !out) return GNNRAG_E_BADARG;
-  if (!gnnrag_frontier_supported(csr, D)) return GNNRAG_E_UNSUPPORTED;
+  if (!gnnrag_frontier_supported(csr, D) || !fr_aligned16(P, out) || csr->N <= 0) return GNNRAG_E_UNSUPPORTED;
   const FrontierWs w = frontier_ws(csr);
   const char* base = (const char*)fws;
   WalkFrArgs a;

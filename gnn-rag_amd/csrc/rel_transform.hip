@@ -16,6 +16,7 @@
 // column slots are interleaved (slot fr of tile a = column 4 fr + a), so the epilogue stores 4 consecutive columns
 // per lane - T as float4, the bf16 planes as 8-byte pieces.
 #include "gnnrag_common.h"
+#include "dense_internal.h"
 
 namespace gnnrag {
 
@@ -143,23 +144,36 @@ extern "C" size_t gnnrag_rel_planes_bytes(int64_t R1, int32_t D, int32_t L) {
   return (size_t)L * 2 * 3 * R1 * kPlaneRow * sizeof(unsigned short);
 }
 
+// THE acceptance test of gnnrag_rel_transform (shapes, offsets, alignment of every operand incl. the outputs, LDS) as
+// one function: the layer stack's GNNRAG_PATH_REUSE_PROJ call asks it, with the real pointers, whether the projecting
+// call took this kernel (and so wrote the planes) or fell back to the k-tiled projection.
+bool gnnrag::rel_transform_accepts(const float* relfeat_fwd, const float* relfeat_inv, int64_t R1, int32_t D, int32_t L,
+                                   const gnnrag_layer_params* layers, int32_t pos_rows, const float* T_out,
+                                   const void* planes_out) {
+  if (D <= 0 || (D & 3)) return false;                                  // float4 operand loads
+  if (planes_out && D > kPlaneHalf) return false;
+  if (R1 >= ((int64_t)1 << 31) / D) return false;
+  uintptr_t align = (uintptr_t)relfeat_fwd | (uintptr_t)relfeat_inv | (uintptr_t)T_out | (uintptr_t)planes_out;
+  for (int j = 0; j < L; ++j) {
+    align |= (uintptr_t)layers[j].W_rel | (uintptr_t)layers[j].b_rel;
+    if (pos_rows > 0) align |= (uintptr_t)layers[j].pos_fwd | (uintptr_t)layers[j].pos_inv;
+  }
+  if (align & 15) return false;                                         // float4 accesses
+  return (size_t)64 * ((D + 15) / 16) * 16 * sizeof(float) <= 160 * 1024;   // 64 columns x K padded to k groups in LDS
+}
+
 extern "C" int gnnrag_rel_transform(const float* relfeat_fwd, const float* relfeat_inv, int64_t R1, int32_t D,
                                     int32_t L, const gnnrag_layer_params* layers, int32_t pos_rows, float* T_out,
                                     void* planes_out, gnnrag_stream_t stream) {
   if (!relfeat_fwd || !relfeat_inv || !layers || !T_out || R1 < 0 || D <= 0 || L <= 0 || pos_rows < 0)
     return GNNRAG_E_BADARG;
-  if (D & 3) return GNNRAG_E_UNSUPPORTED;            // float4 operand loads
-  if (planes_out && D > kPlaneHalf) return GNNRAG_E_UNSUPPORTED;
-  if (R1 >= ((int64_t)1 << 31) / D) return GNNRAG_E_UNSUPPORTED;
-  if (R1 == 0) return 0;
-  uintptr_t align = (uintptr_t)relfeat_fwd | (uintptr_t)relfeat_inv | (uintptr_t)T_out | (uintptr_t)planes_out;
   for (int j = 0; j < L; ++j) {
     if (!layers[j].W_rel) return GNNRAG_E_BADARG;
     if ((layers[j].pos_fwd == nullptr) != (layers[j].pos_inv == nullptr)) return GNNRAG_E_BADARG;
-    align |= (uintptr_t)layers[j].W_rel | (uintptr_t)layers[j].b_rel;
-    if (pos_rows > 0) align |= (uintptr_t)layers[j].pos_fwd | (uintptr_t)layers[j].pos_inv;
   }
-  if (align & 15) return GNNRAG_E_UNSUPPORTED;       // float4 accesses
+  if (!gnnrag::rel_transform_accepts(relfeat_fwd, relfeat_inv, R1, D, L, layers, pos_rows, T_out, planes_out))
+    return GNNRAG_E_UNSUPPORTED;
+  if (R1 == 0) return 0;
   for (int j0 = 0; j0 < L; j0 += kRtMaxL) {
     const int n = L - j0 < kRtMaxL ? L - j0 : kRtMaxL;
     RelTArgs g;
@@ -180,7 +194,6 @@ extern "C" int gnnrag_rel_transform(const float* relfeat_fwd, const float* relfe
     // with planes the column groups run on to 224 columns: the part past D only writes the zero padding
     const unsigned gy = (unsigned)(((planes_out ? kPlaneHalf : D) + 63) / 64), gz = (unsigned)(2 * n);
     const size_t lds = (size_t)64 * ((D + 15) / 16) * 16 * sizeof(float);      // 64 columns x K padded to k groups
-    if (lds > 160 * 1024) return GNNRAG_E_UNSUPPORTED;
     static DeviceMask cap1, cap4;
     if (R1 > 2048) {
       if (lds > 64 * 1024) { const int rc = raise_lds_cap(k_rel_transform<4>, cap4); if (rc) return rc; }

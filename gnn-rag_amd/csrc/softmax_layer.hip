@@ -75,11 +75,25 @@ __global__ __launch_bounds__(1024) void k_masked_softmax(const float* __restrict
   }
 }
 
+// float4 copy that measures the streaming ceiling of the box (bench.py's `measured_copy_ceiling_GBps`): four 16-byte loads
+// per thread in flight before the first store, every block iteration moves 16 KB of contiguous data (round 3's one
+// load -> one store loop reached 4.95 TB/s where the guide's float4 copy reaches 6.29)
 __global__ __launch_bounds__(256) void k_stream_copy(const f32x4* __restrict__ src, f32x4* __restrict__ dst,
                                                      int64_t n4) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (; i < n4; i += stride) dst[i] = src[i];
+  const int64_t stride = (int64_t)gridDim.x * 1024;
+  for (int64_t base = (int64_t)blockIdx.x * 1024; base < n4; base += stride) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = base + u * 256 + threadIdx.x;
+      if (i < n4) v[u] = __builtin_nontemporal_load(src + i);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = base + u * 256 + threadIdx.x;
+      if (i < n4) __builtin_nontemporal_store(v[u], dst + i);
+    }
+  }
 }
 
 struct LayerWs { size_t T_fwd, T_inv, planes, agg, P, nbr, partial, partial_bytes, fws, fws_bytes, total; };
@@ -141,7 +155,7 @@ extern "C" int gnnrag_masked_softmax(const float* score, float* dist, int32_t B,
 extern "C" int gnnrag_stream_copy(const float* src, float* dst, int64_t n, gnnrag_stream_t stream) {
   if (!src || !dst || n < 0 || (n & 3)) return GNNRAG_E_BADARG;
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_stream_copy, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src,
+  hipLaunchKernelGGL(k_stream_copy, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src,
                      (f32x4*)dst, n / 4);
   GNNRAG_LAUNCH_CHECK();
   return 0;
@@ -172,7 +186,11 @@ static int layer_body(const gnnrag_csr* csr, const LayerWs& w, char* base, const
     float* P = (float*)(base + w.P);
     float* nbr = (float*)(base + w.nbr);
     const bool one_dir = only >= 0 && gnnrag_aggregate_fused_variant(csr, D) != GNNRAG_WALK_L2_GATHER;
-    if (seed_prior && only < 0 && gnnrag_frontier_supported(csr, D) && csr->rel_total > 0) {
+    // the frontier kernels issue 16-byte loads / stores on ins, W, T, P (workspace) and the node rows: a misaligned view
+    // takes the regular fused path below, whose launchers check alignment themselves
+    const bool fr_aligned = ((((uintptr_t)ins | (uintptr_t)W_e2e | (uintptr_t)T_fwd | (uintptr_t)T_inv | (uintptr_t)P |
+                               (uintptr_t)nbr | (uintptr_t)dist) & 15) == 0) && csr->N > 0;
+    if (seed_prior && only < 0 && fr_aligned && gnnrag_frontier_supported(csr, D) && csr->rel_total > 0) {
       // The caller says `dist` is a seed distribution (first layer of a ReaRev iteration, rearev.py:208): only the
       // seeds' facts have a prior, so only the relation-table rows those facts use and the neighbour sums of the nodes
       // they reach are computed (frontier.hip; the frontier itself is derived from `dist` on the device, so a prior
@@ -238,17 +256,6 @@ static int rel_projections(const gnnrag_csr* csr, int32_t n, const gnnrag_layer_
     if (rc) return rc;
   }
   return 0;
-}
-
-// whether gnnrag_rel_transform accepted these operands (16-byte alignment): then - and only then - it wrote the planes
-static bool aligned_for_rel_transform(const float* a, const float* b, const gnnrag_layer_params* layers, int L,
-                                      int pos_rows) {
-  uintptr_t x = (uintptr_t)a | (uintptr_t)b;
-  for (int j = 0; j < L; ++j) {
-    x |= (uintptr_t)layers[j].W_rel | (uintptr_t)layers[j].b_rel;
-    if (pos_rows > 0) x |= (uintptr_t)layers[j].pos_fwd | (uintptr_t)layers[j].pos_inv;
-  }
-  return (x & 15) == 0;
 }
 
 extern "C" size_t gnnrag_stack_workspace_bytes(const gnnrag_csr* csr, int32_t L, int32_t D, int32_t I) {
@@ -324,7 +331,9 @@ extern "C" int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnra
   path &= ~GNNRAG_PATH_REUSE_PROJ;
   if (reuse) {
     // the previous call on this workspace left T (and the planes, where this shape writes them) in place
-    planes_written = want_planes && (D & 3) == 0 && aligned_for_rel_transform(relfeat_fwd, relfeat_inv, layers, L, pos_rows);
+    // - exactly when the projecting call's kernel accepted the SAME operands (incl. the outputs inside this workspace)
+    planes_written = want_planes && rel_transform_accepts(relfeat_fwd, relfeat_inv, csr->R1, D, L, layers, pos_rows, Tall,
+                                                          planes_all);
   } else if (upfront) {
     const int rc = rel_projections(csr, L, layers, relfeat_fwd, relfeat_inv, pos_rows, Tall,
                                    want_planes ? planes_all : nullptr, &planes_written, D, math, stream);

@@ -791,6 +791,234 @@ __global__ __launch_bounds__(512, 2) void k_update_b3(UpdB3Args a, int nchunks) 
   else if (NT - a.ct0 == 6) update_b3_part<6, FL>(a, lds, a.ct0 * 16, false, chunk, nchunks);
 }
 
+// ---- the same update with MORE WAVES per CU (round 4) ---------------------------------------------------------------
+// PMC of k_update_b3 at C2 (profiles/r04a_pmc_dense_layer_C2.txt): the matrix pipe is busy 47 % of the waves' lifetime;
+// a wave issues in 27 % of its cycles, is parked at s_waitcnt in 25 % and stalled at issue in 49 % - two 256-register
+// waves per SIMD are not enough to fill the pipe while one of them splits A, waits for LDS fragments or runs its
+// epilogue (tools/probe/mfma_probe: one wave alone sustains 1.0 PFLOP/s on a "2.5 VALU + 0.5 ds_read per MFMA" mix, two
+// 1.6).  k_update_b3w keeps the LDS weight planes, the six plane products and the register epilogue, but a workgroup is
+// 12 or 16 waves (3 / 4 per SIMD, 168 / 128 registers): the A pieces are requested through a 4-slot ring 3-4 k blocks
+// ahead (32 registers instead of a whole tile's 56) with a static refill schedule that runs on into the next tile.
+#ifndef GNNRAG_UPD_WAVES
+#define GNNRAG_UPD_WAVES 8      // 8: k_update_b3 (default until measured); 12 / 16: k_update_b3w
+#endif
+
+template <int CTN, bool FL, int NW>
+__device__ __forceinline__ void update_b3w_part(const UpdB3Args& a, unsigned char* lds, int col0, bool first_part,
+                                                int chunk, int nchunks) {
+  constexpr int RB = kTabSlots * 16;
+  constexpr int PL = kTabNTH * 16 * RB;
+  constexpr int NKB = kTabNKB;
+  constexpr int NTH = 64 * NW;
+  static_assert(NKB == 7, "the ring's refill schedule is written for 7 k blocks");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int D = a.D;
+  const int ncol = min(CTN * 16, D - col0);
+  const int KC = D >> 2;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  float* Bl = reinterpret_cast<float*>(lds + 3 * PL + 64);      // bias / score weights of this part's columns
+  float* Sl = Bl + kTabNTH * 16;
+
+  if (tid < 16) reinterpret_cast<unsigned*>(lds + 3 * PL)[tid] = 0u;
+  for (int j = tid; j < kTabNTH * 16; j += NTH) {
+    Bl[j] = (j < ncol && a.bias) ? a.bias[col0 + j] : 0.f;
+    Sl[j] = j < ncol ? a.w_s[col0 + j] : 0.f;
+  }
+  {   // weight planes of this column part (self block: columns 0..D-1 of e2e_linear.weight)
+    const int total = tab_stage_rows(CTN) * kTabSlots * 2;
+    constexpr int UN = NW >= 12 ? 3 : 6;
+    for (int base = 0; base < total; base += NTH * UN) {
+      f32x4 v[UN];
+      int off[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int idx = base + u * NTH + tid;
+        const int j = idx / (kTabSlots * 2), kc = idx - j * (kTabSlots * 2);
+        v[u] = zero4;
+        off[u] = idx < total ? tab_lds_row(j) * RB + kc * 8 : -1;
+        if (idx < total && j < ncol && kc < KC)
+          v[u] = *reinterpret_cast<const f32x4*>(a.W + (size_t)(col0 + j) * a.ldw + 4 * kc);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (off[u] >= 0) {
+          const Split3 sp = split3(v[u]);
+          unsigned char* dst = lds + off[u];
+          *reinterpret_cast<uint2*>(dst) = sp.hi;
+          *reinterpret_cast<uint2*>(dst + PL) = sp.mid;
+          *reinterpret_cast<uint2*>(dst + 2 * PL) = sp.lo;
+        }
+      }
+    }
+  }
+  // this wave's 16-row tiles
+  const long long U = ((long long)a.M + 15) >> 4;
+  const int c0 = (int)(U * chunk / nchunks), c1 = (int)(U * (chunk + 1) / nchunks);
+  const int nch = c1 - c0;
+  int t = c0 + (int)((long long)nch * wave / NW);
+  const int tend = c0 + (int)((long long)nch * (wave + 1) / NW);
+  const int kmax = D - 8;
+  // 32-bit BYTE offsets from the kernel's uniform base pointers (the launcher admits (M + 1) * D * 4 < 2^32 for this
+  // kernel): scalar base + vector offset addressing, no 64-bit address registers per stream
+  const unsigned char* Ab = reinterpret_cast<const unsigned char*>(a.A);
+  const unsigned char* addb = reinterpret_cast<const unsigned char*>(a.add);
+  unsigned char* Cb = reinterpret_cast<unsigned char*>(a.C);
+  const unsigned rowB = (unsigned)D * 4u;
+  auto a_piece = [&](int tile, int kb, int half) -> f32x4 {
+    const unsigned row = (unsigned)min(tile * 16 + fr, a.M - 1);
+    const unsigned k = (unsigned)(min(32 * kb + 8 * fg, kmax) + 4 * half);
+    return *reinterpret_cast<const f32x4*>(Ab + (size_t)(row * rowB + k * 4u));
+  };
+  // ring of 4 slots: k block kb of a tile lives in slot kb % 4; after slot s has been consumed at step kb it is refilled
+  // with (same tile, kb + 4) for kb = 0..2, with the NEXT tile's k block 3 at kb = 3 and its k blocks 0..2 at kb = 4..6
+  f32x4 ra[4][2];
+  if (t < tend) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      ra[kb][0] = a_piece(t, kb, 0);
+      ra[kb][1] = a_piece(t, kb, 1);
+    }
+  }
+  const float bs = a.b_s[0];
+  unsigned fl_next = 0x01010101u;
+  if (FL && t < tend) fl_next = *reinterpret_cast<const unsigned*>(a.add_flag + (size_t)t * 16 + 4 * fg);
+  __syncthreads();
+
+  for (; t < tend; ++t) {
+    const int rbase = t * 16 + 4 * fg;                       // C layout: rows rbase + q, column slot fr
+    const unsigned fl = fl_next;
+    if (FL) fl_next = *reinterpret_cast<const unsigned*>(a.add_flag + (size_t)(t + 1 < tend ? t + 1 : t) * 16 + 4 * fg);
+    f32x4 acc[CTN];
+#pragma unroll
+    for (int nt = 0; nt < CTN; ++nt) acc[nt] = zero4;
+    const int tload = t + 1 < tend ? t + 1 : t;
+    const int fg_t = opaque_i(fg);                           // keeps the (loop invariant) plane reads inside the tile loop
+    constexpr int PA[6] = {1, 2, 0, 1, 0, 0};
+    constexpr int PB[6] = {1, 0, 2, 0, 1, 0};
+    // the epilogue's operands (nbr rows, mask) are requested half way through the k blocks
+    f32x4 addg[4];
+    float addt[CTN > 4 ? CTN - 4 : 1][4];
+    float mrow = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const bool kok = 32 * kb + 8 * fg_t <= kmax;
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      bf16x8 ap[3];
+      const Split3 s0 = split3(kb < NKB - 1 || kok ? ra[kb & 3][0] : zero4);
+      const Split3 s1 = split3(kb < NKB - 1 || kok ? ra[kb & 3][1] : zero4);
+      ap[0] = __builtin_bit_cast(bf16x8, (u32x4){s0.hi.x, s0.hi.y, s1.hi.x, s1.hi.y});
+      ap[1] = __builtin_bit_cast(bf16x8, (u32x4){s0.mid.x, s0.mid.y, s1.mid.x, s1.mid.y});
+      ap[2] = __builtin_bit_cast(bf16x8, (u32x4){s0.lo.x, s0.lo.y, s1.lo.x, s1.lo.y});
+      {   // refill the slot just consumed (static schedule, see above)
+        const int rt = kb < 3 ? t : tload;
+        const int rk = kb < 3 ? kb + 4 : (kb == 3 ? 3 : kb - 4);
+        ra[kb & 3][0] = a_piece(rt, rk, 0);
+        ra[kb & 3][1] = a_piece(rt, rk, 1);
+      }
+      if (kb == (NW >= 16 ? 5 : 3)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int row = min(rbase + q, a.M - 1);
+          if (FL && ((fl >> (8 * q)) & 0xffu) == 0u) row = a.M;      // not a frontier row: the zero row behind the buffer
+          const unsigned ao = (unsigned)row * rowB + (unsigned)col0 * 4u;
+          addg[q] = *reinterpret_cast<const f32x4*>(addb + (size_t)(ao + 4u * (unsigned)min(4 * fr, ncol - 4)));
+#pragma unroll
+          for (int nt = 4; nt < CTN; ++nt)
+            addt[nt - 4][q] = *reinterpret_cast<const float*>(addb + (size_t)(ao + 4u * (unsigned)min(nt * 16 + fr, ncol - 1)));
+        }
+        const int srow = min(rbase + (2 * (fr & 1) + ((fr >> 1) & 1)), a.M - 1);
+        mrow = a.mask[srow];
+      }
+      const unsigned char* wb = lds + fr * RB + kb * 64 + fg_t * 16;
+      if constexpr (NW >= 16) {
+        // 128 registers: one column tile's fragments at a time (a chain of six dependent MFMAs issues at the pipe's
+        // rate - tools/probe/mfma_probe "1acc"), the next tile's fragments requested before the chain
+        bf16x8 bn[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bn[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL));
+#pragma unroll
+        for (int nt = 0; nt < CTN; ++nt) {
+          bf16x8 b0[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) b0[pl] = bn[pl];
+          if (nt + 1 < CTN) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+              bn[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + (nt + 1) * 16 * RB));
+          }
+#pragma unroll
+          for (int p = 0; p < 6; ++p) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[PA[p]], b0[PB[p]], acc[nt], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < CTN; nt += 2) {
+          bf16x8 b0[3], b1[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            b0[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + nt * 16 * RB));
+            b1[pl] = b0[pl];
+            if (nt + 1 < CTN)
+              b1[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + (nt + 1) * 16 * RB));
+          }
+#pragma unroll
+          for (int p = 0; p < 6; ++p) {
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[PA[p]], b0[PB[p]], acc[nt], 0, 0, 0);
+            if (nt + 1 < CTN)
+              acc[nt + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[PA[p]], b1[PB[p]], acc[nt + 1], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // epilogue from the registers (as k_update_b3)
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 bias_g = *reinterpret_cast<const f32x4*>(Bl + min(4 * fr, kTabNTH * 16 - 4));
+    const f32x4 ws_g = *reinterpret_cast<const f32x4*>(Sl + min(4 * fr, kTabNTH * 16 - 4));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = rbase + q;
+      f32x4 v = {acc[0][q], acc[1][q], acc[2][q], acc[3][q]};
+      v = __builtin_elementwise_max((v + bias_g) + addg[q], zero4);
+      const int c = 4 * fr;
+      if (c + 4 > ncol) {
+        v = zero4;
+      } else if (row < a.M) {
+        *reinterpret_cast<f32x4*>(Cb + (size_t)((unsigned)row * rowB + 4u * (unsigned)(col0 + c))) = v;
+      }
+      part[q] += v[0] * ws_g[0] + v[1] * ws_g[1] + v[2] * ws_g[2] + v[3] * ws_g[3];
+#pragma unroll
+      for (int nt = 4; nt < CTN; ++nt) {
+        const int cc = nt * 16 + fr;
+        float x = fmaxf((acc[nt][q] + Bl[cc]) + addt[nt - 4][q], 0.f);
+        if (cc >= ncol) x = 0.f;
+        else if (row < a.M) *reinterpret_cast<float*>(Cb + (size_t)((unsigned)row * rowB + 4u * (unsigned)(col0 + cc))) = x;
+        part[q] += x * Sl[cc];
+      }
+    }
+    {
+      const float tot = row16_sum4_b3(part, lane);
+      const int srow = rbase + (2 * (fr & 1) + ((fr >> 1) & 1));
+      if (fr < 4 && srow < a.M) {
+        const float share = first_part ? (tot + bs) + (1.0f - mrow) * kVeryNeg : tot;
+        atomicAdd(a.score + srow, share);
+      }
+    }
+  }
+}
+
+template <bool FL, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void k_update_b3w(UpdB3Args a, int nchunks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int blk = blockIdx.x;
+  const int h = (blk >> 3) & 1;
+  const int chunk = (blk >> 4) * 8 + (blk & 7);
+  if (chunk >= nchunks) return;
+  const int NT = (a.D + 15) >> 4;
+  if (h == 0) update_b3w_part<kTabNTH, FL, NW>(a, lds, 0, true, chunk, nchunks);
+  else if (NT - a.ct0 == 6) update_b3w_part<6, FL, NW>(a, lds, a.ct0 * 16, false, chunk, nchunks);
+}
+
 int update_b3_launch(const float* h, const float* nbr, const float* W, const float* b, const float* w_s, const float* b_s,
                      const float* mask, float* h_out, float* score, int64_t BN, int32_t D, int32_t ldw,
                      hipStream_t stream) {
@@ -812,6 +1040,10 @@ int update_b3_launch_f(const float* h, const float* nbr, const uint8_t* add_flag
                        int32_t D, int32_t ldw, hipStream_t stream, bool score_zeroed) {
   if (!update_b3_shape_ok(BN, D, ldw)) return GNNRAG_E_UNSUPPORTED;
   if ((((uintptr_t)h | (uintptr_t)nbr | (uintptr_t)W | (uintptr_t)h_out) & 15) != 0) return GNNRAG_E_UNSUPPORTED;
+  {   // hidden size 200: the register-resident form (update_wr.hip); it needs no zeroed score
+    const int rc = update_wr_launch_f(h, nbr, add_flag, W, b, w_s, b_s, mask, h_out, score, BN, D, ldw, stream);
+    if (rc != GNNRAG_E_UNSUPPORTED) return rc;
+  }
   UpdB3Args a;
   memset(&a, 0, sizeof(a));
   a.A = h; a.W = W; a.bias = b; a.add = nbr; a.w_s = w_s; a.b_s = b_s; a.mask = mask; a.C = h_out; a.score = score;
@@ -834,8 +1066,19 @@ int update_b3_launch_f(const float* h, const float* nbr, const uint8_t* add_flag
     if (rc) return rc;
   }
   const int nblk = ((chunks + 7) / 8) * 16;
+#if GNNRAG_UPD_WAVES > 8
+  {
+    static DeviceMask capw, capw_f;
+    const int rc = add_flag ? raise_lds_cap(k_update_b3w<true, GNNRAG_UPD_WAVES>, capw_f)
+                            : raise_lds_cap(k_update_b3w<false, GNNRAG_UPD_WAVES>, capw);
+    if (rc) return rc;
+  }
+  if (add_flag) hipLaunchKernelGGL((k_update_b3w<true, GNNRAG_UPD_WAVES>), dim3(nblk), dim3(64 * GNNRAG_UPD_WAVES), 160 * 1024, stream, a, chunks);
+  else hipLaunchKernelGGL((k_update_b3w<false, GNNRAG_UPD_WAVES>), dim3(nblk), dim3(64 * GNNRAG_UPD_WAVES), 160 * 1024, stream, a, chunks);
+#else
   if (add_flag) hipLaunchKernelGGL(k_update_b3<true>, dim3(nblk), dim3(512), 160 * 1024, stream, a, chunks);
   else hipLaunchKernelGGL(k_update_b3<false>, dim3(nblk), dim3(512), 160 * 1024, stream, a, chunks);
+#endif
   GNNRAG_LAUNCH_CHECK();
   return 0;
 }

@@ -54,6 +54,12 @@ class ReasonGNNLayer(BaseGNNLayer):
         self.use_stack = os.environ.get("GNNRAG_STACK", "1") != "0"
         self._stack = None
         self._ahead = None
+        # hipGraph replay of the whole-iteration call for SMALL batches (B * N < 4096 node slots, e.g. one WebQSP question:
+        # ~50 launches of 3-14 us per iteration are bound by the host's launch rate): iteration 1 of a forward runs eager
+        # (it also computes the relation projections), iteration 2 captures the sequence over fixed buffers, iterations
+        # 2..T replay it.  GNNRAG_GRAPH=1 switches it on, 0 off (default: off - a capture per batch costs about what it
+        # saves at num_iter = 3; bit-identical to eager either way).
+        self.graph_small = os.environ.get("GNNRAG_GRAPH", "0") == "1"
         # Hidden sizes that are not a multiple of 4 (the released checkpoints use entity_dim 50) would send every
         # kernel down its scalar path and the walk to the table-row gather.  The inference path therefore works on
         # ZERO-PADDED copies (D -> next multiple of 8): padded parameter rows / columns are zero, so the extra
@@ -202,8 +208,20 @@ class ReasonGNNLayer(BaseGNNLayer):
                 self._stack = ops.LayerStack(self.plan, P["relfeat"], P["relfeat_inv"], P["layers"], P["w_score"],
                                              P["b_score"], self.local_entity_mask, self.num_ins, path=self._path_of(0))
                 self._stack_key = P["key"]
-            h, score, dist = self._stack.run(self._state_in(P), current_dist.detach().float(),
-                                             self._pad_last(relational_ins.detach().float(), P))
+            st = self._stack
+            dist_in = current_dist.detach().float()
+            ins_in = self._pad_last(relational_ins.detach().float(), P)
+            if (self.graph_small and st._proj_valid and self.batch_size * self.max_local_entity < 4096 and st.L >= 2
+                    and dist_in.is_contiguous()):
+                if getattr(st, "_graph_rest", None) is None or st._graph_in[0].data_ptr() != dist_in.data_ptr():
+                    st.capture_rest(self._state_in(P), dist_in, ins_in)           # iteration 2: capture ...
+                h, score, dist = st.replay_rest(self._state_in(P), dist_in, ins_in)   # ... and replay (iterations 2..T)
+                # the captured sequence writes fixed buffers: the distributions handed to the caller are copies (the
+                # reference keeps every iteration's distribution, rearev.py:211); the node state is read in place by
+                # the next replay
+                score, dist = score.clone(), dist.clone()
+            else:
+                h, score, dist = st.run(self._state_in(P), dist_in, ins_in)
             self._ahead = dict(ins=relational_ins, h=h, score=score, dist=dist, given=[dist[j] for j in range(self.num_gnn)],
                                emb=[self._state_out(h[j], P) for j in range(self.num_gnn)])
             return self._ahead["emb"][0], score[0], self._ahead["given"][0]

@@ -881,6 +881,47 @@ class LayerStack:
             torch.cuda.current_stream().wait_stream(side)
         self._graph, self._graph_rest, self._graph_in = g, g2, (dist0, ins)
 
+    def capture_rest(self, h_prev, dist0, ins):
+        """Module path (``ReasonGNNLayer._forward_stack``, iterations 2..T of a forward): captures ONLY the sequence without
+        the relation projections (the eager run of iteration 1 left them in the workspace) over fixed buffers - the node
+        state in ``self.h[L-1]`` (``h_prev`` is copied there), the prior ``dist0`` (the reference hands the same seed
+        tensor to every iteration, rearev.py:208) and an instruction buffer of this stack, refreshed by ``replay_rest``."""
+        if self.L < 2:
+            raise ValueError("graph replay needs num_gnn >= 2 (layer 0 reads the buffer the last layer writes)")
+        if not self._proj_valid:
+            raise RuntimeError("capture_rest() needs the projections of an eager run() in the workspace")
+        self.release_graph()
+        self.h, self.score, self.dist = self._new_outputs()
+        self._ins_buf = torch.empty((self.B, self.I, self.D), dtype=torch.float32, device=self.device)
+        self.h[self.L - 1].copy_(h_prev.reshape(self.B, self.N, self.D))
+        self._ins_buf.copy_(ins)
+        h0g, dist0, insb = self._inputs(self.h[self.L - 1], dist0, self._ins_buf)
+        g2 = C.c_void_p()
+        with torch.cuda.device(h0g.device):
+            side = torch.cuda.Stream()                            # no capture on the legacy default stream
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                _lib.check(_lib.load().gnnrag_reason_stack_capture(
+                    *self._args(h0g, dist0, insb, (self.h, self.score, self.dist), reuse=True), _stream(), C.byref(g2)),
+                    "gnnrag_reason_stack_capture")
+            torch.cuda.current_stream().wait_stream(side)
+        self._graph_rest, self._graph_in = g2, (dist0, insb)
+
+    def replay_rest(self, h_prev, dist0, ins):
+        """One replay of the graph of ``capture_rest``: ``h_prev`` must be the previous replay's / capture's last-layer
+        state (``self.h[L-1]``; anything else is copied in), ``dist0`` the captured prior tensor, ``ins`` is copied into the
+        captured instruction buffer.  Returns the fixed buffers (overwritten by the next replay)."""
+        if getattr(self, "_graph_rest", None) is None:
+            raise RuntimeError("capture_rest() first")
+        if dist0.data_ptr() != self._graph_in[0].data_ptr():
+            raise RuntimeError("replay_rest: the prior is not the captured tensor")
+        if h_prev.data_ptr() != self.h[self.L - 1].data_ptr():
+            self.h[self.L - 1].copy_(h_prev.reshape(self.B, self.N, self.D))
+        self._ins_buf.copy_(ins)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().gnnrag_graph_launch(self._graph_rest, _stream()), "gnnrag_graph_launch")
+        return self.h, self.score, self.dist
+
     def replay(self, first: bool = True):
         """Replays the captured sequence.  ``first=False``: the graph without the relation-projection launch (the later
         iterations of a forward; the first one's replay left the projections in the workspace)."""

@@ -41,7 +41,8 @@ COMMON_ARGV = ["ReaRev", "--data_folder", DATA, "--lm", "lstm", "--relation_word
                "--num_iter", "3", "--num_ins", "2", "--num_gnn", "3", "--batch_size", "16", "--test_batch_size", "16"]
 VARIANTS = {
     "d50": {"argv": ["--entity_dim", "50", "--kg_dim", "25", "--name", "synth"], "train": "synth", "epochs": 8},
-    "d200": {"argv": ["--entity_dim", "200", "--kg_dim", "100", "--name", "synth"], "train": "synth200", "epochs": 6},
+    "d200": {"argv": ["--entity_dim", "200", "--kg_dim", "100", "--name", "synth"], "train": "synth200", "epochs": 8,
+             "lr": "0.001"},                      # (lr 0.005 diverges at this width: loss 16 from the first epoch)
     "cwq": {"argv": ["--entity_dim", "50", "--kg_dim", "25", "--name", "cwq"], "train": "synth", "epochs": 0},
 }
 DATASET_VERSION = "r4-learnable-2"
@@ -205,7 +206,8 @@ def make_checkpoint(variant="d50"):
     parser = argparse.ArgumentParser()
     parsing.add_parse_args(parser)
     exp = VARIANTS[variant]["train"]
-    args = parser.parse_args(variant_argv(variant) + ["--checkpoint_dir", CKPT, "--experiment_name", exp, "--lr", "0.005"])
+    args = parser.parse_args(variant_argv(variant) + ["--checkpoint_dir", CKPT, "--experiment_name", exp, "--lr",
+                                                      VARIANTS[variant].get("lr", "0.005")])
     args.use_cuda = False
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)
@@ -306,5 +308,16 @@ def main(force=False):
     print("oracle/_ref staged: " + json.dumps({v: m["test"] for v, m in summary.items()}))
 
 
+def restage_variant(v):
+    """Retrains / re-evaluates ONE variant on the dataset already staged (python oracle/stage_ref.py --variant d200)."""
+    if VARIANTS[v]["epochs"]:
+        _train_in_subprocess(v)
+    m = expect(v)
+    print("stage_ref[%s]: CPU reference metrics %s" % (v, m), flush=True)
+
+
 if __name__ == "__main__":
-    main(force="--force" in sys.argv)
+    if "--variant" in sys.argv:
+        restage_variant(sys.argv[sys.argv.index("--variant") + 1])
+    else:
+        main(force="--force" in sys.argv)

@@ -39,6 +39,7 @@ GNN, CKPT = stage_ref.GNN, stage_ref.CKPT
 STAGED = stage_ref.staged()
 
 TOL = 1e-4
+TIE = 1e-6          # candidates this close in the reference's own output may come out in either order
 
 
 def _run_main_py(tmp_path, variant, extra_env, tag):
@@ -90,14 +91,34 @@ def test_unmodified_main_py_eval_matches_cpu_reference(tmp_path, variant, mode):
     for split in ("eval", "test"):                                        # logged with 4 decimals by the reference
         assert metrics[split] == want_metrics[split], (split, metrics, want_metrics)
     assert len(got) == len(want) and len(got) > 0
-    worst = 0.0
+    worst, reordered, cut_ties = 0.0, 0, 0
     for g, w in zip(got, want):
         assert g["question"] == w["question"] and g["answers"] == w["answers"]
         for key in ("precison", "recall", "f1", "hit", "em"):
             assert g[key] == w[key], (key, g["question"])
-        assert [c[0] for c in g["cand"]] == [c[0] for c in w["cand"]], g["question"]     # same entities, same order
-        for (_, pg), (_, pw) in zip(g["cand"], w["cand"]):
-            worst = max(worst, abs(pg - pw))
+        # the same retrieved entities, in the same order - except that two candidates whose reference probabilities
+        # differ by less than TIE (1e-6: two orders of magnitude below north_star's 1e-4 bar) may be swapped: a
+        # question the model is unsure about retrieves up to 1800 candidates of nearly equal probability, and fp32
+        # sums in a different order decide such ties differently
+        ge, we = [c[0] for c in g["cand"]], [c[0] for c in w["cand"]]
+        pw_of, pg_of = dict(map(tuple, w["cand"])), dict(map(tuple, g["cand"]))
+        assert len(ge) == len(we), g["question"]
+        if set(ge) != set(we):
+            # the top-p cut fell inside a group of (near-)equal probabilities (structurally equivalent nodes): which
+            # members of the group are retrieved depends on the order among ties - every entity only one side retrieved
+            # must sit within TIE of the cut, i.e. of the smallest retrieved probability
+            cut = min(pw_of.values())
+            for e in set(ge) ^ set(we):
+                assert abs((pg_of[e] if e in pg_of else pw_of[e]) - cut) <= TIE, (g["question"], e)
+            cut_ties += 1
+        if ge != we:
+            reordered += 1
+            prob = lambda e: pw_of[e] if e in pw_of else pg_of[e]
+            for a, b in zip(ge, we):
+                assert a == b or abs(prob(a) - prob(b)) <= TIE, (g["question"], a, b, prob(a), prob(b))
+        worst = max([worst] + [abs(pg_of[e] - pw_of[e]) for e in we if e in pg_of])
     assert worst <= TOL, worst
-    print("main.py on the MI355X (%s, %s): %d questions, H@1 %.4f (dev %.4f), max |candidate probability - CPU reference| = %.3g"
-          % (variant, mode, len(got), metrics["test"][1], metrics["eval"][1], worst))
+    assert reordered <= len(got) // 10 and cut_ties <= 3, (reordered, cut_ties)       # ties are the exception
+    print("main.py on the MI355X (%s, %s): %d questions, H@1 %.4f (dev %.4f), max |candidate probability - CPU reference| = %.3g, "
+          "%d questions with a swap among near-equal candidates (|dp| <= %.0e), %d with the top-p cut inside such a group"
+          % (variant, mode, len(got), metrics["test"][1], metrics["eval"][1], worst, reordered, TIE, cut_ties))

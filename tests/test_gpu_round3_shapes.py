@@ -133,3 +133,44 @@ def test_c1_kernel_variants_padded_and_unpadded(dev, monkeypatch):
             got = stack.run_stack(batch, feats, params, dev, use_type_layer=True, path=path)
             _check_stack(got, want64, cfg.T * cfg.L, tol=TOL_INTERNAL, what="C1 np64 pad=%s path %d" % (pad, path))
             _check_stack(got, want, cfg.T * cfg.L, what="C1 torch pad=%s path %d" % (pad, path))
+
+
+def test_module_path_graph_replay_is_bit_identical_to_eager(dev):
+    """``ReasonGNNLayer._forward_stack`` with GNNRAG_GRAPH=1 (B * N < 4096: iteration 1 eager,
+    iteration 2 captures the projection-free sequence, iterations 2..T replay it) against the eager module path on
+    BASELINE config 1 - every layer's scores, distributions and node states bit for bit, over two consecutive forwards
+    (a new batch binds a new stack: capture per forward, as main.py would run it)."""
+    from gnnrag_amd import stack, synth
+    cfg = synth.CONFIGS["C1"]
+    assert cfg.B * cfg.N < 4096 and cfg.T >= 3
+    batch, feats, params = synth.make_batch(cfg), synth.make_features(cfg), synth.make_layer_params(cfg)
+    dvi = stack.DeviceInputs(batch, feats, dev)
+    recs = {}
+    for mode in ("eager", "graph"):
+        layer = stack.build_layer(cfg, batch, params, dev)
+        layer.graph_small = mode == "graph"
+        for rep in range(2):
+            stack.init_reason(layer, batch, dvi, dvi.h0)
+            _, rec = stack.run_layers(layer, cfg, dvi, record=True)
+            recs[(mode, rep)] = rec
+        if mode == "graph":
+            assert layer._stack._graph_rest is not None              # the replay really ran
+    for rep in range(2):
+        for key in ("score", "dist", "h"):
+            for c in range(cfg.T * cfg.L):
+                assert np.array_equal(recs[("eager", rep)][key][c], recs[("graph", rep)][key][c]), (key, c, rep)
+
+
+def test_register_resident_update_kernel_in_a_fresh_process():
+    """k_update_wr (update_wr.hip: W planes in registers, h split once per workgroup through an LDS ring, scores without
+    atomics) is parity-green but measured slower than k_update_b3, so it is opt-in (GNNRAG_UPDATE_WR=1, read when the
+    library is first used): the full-size C2 gates through it, dense and gated (frontier) form, in a process of its own."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GNNRAG_UPDATE_WR="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu",
+                        "tests/test_gpu_baseline_shapes.py::test_c2_full_batch_against_oracle_slices", "-k", "fused and mixed"],
+                       cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

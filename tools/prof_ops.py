@@ -39,6 +39,7 @@ def main():
         Tf = ops.linear(devin.rel_features, rl.weight, rl.bias)
         Ti = ops.linear(devin.rel_features_inv, rl.weight, rl.bias)
         agg = ops.aggregate(layer.plan, dist1, devin.ins[0], Tf, Ti)
+        nbr0 = agg[:, :D].contiguous()                                          # a dense [BN, D] stand-in for nbr
         torch.cuda.synchronize()
         for _ in range(a.reps):
             if "rel" in which:
@@ -63,6 +64,9 @@ def main():
                 if "updf" in which:
                     ops.update_score_fused(h, nbr, e2e.weight, e2e.bias, layer.score_func.weight,
                                            layer.score_func.bias, layer.local_entity_mask, I)
+            if "updfd" in which:                                                # the self-block update alone (dense nbr)
+                ops.update_score_fused(h, nbr0, e2e.weight, e2e.bias,
+                                       layer.score_func.weight, layer.score_func.bias, layer.local_entity_mask, I)
             if "fr" in which:                                                   # seed-prior (frontier) form, piece by piece
                 fr = ops.Frontier(layer.plan, devin.seed_dist)
                 Pf = fr.relation_tables(Tf, Ti, devin.ins[0], e2e.weight)

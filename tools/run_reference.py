@@ -13,6 +13,10 @@ What is substituted, all without touching a reference file:
 Under ``python -m torch.distributed.run --nproc-per-node G ... tools/run_reference.py ... --is_eval ...`` every
 evaluation batch is question-sharded over the G GPUs (``gnnrag_amd.shard.shard_model``: local forward, one RCCL
 all-gather of the scored nodes); rank 0 writes the ``.info`` file and prints the metrics.
+``GNNRAG_E2E_TIMES=1`` prints one ``GNNRAG_E2E {json}`` line at exit: wall time and questions of every ``Evaluator.evaluate``
+call and the time spent inside ``get_batch``, the structure build and ``Model.forward`` (bench.py's ``e2e`` block);
+``GNNRAG_PURE_REFERENCE=1`` runs the reference WITHOUT any substitution (its own CPU / torch path: the baseline of that
+block; start it with CUDA_VISIBLE_DEVICES="").
 Needs a GPU (the package has no CPU path); the reference's own two start-up bugs (an undefined
 ``create_parser_nutrea`` in ``parsing.py``; ``LSTMInstruction`` not passing ``constraint``)
 are shimmed exactly as the tests do."""
@@ -30,6 +34,9 @@ def main():
     sys.path.insert(0, REPO)
     sys.path.insert(0, ref)
     os.chdir(ref)
+    pure = os.environ.get("GNNRAG_PURE_REFERENCE") == "1"
+    if pure:
+        return run_pure(ref)
     import gnnrag_amd  # noqa: F401
     from gnnrag_amd import install
     install.install()
@@ -58,18 +65,9 @@ def main():
         dist.init_process_group("nccl")
         atexit.register(lambda: dist.is_initialized() and dist.destroy_process_group())
 
-    import parsing
-    if not hasattr(parsing, "create_parser_nutrea"):
-        parsing.create_parser_nutrea = lambda p: None
-
-    # second reference bug: LSTMInstruction calls BaseInstruction.__init__(args) without the
-    # `constraint` argument the base class requires; give it the default the other encoders pass
-    from modules.question_encoding import base_encoder
-    _orig_init = base_encoder.BaseInstruction.__init__
-
-    def _init(self, args, constraint=False):
-        _orig_init(self, args, constraint)
-    base_encoder.BaseInstruction.__init__ = _init
+    # the reference's two start-up bugs: an undefined create_parser_nutrea; LSTMInstruction calls
+    # BaseInstruction.__init__(args) without the `constraint` argument the base class requires
+    shim_startup_bugs()
 
     if not os.environ.get("GNNRAG_NO_LOADER_PATCH"):
         import dataset_load
@@ -110,12 +108,99 @@ def main():
 
         evaluate.Evaluator.__init__ = _init_sharded
 
+    times = install_e2e_timers(pure=False) if os.environ.get("GNNRAG_E2E_TIMES") == "1" else None
     sys.argv = [os.path.join(ref, "main.py")] + sys.argv[2:]
     try:
         runpy.run_path(os.path.join(ref, "main.py"), run_name="__main__")
     finally:
         mapped = [l.split()[-1] for l in open("/proc/self/maps") if "libgnnrag_hip" in l]
         print("gnnrag_amd: native library %s" % ("mapped: " + mapped[0] if mapped else "NOT loaded"))
+        if times is not None:
+            import json
+            print("GNNRAG_E2E " + json.dumps(times))
+
+
+def shim_startup_bugs():
+    import parsing
+    if not hasattr(parsing, "create_parser_nutrea"):
+        parsing.create_parser_nutrea = lambda p: None
+    from modules.question_encoding import base_encoder
+    if not getattr(base_encoder.BaseInstruction.__init__, "_gnnrag_shim", False):
+        orig = base_encoder.BaseInstruction.__init__
+
+        def _init(self, args, constraint=False):
+            orig(self, args, constraint)
+        _init._gnnrag_shim = True
+        base_encoder.BaseInstruction.__init__ = _init
+
+
+def run_pure(ref):
+    """The reference as it is (plus its two start-up shims), timed: bench.py's CPU baseline of the e2e block."""
+    import json
+    shim_startup_bugs()
+    times = install_e2e_timers(pure=True) if os.environ.get("GNNRAG_E2E_TIMES") == "1" else None
+    sys.argv = [os.path.join(ref, "main.py")] + sys.argv[2:]
+    try:
+        runpy.run_path(os.path.join(ref, "main.py"), run_name="__main__")
+    finally:
+        if times is not None:
+            print("GNNRAG_E2E " + json.dumps(times))
+
+
+def install_e2e_timers(pure: bool) -> dict:
+    """Wall-clock timers around the stages of an evaluation run, at the reference's own seams: ``Evaluator.evaluate``
+    (evaluate.py:147), ``get_batch`` (dataset_load.py:599), the structure build (``build_matrix`` of the reference,
+    base_gnn.py:19 / this package's ``plan_for``) and ``Model.forward`` (rearev.py:163).  GPU stages are bracketed by
+    device synchronisation, so the split is honest and the run a little slower than an untimed one."""
+    import time
+    import torch
+    import dataset_load
+    import evaluate
+    T = {"evaluate_calls": [], "get_batch_s": 0.0, "forward_s": 0.0, "structure_s": 0.0, "batches": 0,
+         "threads": torch.get_num_threads(), "pure_reference": pure}
+    sync = (lambda: torch.cuda.synchronize()) if (torch.cuda.is_available() and not pure) else (lambda: None)
+
+    def timed(fn, key, count=None, do_sync=False):
+        def wrapper(*a, **kw):
+            if do_sync:
+                sync()
+            t0 = time.perf_counter()
+            try:
+                return fn(*a, **kw)
+            finally:
+                if do_sync:
+                    sync()
+                T[key] += time.perf_counter() - t0
+                if count:
+                    T[count] += 1
+        return wrapper
+
+    dataset_load.SingleDataLoader.get_batch = timed(dataset_load.SingleDataLoader.get_batch, "get_batch_s")
+    from models.ReaRev import rearev
+    rearev.ReaRev.forward = timed(rearev.ReaRev.forward, "forward_s", "batches", do_sync=True)
+    if pure:
+        from modules.kg_reasoning import base_gnn
+        base_gnn.BaseGNNLayer.build_matrix = timed(base_gnn.BaseGNNLayer.build_matrix, "structure_s")
+    else:
+        from gnnrag_amd.modules.kg_reasoning import base_gnn as g_base
+        import gnnrag_amd.modules.layer_init as g_li
+        g_base.plan_for = g_li.plan_for = timed(g_base.plan_for, "structure_s", do_sync=True)   # TypeLayer builds it first
+    ev = evaluate.Evaluator.evaluate
+
+    def evaluate_timed(self, valid_data, *a, **kw):
+        before = (T["get_batch_s"], T["forward_s"], T["structure_s"], T["batches"])
+        sync()
+        t0 = time.perf_counter()
+        out = ev(self, valid_data, *a, **kw)
+        sync()
+        dt = time.perf_counter() - t0
+        T["evaluate_calls"].append({"questions": int(valid_data.num_data), "seconds": dt,
+                                    "get_batch_s": T["get_batch_s"] - before[0], "forward_s": T["forward_s"] - before[1],
+                                    "structure_s": T["structure_s"] - before[2], "batches": T["batches"] - before[3],
+                                    "max_local_entity": int(valid_data.max_local_entity)})
+        return out
+    evaluate.Evaluator.evaluate = evaluate_timed
+    return T
 
 
 if __name__ == "__main__":

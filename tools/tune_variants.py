@@ -56,6 +56,11 @@ VARIANTS = {
     "light_nomem": {"GNNRAG_LIGHT_ABL": 3}, "hub_ks32": {"GNNRAG_HUB_KS_MAX": 32}, "hub_ks8": {"GNNRAG_HUB_KS_MAX": 8}, "hub_ks4": {"GNNRAG_HUB_KS_MAX": 4}, "hub_wg8192": {"GNNRAG_HUB_W_GRID": 8192}, "hub_wg512": {"GNNRAG_HUB_W_GRID": 512},
     # round 4: the compiler SLP-packs the split's subtractions into v_pk_add_f32, which is expensive beside MFMAs
     "noslp": {"__flags__": ["-fno-slp-vectorize"]},
+    # round 4: the self-block update with 12 / 16 waves per workgroup (k_update_b3w)
+    "updw12": {"GNNRAG_UPD_WAVES": 12}, "updw16": {"GNNRAG_UPD_WAVES": 16},
+    # the register-resident update (update_wr.hip; measured slower, opt-in) on at run time ("__env__": the default build
+    # with these environment variables)
+    "wr_on": {"__env__": {"GNNRAG_UPDATE_WR": "1"}},
     "split_trunc": {"GNNRAG_SPLIT_RN": 0},      # the truncation form of the exact 3-way bf16 split (rounds 1-2)
     "vq_nolds": {"GNNRAG_VQ_ABL": 1}, "vq_noa": {"GNNRAG_VQ_ABL": 2}, "vq_nostage": {"GNNRAG_VQ_ABL": 4},
     "upd_nolds": {"GNNRAG_UPD_ABL": 1}, "upd_noa": {"GNNRAG_UPD_ABL": 2}, "upd_noadd": {"GNNRAG_UPD_ABL": 4},
@@ -115,10 +120,13 @@ def main():
     names = [a for a in sys.argv[1:] if not a.startswith("--")] or list(VARIANTS)
     if "--build" in sys.argv:
         for n in names:
-            print(build.build_variant(n, VARIANTS[n]))
+            if not VARIANTS[n] or set(VARIANTS[n]) - {"__env__"}:
+                print(build.build_variant(n, VARIANTS[n]))
     if "--run" in sys.argv:
         for n in names:
-            env = dict(os.environ, GNNRAG_LIB=os.path.join(build.LIBDIR, "exp_%s.so" % n))
+            only_env = not (set(VARIANTS[n]) - {"__env__"})
+            env = dict(os.environ, GNNRAG_LIB=os.path.join(build.LIBDIR, "exp_%s.so" % ("default" if only_env else n)),
+                       **VARIANTS[n].get("__env__", {}))
             r = subprocess.run([sys.executable, "-c", CHILD % REPO], env=env, capture_output=True, text=True,
                                timeout=600)
             line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
