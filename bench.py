@@ -286,6 +286,12 @@ def main():
     csr_build_ms = (time.perf_counter() - t0) * 1e3 / 3
     csr_cached_ms, csr_concat_ms = (cached_structure_ms(batch, dev, ops)
                                     if rank == 0 and not os.environ.get("BENCH_SKIP_STRUCTURE_TIMING") else (None, None))
+    overlapped = None
+    if rank == 0 and graph is None and not strong and not os.environ.get("BENCH_SKIP_STRUCTURE_TIMING"):
+        try:
+            overlapped = overlapped_build_ms(batch, dev, step, 48)
+        except Exception as e:                       # never fail the bench on the side measurement
+            overlapped = {"error": repr(e)[:300]}
 
     ms_per_step = elapsed * 1e3 / args.steps
     typed_edges = global_B * cfg.E * cfg.L * cfg.T
@@ -315,6 +321,11 @@ def main():
         # host-buffer boundary: int64 tuple -> int32 upload over PCIe + device structure build, once per batch,
         # amortised over ONE step (a ReaRev forward runs num_iter steps on the same structure); never `value`
         "value_incl_upload_and_build": typed_edges / (elapsed / args.steps + csr_build_ms * 1e-3),
+        # the same with the next batch's structure built by a worker thread on a side stream
+        # while this batch's step runs (device fact cache, a fresh structure every step)
+        "structure_build_overlapped": overlapped,
+        "value_incl_overlapped_build": (typed_edges / (overlapped["ms_per_build_plus_step_prefetched"] * 1e-3)
+                                        if overlapped and "ms_per_build_plus_step_prefetched" in overlapped else None),
         "dense_math": math_name,
         "pre_run": ("%.0f ms of HBM copy kernels and dummy matrix products before the warm-up steps (clock ramp of an idle chip; not steps, nothing of "
                     "the workload is computed or cached)" % args.clock_ramp_ms) if args.clock_ramp_ms > 0 else None,
@@ -384,6 +395,51 @@ def cached_structure_ms(batch, dev, ops):
     torch.cuda.synchronize()
     wall_ms = (time.perf_counter() - t0) * 1e3 / 5
     return cached_ms, {"host_enqueue_ms": host_ms, "wall_ms_incl_device": wall_ms}
+
+
+def overlapped_build_ms(batch, dev, step, steps):
+    """First-pass structure build OFF the critical path (``data/fact_mat.StructurePrefetcher``): while the step of batch k
+    runs, a worker thread assembles batch k + 1's tuple from the device-resident fact cache and builds its structure on a
+    side stream; the caller only waits for the build's event.  Every iteration requests a NEW batch from the loader (all
+    cache hits on the questions' id blocks, never on a structure): wall clock per (build + step) pair, and the same loop
+    with the build in line for comparison."""
+    import torch
+    from gnnrag_amd.data import fact_mat
+    from gnnrag_amd.modules.kg_reasoning.base_gnn import plan_for
+    cfg = batch.cfg
+    et = batch.edge_tuple
+    bid = np.asarray(et[3])
+    bounds = np.searchsorted(bid, np.arange(cfg.B + 1))
+    reps = 8                                           # the loader walks `reps` batches of the same questions
+
+    class _Loader:
+        max_local_entity, data_eff, use_self_loop, num_kb_relation = cfg.N, False, False, cfg.R1 - 1
+        kb_adj_mats = [tuple((np.asarray(et[k][bounds[b]:bounds[b + 1]]) - (b * cfg.N if k != 1 else 0)) for k in range(3))
+                       for b in range(cfg.B)] * reps
+        global2local_entity_maps = [()] * (cfg.B * reps)
+        num_data = cfg.B * reps
+        batches = np.arange(cfg.B * reps)
+
+    out = {}
+    for mode in ("in_line", "prefetched"):
+        ld = _Loader()
+        fact_mat.patch_loader(ld, cache=True, device=dev, prefetch=(mode == "prefetched"))
+        for r in range(reps):                          # first use uploads the questions' blocks
+            ld._build_fact_mat(np.arange(r * cfg.B, (r + 1) * cfg.B), 0.0)
+        torch.cuda.synchronize()
+        n = 0
+        t0 = time.perf_counter()
+        for _ in range(max(1, steps // reps)):
+            for r in range(reps):
+                bf = ld._build_fact_mat(np.arange(r * cfg.B, (r + 1) * cfg.B), 0.0)
+                plan_for(bf, cfg.B, cfg.N, cfg.R1, dev)
+                step()
+                n += 1
+        torch.cuda.synchronize()
+        out[mode] = (time.perf_counter() - t0) * 1e3 / n
+    return {"ms_per_build_plus_step_in_line": out["in_line"], "ms_per_build_plus_step_prefetched": out["prefetched"],
+            "note": "device-resident fact cache; every iteration builds a fresh structure; prefetched = worker thread + side "
+                    "stream one batch ahead (GNNRAG_PREFETCH=1 in tools/run_reference.py)"}
 
 
 def strong_shard(gbatch, gfeats, rank, world):
@@ -751,7 +807,7 @@ def e2e_leg():
     ncpu = os.cpu_count() or 1
     cpu_threads = min(32, ncpu)
 
-    def run(variant, pure, batch, data=None):
+    def run(variant, pure, batch, data=None, extra_env=None):
         argv = list(stage_ref.variant_argv(variant))
         if data:
             argv = [data if a == stage_ref.DATA else a for a in argv]
@@ -767,6 +823,7 @@ def e2e_leg():
                        MKL_NUM_THREADS=str(cpu_threads))
         else:
             env.update(GNNRAG_DEVICE_FACTS="1")
+        env.update(extra_env or {})
         t0 = time.perf_counter()
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
         wall = time.perf_counter() - t0
@@ -792,8 +849,16 @@ def e2e_leg():
     out = {"entry": "unmodified gnn/main.py --is_eval via tools/run_reference.py; staged synthetic dataset (oracle/stage_ref.py: "
                     "a relation path from the seed determines the answer; 520 test questions, subgraphs up to 2000 entities)",
            "host_cores": ncpu}
-    out["d200_batch16"] = {"gpu": run("d200", False, 16), "cpu_reference_sample32": run("d200", True, 16, sample)}
-    out["c1_d50_batch1"] = {"gpu": run("d50", False, 1), "cpu_reference_sample32": run("d50", True, 1, sample)}
+    out["d200_batch16"] = {"gpu": run("d200", False, 16),
+                           # the next batch's tuple + structure built by a worker thread on a side stream (StructurePrefetcher)
+                           "gpu_prefetch": run("d200", False, 16, extra_env={"GNNRAG_PREFETCH": "1"}),
+                           # + the question encoder's nn.LSTM off MIOpen (GNNRAG_MIOPEN_RNN=0: MIOpen's RNN call is ~12 ms
+                           # at these shapes, half of a batch's forward; the encoder is the reference's, a backend switch)
+                           "gpu_prefetch_native_lstm": run("d200", False, 16, extra_env={"GNNRAG_PREFETCH": "1", "GNNRAG_MIOPEN_RNN": "0"}),
+                           "cpu_reference_sample32": run("d200", True, 16, sample)}
+    out["c1_d50_batch1"] = {"gpu": run("d50", False, 1),
+                            "gpu_native_lstm": run("d50", False, 1, extra_env={"GNNRAG_MIOPEN_RNN": "0"}),
+                            "cpu_reference_sample32": run("d50", True, 1, sample)}
     for k in ("d200_batch16", "c1_d50_batch1"):
         g, c = out[k]["gpu"], out[k]["cpu_reference_sample32"]
         if "questions_per_s" in g and "questions_per_s" in c:

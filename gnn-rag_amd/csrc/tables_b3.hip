@@ -336,6 +336,12 @@ constexpr int kVqRowB = 2 * kVqHalf * 2;       // bytes per plane row: [relu(T) 
 #ifndef GNNRAG_UPD_ABL
 #define GNNRAG_UPD_ABL 0         // timing-only ablations of k_update_b3: 1 no LDS reads, 2 no A refills, 4 no nbr
 #endif                           // loads, 8 no stores, 16 no 3-way split
+#ifndef GNNRAG_UPD_PRIO
+#define GNNRAG_UPD_PRIO 0        // k_update_b3: s_setprio level around every k block's MFMA section (experiment)
+#endif
+#ifndef GNNRAG_UPD_DESYNC
+#define GNNRAG_UPD_DESYNC 0      // k_update_b3: 64-cycle sleeps of waves 4..7 before their first tile (experiment)
+#endif
 #ifndef GNNRAG_VQ_ABL
 #define GNNRAG_VQ_ABL 0          // timing-only ablations (wrong results): 1 no LDS fragment reads, 2 no A refills,
 #endif                           // 4 no V staging, 8 no epilogue stores
@@ -659,6 +665,13 @@ __device__ __forceinline__ void update_b3_part(const UpdB3Args& a, unsigned char
   unsigned fl_next = 0x01010101u;
   if (FL && t < tend) fl_next = *reinterpret_cast<const unsigned*>(a.add_flag + (size_t)t * 16 + 4 * fg);
   __syncthreads();
+#if GNNRAG_UPD_DESYNC > 0
+  // experiment (round 4): the two waves of a SIMD (w and w + 4) run identical code from the same start and stay in phase -
+  // both split, both read fragments, both issue MFMAs at the same time; a one-time offset of about half a tile for the
+  // second wave would let one wave's VALU / LDS phases fall under the other's MFMAs (no barrier follows)
+  if (wave >= 4)
+    for (int i = 0; i < GNNRAG_UPD_DESYNC; ++i) __builtin_amdgcn_s_sleep(1);
+#endif
 
   for (; t < tend; ++t) {
     const int rbase = t * 16 + 4 * fg;                       // C layout: rows rbase + q, column slot fr
@@ -717,6 +730,9 @@ __device__ __forceinline__ void update_b3_part(const UpdB3Args& a, unsigned char
       ra[kb][1] = a_piece(tload, kb, 1);
 #endif
       const unsigned char* wb = lds + fr * RB + kb * 64 + fg_t * 16;
+#if GNNRAG_UPD_PRIO
+      __builtin_amdgcn_s_setprio(GNNRAG_UPD_PRIO);          // experiment: the wave in its MFMA block wins the issue arbitration
+#endif
 #pragma unroll
       for (int nt = 0; nt < CTN; nt += 2) {
         bf16x8 b0[3], b1[3];
@@ -739,6 +755,9 @@ __device__ __forceinline__ void update_b3_part(const UpdB3Args& a, unsigned char
             acc[nt + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[PA[p]], b1[PB[p]], acc[nt + 1], 0, 0, 0);
         }
       }
+#if GNNRAG_UPD_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
     // epilogue from the registers
     float part[4] = {0.f, 0.f, 0.f, 0.f};

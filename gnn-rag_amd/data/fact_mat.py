@@ -142,6 +142,8 @@ class BatchFacts:
         # DeviceStructureCache: the questions' cached single-question structures (ops.CsrPlan, B = 1), in batch order -
         # the modules then assemble the batch structure by concatenation (ops.CsrPlan.concat) instead of sorting
         self.plans = plans
+        # StructurePrefetcher: (finished ops.CsrPlan of this batch, the event recorded behind its build, (B, N, R1))
+        self.prebuilt = None
 
     @property
     def hrt_device(self):
@@ -297,7 +299,80 @@ class DeviceStructureCache(DeviceFactCache):
                           make_hrt=lambda: _cat_blocks([p._hrt[:, : p.F] for p in plans], sizes, N).to(self.device))
 
 
-def patch_loader(loader, cache: bool = False, keep_rng_stream: bool = False, device=None, structures: bool = False):
+class StructurePrefetcher:
+    """First-pass structure build OFF the critical path: while the GPU runs batch k, a worker
+    thread assembles batch k + 1's device-resident tuple and builds its structure on a SIDE STREAM (the build's one wait
+    for its stream - it hands the relation counts to the host - then blocks the worker, not the caller).  The batch
+    handed out carries the finished structure (``BatchFacts.prebuilt``); ``plan_for`` makes the caller's stream wait for
+    the build's event and uses it.  Evaluation order is known (``loader.batches``, dataset_load.py:599-603), so the next
+    batch is the next slice of the same size; anything else (a different slice, fact dropout) is simply built in line.
+    One batch ahead, one worker: results are bit-identical to the in-line build (same kernels, same inputs)."""
+
+    def __init__(self, loader, cache, device):
+        import concurrent.futures
+        import threading
+        import torch
+        self.loader, self.cache, self.device = loader, cache, torch.device(device)
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="gnnrag-prefetch")
+        self.lock = threading.Lock()
+        self.side = None
+        self.pending = None              # (key, future)
+        self.hits = self.misses = 0
+
+    @staticmethod
+    def _key(sample_ids):
+        return np.asarray(sample_ids, dtype=np.int64).tobytes()
+
+    def _build(self, sample_ids):
+        import torch
+        from .. import ops
+        with torch.cuda.device(self.device):
+            if self.side is None:
+                self.side = torch.cuda.Stream()
+            with torch.cuda.stream(self.side):
+                with self.lock:
+                    bf = self.cache.batch(sample_ids)
+                N = self.loader.max_local_entity
+                R1 = self.loader.num_kb_relation + 1
+                if bf.plans is not None:
+                    plan = ops.CsrPlan.concat(bf.plans, N, R1, self.device)
+                else:
+                    plan = ops.CsrPlan(None, None, None, len(sample_ids), N, R1, self.device, hrt_device=bf.hrt_device)
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+        bf.prebuilt = (plan, ev, (len(sample_ids), N, R1))
+        return bf
+
+    def get(self, sample_ids):
+        key = self._key(sample_ids)
+        bf = None
+        if self.pending is not None:
+            pkey, fut = self.pending
+            self.pending = None
+            if pkey == key:
+                bf = fut.result()
+                self.hits += 1
+            else:
+                fut.result()                                   # an unexpected order: drop it (its device work first)
+                if self.side is not None:
+                    self.side.synchronize()
+        if bf is None:
+            self.misses += 1
+            with self.lock:
+                bf = self.cache.batch(sample_ids)
+        # the next slice of loader.batches, same size
+        ld = self.loader
+        batches = np.asarray(ld.batches)
+        n = len(sample_ids)
+        pos = np.flatnonzero(batches == sample_ids[0]) if n else np.zeros(0, np.int64)
+        if len(pos) and np.array_equal(batches[pos[0]: pos[0] + n], np.asarray(sample_ids)) and pos[0] + n < len(batches):
+            nxt = batches[pos[0] + n: pos[0] + 2 * n].copy()
+            self.pending = (self._key(nxt), self.pool.submit(self._build, nxt))
+        return bf
+
+
+def patch_loader(loader, cache: bool = False, keep_rng_stream: bool = False, device=None, structures: bool = False,
+                 prefetch: bool = False):
     """Rebinds ``loader._build_fact_mat`` to the vectorised builder (the reference file is untouched).
     ``cache=True`` additionally serves ``fact_dropout == 0`` batches from a :class:`FactCache`.  The cached
     path does not draw the per-question ``np.random.permutation`` the reference draws even without dropout
@@ -307,13 +382,17 @@ def patch_loader(loader, cache: bool = False, keep_rng_stream: bool = False, dev
     at the cost of most of the caching gain).  Use the plain cache for evaluation-only runs.  ``device``: keep the
     per-question id blocks on that GPU (:class:`DeviceFactCache`; the tuple is then a :class:`BatchFacts`, readable by
     the MI355X modules only).  ``structures`` (with ``device``): also cache every question's sorted structure on the GPU,
-    so that a batch's structure is a concatenation (:class:`DeviceStructureCache`)."""
+    so that a batch's structure is a concatenation (:class:`DeviceStructureCache`).  ``prefetch`` (with ``device``): the
+    next batch's tuple and structure are built by a worker thread on a side stream while the current batch runs
+    (:class:`StructurePrefetcher`)."""
     fc = None
     if cache:
         if device is not None and structures:
             fc = DeviceStructureCache(loader, device)
         else:
             fc = DeviceFactCache(loader, device) if device is not None else FactCache(loader)
+    pf = StructurePrefetcher(loader, fc, device) if (prefetch and fc is not None and device is not None) else None
+    loader._gnnrag_prefetcher = pf
 
     def build(self, sample_ids, fact_dropout):
         if fc is not None and fact_dropout == 0:
@@ -321,6 +400,8 @@ def patch_loader(loader, cache: bool = False, keep_rng_stream: bool = False, dev
                 for sample_id in sample_ids:
                     n = len(self.create_kb_adj_mats(sample_id)[0]) if self.data_eff else len(self.kb_adj_mats[sample_id][0])
                     np.random.permutation(n)                                   # dataset_load.py:489
+            if pf is not None:
+                return pf.get(sample_ids)
             return fc.batch(sample_ids)
         return build_fact_mat(self, sample_ids, fact_dropout)
 

@@ -41,8 +41,11 @@ COMMON_ARGV = ["ReaRev", "--data_folder", DATA, "--lm", "lstm", "--relation_word
                "--num_iter", "3", "--num_ins", "2", "--num_gnn", "3", "--batch_size", "16", "--test_batch_size", "16"]
 VARIANTS = {
     "d50": {"argv": ["--entity_dim", "50", "--kg_dim", "25", "--name", "synth"], "train": "synth", "epochs": 8},
-    "d200": {"argv": ["--entity_dim", "200", "--kg_dim", "100", "--name", "synth"], "train": "synth200", "epochs": 8,
-             "lr": "0.001"},                      # (lr 0.005 diverges at this width: loss 16 from the first epoch)
+    "d200": {"argv": ["--entity_dim", "200", "--kg_dim", "100", "--name", "synth"], "train": "synth200", "epochs": 10,
+             # at this width a constant lr either diverges in the first epoch (0.004, 0.005: loss 16) or stays on the
+             # "uniform over the seed's neighbourhood" plateau (0.001, 0.0025: H@1 0.16-0.19 after 8-10 epochs): the
+             # reference's trainer is stepped with a warm-up (the optimiser's lr is set before every train_epoch call)
+             "lr": "0.0005", "lr_by_epoch": [0.0005, 0.001, 0.002, 0.003, 0.004, 0.004, 0.004, 0.004, 0.004, 0.004]},
     "cwq": {"argv": ["--entity_dim", "50", "--kg_dim", "25", "--name", "cwq"], "train": "synth", "epochs": 0},
 }
 DATASET_VERSION = "r4-learnable-2"
@@ -207,7 +210,8 @@ def make_checkpoint(variant="d50"):
     parsing.add_parse_args(parser)
     exp = VARIANTS[variant]["train"]
     args = parser.parse_args(variant_argv(variant) + ["--checkpoint_dir", CKPT, "--experiment_name", exp, "--lr",
-                                                      VARIANTS[variant].get("lr", "0.005")])
+                                                      os.environ.get("GNNRAG_STAGE_LR") or VARIANTS[variant].get("lr", "0.005")]
+                             + (os.environ.get("GNNRAG_STAGE_ARGS", "").split()))
     args.use_cuda = False
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)
@@ -215,7 +219,11 @@ def make_checkpoint(variant="d50"):
     from train_model import Trainer_KBQA
     from utils import create_logger
     trainer = Trainer_KBQA(args=vars(args), model_name=args.model_name, logger=create_logger(args))
-    for epoch in range(VARIANTS[variant]["epochs"]):
+    for epoch in range(int(os.environ.get("GNNRAG_STAGE_EPOCHS") or VARIANTS[variant]["epochs"])):
+        sched = VARIANTS[variant].get("lr_by_epoch")
+        if sched and not os.environ.get("GNNRAG_STAGE_LR"):
+            for grp in trainer.optim_model.param_groups:
+                grp["lr"] = sched[min(epoch, len(sched) - 1)]
         loss, _, h1, f1 = trainer.train_epoch()
         print("stage_ref[%s]: epoch %d loss %.4f train h1 %.3f f1 %.3f" % (variant, epoch + 1, loss, np.mean(h1), np.mean(f1)),
               flush=True)

@@ -145,3 +145,40 @@ def test_batch_structure_as_concatenation_of_cached_question_structures(shape):
         if k != "big":
             np.testing.assert_array_equal(pa[k], pb[k], err_msg="shard " + k)
     np.testing.assert_array_equal(sb.hrt_device.cpu().numpy(), np.stack([sa[0], sa[1], sa[2]]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("structures", [False, True], ids=["fact_cache", "structure_cache"])
+def test_prefetched_structure_is_the_in_line_structure(structures):
+    """First-pass structure build off the critical path (StructurePrefetcher): walking the loader's batches in order, every
+    batch after the first arrives with a structure a worker thread built on a side stream - bit-identical to the structure
+    built in line from the same tuple, and ``plan_for`` hands out exactly that object; an out-of-order request is built in
+    line (and still correct)."""
+    import torch
+    import gnnrag_amd  # noqa: F401
+    from gnnrag_amd import ops
+    from gnnrag_amd.data.fact_mat import FactCache, patch_loader
+    from gnnrag_amd.modules.kg_reasoning.base_gnn import plan_for
+    dev = torch.device("cuda", 0)
+    ld = _StubLoader(np.random.default_rng(21), n_q=23, N=400, num_rel=30)
+    ld.num_data = 23
+    ld.batches = np.arange(23)
+    host = FactCache(ld)
+    patch_loader(ld, cache=True, device=dev, structures=structures, prefetch=True)
+    N, R1, bs = ld.max_local_entity, ld.num_kb_relation + 1, 4
+    order = [list(range(s, min(s + bs, 23))) for s in range(0, 23, bs)]
+    for k, ids in enumerate(order + [order[2], order[0]]):                    # then two out-of-order requests
+        bf = ld._build_fact_mat(np.asarray(ids), 0.0)
+        a = host.batch(ids)
+        want = ops.CsrPlan(a[0], a[1], a[2], len(ids), N, R1, dev).to_host()
+        got_plan = plan_for(bf, len(ids), N, R1, dev)
+        if 0 < k < len(order):
+            assert bf.prebuilt is not None and got_plan is bf.prebuilt[0]     # built ahead by the worker
+        got = got_plan.to_host()
+        for key in want:
+            if key == "big":
+                assert all(np.array_equal(x, y) for x, y in zip(want[key], got[key]))
+            else:
+                np.testing.assert_array_equal(want[key], got[key], err_msg="%s (batch %d)" % (key, k))
+    pf = ld._gnnrag_prefetcher
+    assert pf.hits == len(order) - 1 and pf.misses == 3, (pf.hits, pf.misses)

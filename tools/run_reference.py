@@ -65,6 +65,13 @@ def main():
         dist.init_process_group("nccl")
         atexit.register(lambda: dist.is_initialized() and dist.destroy_process_group())
 
+    # GNNRAG_MIOPEN_RNN=0: the reference's question encoder is an nn.LSTM over a handful of tokens; MIOpen's RNN call takes
+    # ~12 ms per call at these shapes on the MI355X (half of an evaluation batch's forward, tools/profile_e2e.sh) - with
+    # the cudnn/MIOpen backend off torch runs its own per-step kernels.  A backend setting, no reference code is touched;
+    # the encoder itself is out of this package's scope.
+    if os.environ.get("GNNRAG_MIOPEN_RNN") == "0":
+        import torch
+        torch.backends.cudnn.enabled = False
     # the reference's two start-up bugs: an undefined create_parser_nutrea; LSTMInstruction calls
     # BaseInstruction.__init__(args) without the `constraint` argument the base class requires
     shim_startup_bugs()
@@ -88,8 +95,10 @@ def main():
                         dev = torch.device("cuda", torch.cuda.current_device())
                     # GNNRAG_DEVICE_STRUCTURES=1: additionally every question's sorted structure stays on the GPU and a
                     # batch's structure is their concatenation (no per-batch sort)
+                    # GNNRAG_PREFETCH=1: the next batch's tuple + structure are built on a side stream by a worker thread
                     patch_loader(dataset[split], cache=(split != "train"), keep_rng_stream=not is_eval, device=dev,
-                                 structures=bool(os.environ.get("GNNRAG_DEVICE_STRUCTURES")) and dev is not None)
+                                 structures=bool(os.environ.get("GNNRAG_DEVICE_STRUCTURES")) and dev is not None,
+                                 prefetch=os.environ.get("GNNRAG_PREFETCH") == "1" and dev is not None)
             return dataset
 
         dataset_load.load_data = load_data

@@ -61,6 +61,9 @@ VARIANTS = {
     # the register-resident update (update_wr.hip; measured slower, opt-in) on at run time ("__env__": the default build
     # with these environment variables)
     "wr_on": {"__env__": {"GNNRAG_UPDATE_WR": "1"}},
+    # k_update_b3 with the second wave of every SIMD started ~1/4, 1/2, 1 tile late (phase-locking experiment)
+    "prio2": {"GNNRAG_UPD_PRIO": 2}, "prio2_desync80": {"GNNRAG_UPD_PRIO": 2, "GNNRAG_UPD_DESYNC": 80},
+    "desync40": {"GNNRAG_UPD_DESYNC": 40}, "desync80": {"GNNRAG_UPD_DESYNC": 80}, "desync160": {"GNNRAG_UPD_DESYNC": 160},
     "split_trunc": {"GNNRAG_SPLIT_RN": 0},      # the truncation form of the exact 3-way bf16 split (rounds 1-2)
     "vq_nolds": {"GNNRAG_VQ_ABL": 1}, "vq_noa": {"GNNRAG_VQ_ABL": 2}, "vq_nostage": {"GNNRAG_VQ_ABL": 4},
     "upd_nolds": {"GNNRAG_UPD_ABL": 1}, "upd_noa": {"GNNRAG_UPD_ABL": 2}, "upd_noadd": {"GNNRAG_UPD_ABL": 4},
@@ -93,16 +96,23 @@ with torch.no_grad():
     agg = ops.aggregate(layer.plan, dense, devin.ins[0], Tf, Ti)
     ms = {}
     seed = devin.seed_dist
-    for name, prior in (("aggf_dense", dense), ("aggf_seed", seed)):
+    only_upd = os.environ.get("GNNRAG_TUNE_ONLY") == "upd"      # the self-block update alone (short child)
+    for name, prior in ((("aggf_dense", dense), ("aggf_seed", seed)) if not only_upd else ()):
         fn = lambda: ops.aggregate_fused(layer.plan, prior, P)
         fn()
         ms[name] = float(np.mean(bench._events_ms(fn, 20)))
-    if os.environ.get("GNNRAG_TUNE_GEMM"):
+    if os.environ.get("GNNRAG_TUNE_GEMM") and not only_upd:
         _, planes = ops.rel_transform(devin.rel_features, devin.rel_features_inv, [(rl.weight, rl.bias, None, None)], planes=True)
         fn = lambda: ops.relation_tables_planes(layer.plan, planes[0], devin.ins[0], e2e.weight)
         fn()
         ms["tables_vq"] = float(np.mean(bench._events_ms(fn, 10)))
-    for math in ((0, 1) if os.environ.get("GNNRAG_TUNE_GEMM") else ()):
+    if only_upd:
+        ops.set_dense_math(1)
+        fn = lambda: ops.update_score_fused(h, nbr, e2e.weight, e2e.bias, sf.weight, sf.bias, layer.local_entity_mask, I)
+        fn()
+        for rep in range(3):
+            ms["upd_fused_m1_%%d" %% rep] = float(np.mean(bench._events_ms(fn, 20)))
+    for math in ((0, 1) if os.environ.get("GNNRAG_TUNE_GEMM") and not only_upd else ()):
         ops.set_dense_math(math)
         fns = {"tables": lambda: ops.relation_tables(layer.plan, Tf, Ti, devin.ins[0], e2e.weight),
                "upd": lambda: ops.update_score(h, agg, e2e.weight, e2e.bias, sf.weight, sf.bias, layer.local_entity_mask, I),
