@@ -75,6 +75,8 @@ SIGNATURES = {
                                         C.POINTER(RelorderStruct), _VP]),
     "gnnrag_backward_workspace_bytes": (C.c_size_t, [C.POINTER(CsrStruct), C.POINTER(RelorderStruct), C.c_int32,
                                                      C.c_int32]),
+    "gnnrag_aggregate_fused_backward": (C.c_int, [C.POINTER(CsrStruct), C.POINTER(RelorderStruct), _VP, _VP, _VP, _VP, _VP,
+                                                 C.c_int32, _VP, C.c_size_t, _VP]),
     "gnnrag_aggregate_backward": (C.c_int, [C.POINTER(CsrStruct), C.POINTER(RelorderStruct), _VP, _VP, _VP, _VP, _VP,
                                             _VP, _VP, _VP, _VP, C.c_int32, C.c_int32, _VP, C.c_size_t, _VP]),
     "gnnrag_typelayer_backward": (C.c_int, [C.POINTER(CsrStruct), C.POINTER(RelorderStruct), _VP, _VP, C.c_int, _VP,
@@ -121,7 +123,7 @@ SIGNATURES = {
     "gnnrag_error_string": (C.c_char_p, [C.c_int]),
 }
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 PATH_AUTO, PATH_UNFUSED, PATH_FUSED = 0, 1, 2
 PATH_ONLY_FWD, PATH_ONLY_INV = 0x10, 0x20        # OR-ed into the path: one-direction layers (NSM)
 PATH_SEED_PRIOR = 0x40                           # OR-ed into the path: the (first layer's) prior is a seed distribution

@@ -34,6 +34,42 @@ class AggregateFn(torch.autograd.Function):
         return None, g_dist.view(ctx.plan.B, ctx.plan.N), g_ins, g_Tf, g_Ti
 
 
+class FusedAggregateFn(torch.autograd.Function):
+    """nbr [BN, D] = the fused walk over per-question relation tables P [2, rel_total, D] (``gnnrag_aggregate_fused``);
+    backward on ``gnnrag_aggregate_fused_backward`` (gather kernels, fixed summation order)."""
+
+    @staticmethod
+    def forward(ctx, plan, dist, P):
+        dist = dist.detach().float().contiguous()
+        P = P.detach().float().contiguous()
+        ctx.plan = plan
+        ctx.save_for_backward(dist, P)
+        return ops.aggregate_fused(plan, dist, P)
+
+    @staticmethod
+    def backward(ctx, g_nbr):
+        dist, P = ctx.saved_tensors
+        g_dist, g_P = ops.aggregate_fused_backward(ctx.plan, dist, P, g_nbr.float().contiguous())
+        return None, g_dist.view(ctx.plan.B, ctx.plan.N), g_P
+
+
+def relation_tables_dense(plan, T_fwd, T_inv, ins, W_e2e):
+    """Differentiable per-question relation tables of the fused form in plain torch ops:
+    P[d, (b, r), :] = sum_i W_e2e[:, (1 + 2 i + d) D : (2 + 2 i + d) D] . relu(T_d[r] * ins[b, i]) over the compact rows
+    (question, relation in use) of the structure - a few ten thousand rows, where the per-fact form of the reference
+    (reasongnn.py:71-79) has one row per fact.  [2, rel_total, D]."""
+    rows = plan.rel_rows_device()
+    b, r = rows[:, 0].long(), rows[:, 1].long()
+    I, D = ins.shape[1], ins.shape[2]
+    q = ins.index_select(0, b)                                             # [M, I, D]
+    out = []
+    for d, T in enumerate((T_fwd, T_inv)):
+        z = torch.relu(T.index_select(0, r).unsqueeze(1) * q)             # [M, I, D]
+        Wd = torch.stack([W_e2e[:, (1 + 2 * i + d) * D:(2 + 2 * i + d) * D] for i in range(I)])    # [I, D_out, D]
+        out.append(torch.einsum("mik,iok->mo", z, Wd))
+    return torch.stack(out)
+
+
 class TypeAggFn(torch.autograd.Function):
     """h0 [BN, D] = relu(sum over incident facts of v_f T[rel_f]) (both directions)."""
 

@@ -66,16 +66,19 @@ struct BwdArgs {
 //   sum_f w_f sum_i < g_agg[dst_f, 2i+d, :], relu(T_d[rel_f,:] * q_i) >.
 // V4: the lane owns float4 columns lane, lane + 64, ... (D % 4 == 0); else scalar columns lane, lane + 64, ...
 // Two facts per step so their row loads overlap.
-template <bool V4>
+// FUSED (backward of the fused walk, gnnrag_aggregate_fused_backward): the message of a fact is row
+// rel_off[b] + (compact relation) of the question's own table P[d] (a.T[d]; `q` then carries that row offset in its
+// ADDRESS-free form `roff`), nothing is multiplied by an instruction or gated, g is [BN, D] for both directions.
+template <bool V4, bool FUSED = false>
 __device__ __forceinline__ float prior_grad_range(const BwdArgs& a, const float* __restrict__ q, int d, int j0,
-                                                  int j1, int lane) {
+                                                  int j1, int lane, int roff = 0) {
   const int o = 1 - d;
-  const int D = a.D, I = a.I;
-  const size_t ld = (size_t)2 * I * D;
-  const int2* __restrict__ edge = a.edge[o];
+  const int D = a.D, I = FUSED ? 1 : a.I;
+  const size_t ld = FUSED ? (size_t)D : (size_t)2 * I * D;
+  const int2* __restrict__ edge = FUSED ? a.edge_l[o] : a.edge[o];
   const float* __restrict__ w = a.w[o];
-  const float* __restrict__ T = a.T[d];
-  const float* __restrict__ g = a.g + (size_t)d * D;
+  const float* __restrict__ T = a.T[d] + (FUSED ? (size_t)roff * D : 0);
+  const float* __restrict__ g = FUSED ? a.g : a.g + (size_t)d * D;
   constexpr int W = V4 ? 4 : 1;
   typedef float vec __attribute__((ext_vector_type(W)));
   auto dot2 = [&](const float* t0, const float* g0, const float* t1, const float* g1, float& p0, float& p1) {
@@ -83,11 +86,14 @@ __device__ __forceinline__ float prior_grad_range(const BwdArgs& a, const float*
       const vec tv0 = *reinterpret_cast<const vec*>(t0 + c);
       const vec tv1 = *reinterpret_cast<const vec*>(t1 + c);
       for (int i = 0; i < I; ++i) {
-        const vec qv = *reinterpret_cast<const vec*>(q + i * D + c);
         const vec gv0 = *reinterpret_cast<const vec*>(g0 + (size_t)2 * i * D + c);
         const vec gv1 = *reinterpret_cast<const vec*>(g1 + (size_t)2 * i * D + c);
-        const vec m0 = __builtin_elementwise_max(tv0 * qv, (vec)0.f);
-        const vec m1 = __builtin_elementwise_max(tv1 * qv, (vec)0.f);
+        vec m0 = tv0, m1 = tv1;
+        if constexpr (!FUSED) {
+          const vec qv = *reinterpret_cast<const vec*>(q + i * D + c);
+          m0 = __builtin_elementwise_max(tv0 * qv, (vec)0.f);
+          m1 = __builtin_elementwise_max(tv1 * qv, (vec)0.f);
+        }
 #pragma unroll
         for (int k = 0; k < W; ++k) {
           p0 += gv0[k] * m0[k];
@@ -124,12 +130,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // one wave per source node; blockIdx.y = question (its instructions are staged in LDS once)
-template <bool V4>
+template <bool V4, bool FUSED = false>
 __global__ __launch_bounds__(256) void k_bwd_prior(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float q_s[];      // [I][D]
   const int b = blockIdx.y;
-  for (int x = threadIdx.x; x < a.I * a.D; x += 256) q_s[x] = a.ins[(size_t)b * a.I * a.D + x];
-  __syncthreads();
+  if constexpr (!FUSED) {
+    for (int x = threadIdx.x; x < a.I * a.D; x += 256) q_s[x] = a.ins[(size_t)b * a.I * a.D + x];
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nl = blockIdx.x * 4 + wave;
   if (nl >= a.N) return;
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(256) void k_bwd_prior(const BwdArgs a) {
     const int o = 1 - d;
     const int beg = a.row_ptr[o][s], end = a.row_ptr[o][s + 1];
     if (end - beg > a.heavy_deg) continue;           // k_bwd_prior_heavy adds these
-    acc += prior_grad_range<V4>(a, q_s, d, beg, end, lane);
+    acc += prior_grad_range<V4, FUSED>(a, q_s, d, beg, end, lane, FUSED ? a.rel_off[b] : 0);
   }
   acc = wave_sum(acc);
   if (lane == 0) a.g_dist[s] = acc;
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(256) void k_bwd_prior(const BwdArgs a) {
 
 // rows above heavy_deg: one workgroup per 256-fact chunk (64 facts per wave) -> part[o][chunk][wave];
 // k_bwd_prior_heavy_reduce adds a row's pieces in order onto k_bwd_prior's store (no atomics)
-template <bool V4>
+template <bool V4, bool FUSED = false>
 __global__ __launch_bounds__(256) void k_bwd_prior_heavy(const BwdArgs a, float* __restrict__ part) {
   const int o = blockIdx.y, d = 1 - o;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -166,8 +174,8 @@ __global__ __launch_bounds__(256) void k_bwd_prior_heavy(const BwdArgs a, float*
     const int cend = min(cbeg + kHeavyDeg, a.row_ptr[o][s + 1]);
     const int beg = min(cbeg + wave * (kHeavyDeg / 4), cend);
     const int end = min(beg + kHeavyDeg / 4, cend);
-    const float* q = a.ins + (size_t)(s / a.N) * a.I * a.D;
-    const float acc = wave_sum(prior_grad_range<V4>(a, q, d, beg, end, lane));
+    const float* q = FUSED ? nullptr : a.ins + (size_t)(s / a.N) * a.I * a.D;
+    const float acc = wave_sum(prior_grad_range<V4, FUSED>(a, q, d, beg, end, lane, FUSED ? a.rel_off[s / a.N] : 0));
     if (lane == 0) part[((size_t)o * a.max_chunks + c) * 4 + wave] = acc;
   }
 }
@@ -410,7 +418,9 @@ __global__ __launch_bounds__(256) void k_bwd_reduce_tables(const BwdArgs a, cons
 // and written on their own:  Vc[chunk][d][:] = sum_i U[d][i]*gate*q_i   (-> g_T_d[r] over chunks),
 //                            Qc[chunk][i][:] = sum_d U[d][i]*gate*t_d   (-> g_ins[b,i] over chunks).
 // No atomics: every output element has one writer and the reductions run in a fixed order.
-template <int NI, int CPL>
+// FUSED (backward of the fused walk): g is [BN, D] for both directions and the chunk's raw sums are the result -
+// Vc[chunk][d][:] = U[d] = sum_f w_f dist[src_d(f)] g[dst_d(f), :], the chunk's share of g_P[d][row]; no gate, no Qc.
+template <int NI, int CPL, bool FUSED = false>
 __global__ __launch_bounds__(256) void k_bwd_rel_gather(const BwdArgs a, const int2* __restrict__ ht,
                                                         const float* __restrict__ w,
                                                         const int32_t* __restrict__ row_ptr,
@@ -432,7 +442,7 @@ __global__ __launch_bounds__(256) void k_bwd_rel_gather(const BwdArgs a, const i
   const int beg = row_ptr[row] + (c - chunk_ptr[row]) * kHeavyDeg;
   const int end = min(beg + kHeavyDeg, row_ptr[row + 1]);
   const int D = a.D;
-  const size_t ld = (size_t)2 * NI * D;
+  const size_t ld = FUSED ? (size_t)D : (size_t)2 * NI * D;
   f32x4 U[2][NI][CPL];
 #pragma unroll
   for (int d = 0; d < 2; ++d)
@@ -468,7 +478,7 @@ __global__ __launch_bounds__(256) void k_bwd_rel_gather(const BwdArgs a, const i
       for (int d = 0; d < 2; ++d) {
         const float pv = p[u][d];
         if (pv == 0.f) continue;                // wave-uniform
-        const float* grow = a.g + (size_t)(d == 0 ? e[u].y : e[u].x) * ld + (size_t)d * D;
+        const float* grow = a.g + (size_t)(d == 0 ? e[u].y : e[u].x) * ld + (FUSED ? 0 : (size_t)d * D);
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -478,6 +488,15 @@ __global__ __launch_bounds__(256) void k_bwd_rel_gather(const BwdArgs a, const i
     }
   }
   float* vout = Vc + (size_t)c * 2 * D;
+  if constexpr (FUSED) {
+#pragma unroll
+    for (int m = 0; m < CPL; ++m)
+      if (cv[m]) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) *reinterpret_cast<f32x4*>(vout + (size_t)d * D + col[m]) = U[d][0][m];
+      }
+    return;
+  }
   float* qout = Qc + (size_t)c * NI * D;
   const float* qin = a.ins + (size_t)br.x * NI * D;
 #pragma unroll
@@ -630,6 +649,20 @@ __global__ __launch_bounds__(1024) void k_bwd_reduce_ins_chunks(const BwdArgs a,
     if (grp == 0 && col < D)
       a.g_ins[((size_t)b * NI + i) * D + col] = ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
     __syncthreads();
+  }
+}
+
+// fused walk: g_P[d][row][:] = sum over the row's chunks of Vc, in chunk order (one workgroup per compact row)
+__global__ __launch_bounds__(256) void k_bwd_reduce_rows_chunks(const float* __restrict__ Vc,
+                                                                const int32_t* __restrict__ chunk_ptr, int Rtot, int D,
+                                                                float* __restrict__ g_P) {
+  const int row = blockIdx.x;
+  const int c0 = chunk_ptr[row], c1 = chunk_ptr[row + 1];
+  for (int x = threadIdx.x; x < 2 * D; x += 256) {
+    const int d = x >= D, col = x - d * D;
+    float acc = 0.f;
+    for (int c = c0; c < c1; ++c) acc += Vc[((size_t)c * 2 + d) * D + col];
+    g_P[((size_t)d * Rtot + row) * D + col] = acc;
   }
 }
 
@@ -803,6 +836,61 @@ extern "C" int gnnrag_aggregate_backward(const gnnrag_csr* csr, const gnnrag_rel
   hipLaunchKernelGGL(k_bwd_reduce_ins_chunks, dim3(csr->B, I), dim3(1024), 0, stream, a, (const float*)Qc,
                      (const int32_t*)relorder->chunk_ptr);
   GNNRAG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gnnrag_aggregate_fused_backward(const gnnrag_csr* csr, const gnnrag_relorder* relorder, const float* dist,
+                                               const float* P, const float* g_nbr, float* g_dist, float* g_P, int32_t D,
+                                               void* workspace, size_t workspace_bytes, gnnrag_stream_t stream_) {
+  if (!csr || !relorder || !dist || !P || !g_nbr || !g_dist || !g_P || D <= 0 || csr->rel_total < 0) return GNNRAG_E_BADARG;
+  if (relorder->F != csr->F || relorder->rel_total != csr->rel_total) return GNNRAG_E_BADARG;
+  if (!gather_ok(relorder, D, 1) || ((((uintptr_t)P | (uintptr_t)g_nbr | (uintptr_t)g_P) & 15) != 0)) return GNNRAG_E_UNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_;
+  BwdArgs a;
+  fill_bwd(a, csr, D, 1);
+  a.w[0] = csr->w_gnn[0];
+  a.w[1] = csr->w_gnn[1];
+  a.dist = dist;
+  a.T[0] = P;
+  a.T[1] = P + (size_t)csr->rel_total * D;
+  a.g = g_nbr;
+  a.g_dist = g_dist;
+  const dim3 pgrid((csr->N + 3) / 4, csr->B);
+  hipLaunchKernelGGL((k_bwd_prior<true, true>), pgrid, dim3(256), 0, stream, a);
+  GNNRAG_LAUNCH_CHECK();
+  const size_t need = bwd_gather_ws_bytes(relorder, D, 1);
+  const size_t hbytes = (size_t)2 * csr->max_chunks * 4 * sizeof(float);
+  if (!workspace || workspace_bytes < (need > hbytes ? need : hbytes)) return GNNRAG_E_WORKSPACE;
+  if (csr->F > 0) {
+    float* part = (float*)workspace;
+    const int nb = csr->max_chunks < 4096 ? csr->max_chunks : 4096;
+    hipLaunchKernelGGL((k_bwd_prior_heavy<true, true>), dim3(nb > 0 ? nb : 1, 2), dim3(256), 0, stream, a, part);
+    GNNRAG_LAUNCH_CHECK();
+    for (int o = 0; o < 2; ++o) {
+      hipLaunchKernelGGL(k_bwd_prior_heavy_reduce, dim3((csr->heavy_cap + 255) / 256 < 64 ? (csr->heavy_cap + 255) / 256 : 64),
+                         dim3(256), 0, stream, a, (const float*)part, o);
+      GNNRAG_LAUNCH_CHECK();
+    }
+  }
+  float* Vc = (float*)workspace;
+  if (relorder->n_chunks > 0) {
+    const int nblk = 8 * ((relorder->n_chunks + 31) / 32);
+    const int cpl = (D / 4 + 63) / 64;
+#define GNNRAG_GATHER_F(C)                                                                                      \
+  hipLaunchKernelGGL((k_bwd_rel_gather<1, C, true>), dim3(nblk), dim3(256), 0, stream, a, (const int2*)relorder->ht, \
+                     (const float*)relorder->w, (const int32_t*)relorder->row_ptr,                             \
+                     (const int32_t*)relorder->chunk_ptr, relorder->n_chunks, Vc, (float*)nullptr)
+    if (cpl == 1) GNNRAG_GATHER_F(1);
+    else if (cpl == 2) GNNRAG_GATHER_F(2);
+    else GNNRAG_GATHER_F(4);
+#undef GNNRAG_GATHER_F
+    GNNRAG_LAUNCH_CHECK();
+  }
+  if (csr->rel_total > 0) {
+    hipLaunchKernelGGL(k_bwd_reduce_rows_chunks, dim3(csr->rel_total), dim3(256), 0, stream, (const float*)Vc,
+                       (const int32_t*)relorder->chunk_ptr, csr->rel_total, D, g_P);
+    GNNRAG_LAUNCH_CHECK();
+  }
   return 0;
 }
 

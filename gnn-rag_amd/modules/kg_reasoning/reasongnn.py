@@ -21,7 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ...autograd import AggregateFn, linear as ag_linear
+from ...autograd import AggregateFn, FusedAggregateFn, linear as ag_linear, relation_tables_dense
 from .base_gnn import BaseGNNLayer
 
 VERY_NEG_NUMBER = -100000000000
@@ -68,6 +68,8 @@ class ReasonGNNLayer(BaseGNNLayer):
         self.pad_dim = os.environ.get("GNNRAG_PAD_DIM", "1") != "0"
         # training: dense projections on the library's kernels forward and backward (0: nn.Linear / rocBLAS)
         self.native_dense = os.environ.get("GNNRAG_NATIVE_DENSE", "1") != "0"
+        # training without active dropout: the fused form (relation tables + fused walk with its own backward)
+        self.train_fused = os.environ.get("GNNRAG_TRAIN_FUSED", "1") != "0"
         self._padded = None
 
     def init_layers(self, args):
@@ -252,6 +254,23 @@ class ReasonGNNLayer(BaseGNNLayer):
             pad = T_fwd.new_zeros(T_fwd.size(0) - pos.size(0), D)      # relation rows without a pos_emb row
             T_fwd = T_fwd + torch.cat([pos, pad], dim=0)
             T_inv = T_inv + torch.cat([pos_inv, pad], dim=0)
+        # Training on the FUSED form (round 4): without dropout between the aggregation and e2e_linear
+        # (reasongnn.py:161-163; dropout acts on cat(h, agg) elementwise and cannot be pushed through the
+        # re-association) the neighbour part is e2e_linear's column blocks applied to per-question relation tables
+        # (a dense, differentiable expression over a few ten thousand rows) and the fused walk with its own backward:
+        # agg [BN, 2I D] and the K = 2I D product never exist.  GNNRAG_TRAIN_FUSED=0 keeps the unfused autograd form.
+        drop_active = self.training and self.linear_dropout > 0
+        if native and self.train_fused and not drop_active and self.plan.rel_total > 0:
+            W = e2e_linear.weight
+            P = relation_tables_dense(self.plan, T_fwd, T_inv, relational_ins.float(), W)
+            nbr = FusedAggregateFn.apply(self.plan, current_dist.float(), P)
+            pre = ag_linear(self.local_entity_emb.float().reshape(B * N, D), W[:, :D], e2e_linear.bias) + nbr
+            self.local_entity_emb = F.relu(pre).view(B, N, D)
+            mask = self.local_entity_mask
+            self.possible_cand.append(mask)
+            score = self.score_func(self.local_entity_emb).squeeze(dim=2) + (1 - mask) * VERY_NEG_NUMBER
+            new_dist = self.softmax_d1(score)
+            return (score, new_dist) if return_score else (new_dist, self.local_entity_emb)
         agg = AggregateFn.apply(self.plan, current_dist.float(), relational_ins.float(), T_fwd, T_inv)
         if native:
             # e2e_linear over cat(h, agg) as two products (no [BN, (2I+1)D] copy of the concatenation): dropout acts

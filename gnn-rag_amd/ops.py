@@ -292,6 +292,14 @@ class CsrPlan:
         self._attach("w_rel", weight_rel_list, False)
 
     # -- debug / test views --------------------------------------------------------------------
+    def rel_rows_device(self) -> torch.Tensor:
+        """[rel_total, 2] int32 (question, relation id) of every compact relation row, a view of the structure's own
+        device memory (the differentiable relation tables of training index T and the instructions with it)."""
+        if self.rel_total == 0:
+            return torch.zeros((0, 2), dtype=torch.int32, device=self.device)
+        off = int(C.cast(self.c.rel_rows, C.c_void_p).value) - self._mem.data_ptr()
+        return self._mem[off: off + 8 * self.rel_total].view(torch.int32).view(-1, 2)
+
     def _view(self, addr: int, n: int, dtype):
         if n == 0:
             return torch.zeros(0, dtype=dtype)
@@ -675,6 +683,26 @@ def aggregate_backward(plan: CsrPlan, dist, ins, T_fwd, T_inv, g_agg, gather: bo
             g_dist.data_ptr(), g_ins.data_ptr(), g_Tf.data_ptr(), g_Ti.data_ptr(), D, I, ws.data_ptr(), ws.numel(),
             _stream()), "gnnrag_aggregate_backward")
     return g_dist, g_ins, g_Tf, g_Ti
+
+
+def aggregate_fused_backward(plan: CsrPlan, dist, P, g_nbr):
+    """Gradients of ``aggregate_fused`` with respect to (dist, P): g_dist [BN], g_P [2, rel_total, D]."""
+    lib = _lib.load()
+    P = _chk(P, "P")
+    D = P.shape[-1]
+    if tuple(P.shape) != (2, plan.rel_total, D) or D % 4:
+        raise ValueError("P must be [2, plan.rel_total, D] with D % 4 == 0")
+    dist = _chk(dist, "dist").reshape(-1)
+    g_nbr = _chk(g_nbr, "g_nbr", shape=(plan.B * plan.N, D))
+    g_dist = torch.empty(plan.B * plan.N, dtype=torch.float32, device=dist.device)
+    g_P = torch.zeros_like(P) if plan.rel_total == 0 else torch.empty_like(P)
+    ro = plan.relorder()
+    ws = plan.backward_workspace(D, 1, ro)
+    with torch.cuda.device(dist.device):
+        _lib.check(lib.gnnrag_aggregate_fused_backward(
+            C.byref(plan.c), C.byref(ro), dist.data_ptr(), P.data_ptr(), g_nbr.data_ptr(), g_dist.data_ptr(),
+            g_P.data_ptr(), D, ws.data_ptr(), ws.numel(), _stream()), "gnnrag_aggregate_fused_backward")
+    return g_dist, g_P
 
 
 def typelayer_backward(plan: CsrPlan, g_pre: torch.Tensor, use_w_rel: bool, gather: bool = True) -> torch.Tensor:

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GNNRAG_ABI_VERSION 12
+#define GNNRAG_ABI_VERSION 13
 
 #define GNNRAG_E_BADARG      (-1)  /* null pointer / negative size / inconsistent sizes   */
 #define GNNRAG_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set (see DESIGN)  */
@@ -266,6 +266,18 @@ int gnnrag_aggregate_backward(const gnnrag_csr* csr, const gnnrag_relorder* relo
                               float* g_dist, float* g_ins, float* g_T_fwd, float* g_T_inv,
                               int32_t D, int32_t I, void* workspace, size_t workspace_bytes,
                               gnnrag_stream_t stream);
+
+/* Backward of gnnrag_aggregate_fused (training on the fused form, linear_dropout = 0):
+ *   nbr[n, :] = sum_d sum_{f: dst_d(f)=n} w_f * dist[src_d(f)] * P[d, row(b, rel_f), :]
+ *   g_dist[s]        = sum_d sum_{f: src_d(f)=s} w_f * < g_nbr[dst_d(f), :], P[d, row(b, rel_f), :] >
+ *   g_P[d, row, :]   = sum_{f in row} w_f * dist[src_d(f)] * g_nbr[dst_d(f), :]
+ * both fully written; the relation tables P themselves are a differentiable dense expression of a few ten thousand
+ * rows on the caller's side (gnn-rag_amd/autograd.py: relation_tables_dense).  Needs the (question, relation) ordering
+ * (gnnrag_relorder) and D % 4 == 0; gather kernels, chunk partials summed in a fixed order, no atomics.
+ * workspace: gnnrag_backward_workspace_bytes(csr, relorder, D, 1). */
+int gnnrag_aggregate_fused_backward(const gnnrag_csr* csr, const gnnrag_relorder* relorder, const float* dist,
+                                    const float* P, const float* g_nbr, float* g_dist, float* g_P, int32_t D,
+                                    void* workspace, size_t workspace_bytes, gnnrag_stream_t stream);
 
 /* Backward of gnnrag_typelayer with respect to T (layer_init.py:47-57):
  *   g_T[r,:] = sum_{f: rel_f=r} v_f (g_pre[tail_f,:] + g_pre[head_f,:]),

@@ -120,14 +120,86 @@ def test_empty_batch_backward(dev):
     assert not ops.typelayer_backward(plan, torch.randn(16, D, device=dev), False).cpu().numpy().any()
 
 
+@pytest.mark.parametrize("name", ["tiny", "tinyfb", "hub", "huge", "wide", "norm"])
+def test_fused_walk_backward_vs_f64(dev, name):
+    """gnnrag_aggregate_fused_backward (training on the fused form): g_dist and g_P against float64 sums over the caller's
+    fact tuple - light rows, rows of more than 256 and more than 4096 facts, a Freebase-sized vocabulary with few
+    relations per question, D > 256, normalized_gnn weights (applied twice, as the forward does); the forward value
+    against the same sums; two runs bit-identical (gather kernels, fixed order)."""
+    from gnnrag_amd import ops, synth
+    cfg = (synth.GraphConfig(name="norm", B=2, N=60, E=300, R=9, D=64, I=2, L=1, seed=8, normalized_gnn=True)
+           if name == "norm" else _cfg(name))
+    batch = synth.make_batch(cfg)
+    B, N, D = cfg.B, cfg.N, cfg.D
+    et = batch.edge_tuple
+    h, r, t = (np.asarray(et[k]).astype(np.int64) for k in range(3))
+    plan = ops.CsrPlan(h, r, t, B, N, cfg.R1, dev)
+    w = np.ones(len(h))
+    if cfg.normalized_gnn:
+        plan.attach_w_gnn(et[5])
+        w = np.asarray(et[5], dtype=np.float64) ** 2                  # reasongnn.py:80,84: the weight enters twice
+    rows = plan.to_host()["rel_rows"].astype(np.int64)
+    key = rows[:, 0] * (cfg.R1 + 1) + rows[:, 1]
+    row_of = np.searchsorted(key, (h // N) * (cfg.R1 + 1) + r)
+    assert (key[row_of] == (h // N) * (cfg.R1 + 1) + r).all()
+    rng = np.random.default_rng(23)
+    dist = rng.random((B, N)).astype(np.float32)
+    dist[:, ::5] = 0.0
+    P = (0.3 * rng.standard_normal((2, plan.rel_total, D))).astype(np.float32)
+    g = rng.standard_normal((B * N, D)).astype(np.float32)
+    d64, P64, g64 = dist.reshape(-1).astype(np.float64), P.astype(np.float64), g.astype(np.float64)
+    want_nbr = np.zeros((B * N, D))
+    np.add.at(want_nbr, t, (w * d64[h])[:, None] * P64[0][row_of])
+    np.add.at(want_nbr, h, (w * d64[t])[:, None] * P64[1][row_of])
+    want_gd = np.zeros(B * N)
+    np.add.at(want_gd, h, w * np.einsum("fd,fd->f", g64[t], P64[0][row_of]))
+    np.add.at(want_gd, t, w * np.einsum("fd,fd->f", g64[h], P64[1][row_of]))
+    want_gP = np.zeros_like(P64)
+    np.add.at(want_gP[0], row_of, (w * d64[h])[:, None] * g64[t])
+    np.add.at(want_gP[1], row_of, (w * d64[t])[:, None] * g64[h])
+    d_dist, d_P, d_g = _dev(dev, dist, P, g)
+    _close(ops.aggregate_fused(plan, d_dist, d_P).cpu().numpy(), want_nbr, TOL_KERNEL, "nbr")
+    got_gd, got_gP = ops.aggregate_fused_backward(plan, d_dist, d_P, d_g)
+    _close(got_gd.cpu().numpy(), want_gd, TOL_KERNEL, "g_dist")
+    _close(got_gP.cpu().numpy(), want_gP, TOL_KERNEL, "g_P")
+    again = ops.aggregate_fused_backward(plan, d_dist, d_P, d_g)
+    assert torch.equal(got_gd, again[0]) and torch.equal(got_gP, again[1])
+
+
+def test_dense_relation_tables_match_the_kernel(dev):
+    """autograd.relation_tables_dense (the differentiable torch expression training uses) computes what
+    gnnrag_relation_tables computes (exact-fp32 mode), rows in the structure's compact order."""
+    from gnnrag_amd import ops, synth
+    from gnnrag_amd.autograd import relation_tables_dense
+    cfg = _cfg("tinyfb")
+    batch = synth.make_batch(cfg)
+    et = batch.edge_tuple
+    plan = ops.CsrPlan(et[0], et[1], et[2], cfg.B, cfg.N, cfg.R1, dev)
+    g = torch.Generator().manual_seed(3)
+    r = lambda *sh: (0.4 * torch.randn(*sh, generator=g)).to(dev)
+    Tf, Ti, ins, W = r(cfg.R1, cfg.D), r(cfg.R1, cfg.D), r(cfg.B, cfg.I, cfg.D), r(cfg.D, (2 * cfg.I + 1) * cfg.D)
+    old = ops.set_dense_math(ops.MATH_FP32)
+    try:
+        want = ops.relation_tables(plan, Tf, Ti, ins, W)
+    finally:
+        ops.set_dense_math(old)
+    got = relation_tables_dense(plan, Tf, Ti, ins, W)
+    _close(got.cpu().numpy(), want.cpu().numpy(), TOL_KERNEL, "P")
+
+
+@pytest.mark.parametrize("form", ["fused", "unfused"])
 @pytest.mark.parametrize("name", ["layer_d200.npz", "layer_d50.npz"])
-def test_module_gradients_match_reference_fixture(dev, name):
+def test_module_gradients_match_reference_fixture(dev, name, form):
     """Our ReasonGNNLayer with autograd enabled: same loss as tests/golden/make_golden_grad.py, gradients
-    of every parameter and input against what autograd gave through the live reference module."""
+    of every parameter and input against what autograd gave through the live reference module - on the fused training
+    form and on the unfused one."""
     from gnnrag_amd import stack
     cfg, batch, feats, params, ref = load_golden(name)
     z = np.load(os.path.join(GOLDEN, "grad_" + name))
     layer = stack.build_layer(cfg, batch, params, dev).train()
+    # "fused": relation tables + fused walk with its own backward (the default without active dropout, hidden sizes that
+    # are a multiple of 4 - layer_d50 falls back to the unfused form by itself); "unfused": AggregateFn as in round 2
+    layer.train_fused = form == "fused"
     inp = {k: torch.tensor(feats[k], device=dev, requires_grad=True)
            for k in ("h0", "rel_features", "rel_features_inv", "ins")}
     layer.init_reason(local_entity=torch.from_numpy(batch.local_entity).to(dev), kb_adj_mat=batch.edge_tuple,

@@ -49,6 +49,10 @@ def main():
             res["aggregate_%s_ms" % nm] = ev_ms(lambda: ops.aggregate(plan, prior, devin.ins[0], Tf, Ti))
             res["aggregate_backward_%s_ms" % nm] = ev_ms(
                 lambda: ops.aggregate_backward(plan, prior, devin.ins[0], Tf, Ti, g))
+        P = ops.relation_tables(plan, Tf, Ti, devin.ins[0], layer.e2e_linear0.weight)
+        gn = torch.randn(B * N, D, device=dev)
+        res["aggregate_fused_dense_ms"] = ev_ms(lambda: ops.aggregate_fused(plan, dense, P))
+        res["aggregate_fused_backward_dense_ms"] = ev_ms(lambda: ops.aggregate_fused_backward(plan, dense, P, gn))
     layer.train()
 
     def step():
@@ -60,7 +64,9 @@ def main():
         (d * d).sum().backward()
 
     with torch.enable_grad():
-        res["train_fwd_bwd_%d_layers_ms" % cfg.L] = ev_ms(step, 5)
+        for form in ("fused", "unfused"):
+            layer.train_fused = form == "fused"
+            res["train_fwd_bwd_%d_layers_%s_ms" % (cfg.L, form)] = ev_ms(step, 5)
     with torch.no_grad():
         layer.eval()
 
