@@ -348,6 +348,9 @@ constexpr int kVqRowB = 2 * kVqHalf * 2;       // bytes per plane row: [relu(T) 
 #ifndef GNNRAG_VQ_UN
 #define GNNRAG_VQ_UN 3
 #endif
+#ifndef GNNRAG_VQ_ORDER
+#define GNNRAG_VQ_ORDER 0       // 1: column-tile pairs outer, row tiles inner (V fragments read once per k block and pair)
+#endif
 constexpr int kVqTPW = GNNRAG_VQ_TPW;          // row tiles per wave and pass
 
 struct VqArgs {
@@ -476,6 +479,47 @@ __device__ __forceinline__ void tables_vq_part(const VqArgs& a, unsigned char* l
         for (int pl = 0; pl < 3; ++pl)
           ap[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(planes + pl * plane_stride + aoff[j] +
                                                                                  s * (kVqHalf * 2)));
+#if GNNRAG_VQ_ORDER == 1
+      // Round 4 experiment: column-tile pairs OUTER, row tiles INNER - a pair's six V fragments are read from LDS once and
+      // multiplied against all of the wave's row tiles (5 x fewer ds_read_b128: 24 instead of 120 per k block); a tile's A
+      // fragments of the next k block are requested right after its last products of this one, i.e. ~48 MFMAs ahead
+      for (int kb = 0; kb < NKB; ++kb) {
+        const int kbn = min(kb + 1, NKB - 1);
+        const unsigned char* wb = lds + fr * RB + kb * 64 + fg * 16;
+        constexpr int PA[6] = {1, 2, 0, 1, 0, 0};
+        constexpr int PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+        for (int nt = 0; nt < CTN; nt += 2) {
+          bf16x8 b0[3], b1[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            b0[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + nt * 16 * RB));
+            b1[pl] = b0[pl];
+            if (nt + 1 < CTN)
+              b1[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + (nt + 1) * 16 * RB));
+          }
+#pragma unroll
+          for (int j = 0; j < kVqTPW; ++j) {
+            if (j < ntile) {                                  // wave-uniform
+#pragma unroll
+              for (int p = 0; p < 6; ++p) {
+                acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[j][PA[p]], b0[PB[p]], acc[j][nt], 0, 0, 0);
+                if (nt + 1 < CTN)
+                  acc[j][nt + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[j][PA[p]], b1[PB[p]], acc[j][nt + 1], 0, 0, 0);
+              }
+            }
+            if (nt + 2 >= CTN) {                              // the k block's last pair: this tile's fragments of the next one
+#pragma unroll
+              for (int pl = 0; pl < 3; ++pl)
+                ap[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(planes + pl * plane_stride + aoff[j] +
+                                                                                       s * (kVqHalf * 2) + kbn * 64));
+            }
+          }
+        }
+      }
+    }
+
+#else
       for (int kb = 0; kb < NKB; ++kb) {        // (not unrolled: register pressure)
         const int kbn = min(kb + 1, NKB - 1);   // (the last block requests itself again: no branch around a load)
         const unsigned char* wb = lds + fr * RB + kb * 64 + fg * 16;
@@ -517,6 +561,7 @@ __device__ __forceinline__ void tables_vq_part(const VqArgs& a, unsigned char* l
       }
     }
 
+#endif
     // ---- epilogue: the pass's tiles leave the registers (C layout: rows 4 fg + q, column slot fr) ----
 #pragma unroll
     for (int j = 0; j < kVqTPW; ++j) {

@@ -219,6 +219,8 @@ def make_checkpoint(variant="d50"):
     from train_model import Trainer_KBQA
     from utils import create_logger
     trainer = Trainer_KBQA(args=vars(args), model_name=args.model_name, logger=create_logger(args))
+    if os.environ.get("GNNRAG_STAGE_RESUME") == "1":           # more epochs on the checkpoint already staged
+        trainer.load_ckpt(os.path.join(CKPT, ckpt_name(variant)))
     for epoch in range(int(os.environ.get("GNNRAG_STAGE_EPOCHS") or VARIANTS[variant]["epochs"])):
         sched = VARIANTS[variant].get("lr_by_epoch")
         if sched and not os.environ.get("GNNRAG_STAGE_LR"):
