@@ -287,7 +287,8 @@ def main():
     csr_cached_ms, csr_concat_ms = (cached_structure_ms(batch, dev, ops)
                                     if rank == 0 and not os.environ.get("BENCH_SKIP_STRUCTURE_TIMING") else (None, None))
     overlapped = None
-    if rank == 0 and graph is None and not strong and not os.environ.get("BENCH_SKIP_STRUCTURE_TIMING"):
+    # (single process only: `step` enqueues the ranks' all-gather when a process group is up - rank 0 alone must not call it)
+    if rank == 0 and not distributed and graph is None and not strong and not os.environ.get("BENCH_SKIP_STRUCTURE_TIMING"):
         try:
             overlapped = overlapped_build_ms(batch, dev, step, 48)
         except Exception as e:                       # never fail the bench on the side measurement
