@@ -804,14 +804,13 @@ def e2e_leg():
     import stage_ref
     if not stage_ref.staged():
         return {"skipped": "oracle/_ref not staged (python oracle/stage_ref.py in the build container)"}
-    sample = os.path.join(stage_ref.DST, "data", "synth_sample") + "/"
     ncpu = os.cpu_count() or 1
     cpu_threads = min(32, ncpu)
 
     def run(variant, pure, batch, data=None, extra_env=None):
         argv = list(stage_ref.variant_argv(variant))
-        if data:
-            argv = [data if a == stage_ref.DATA else a for a in argv]
+        if data:                                       # the variant's bounded sample (first 32 test questions)
+            argv = [stage_ref.sample_folder(variant) if a == stage_ref.data_folder(variant) else a for a in argv]
         i = argv.index("--test_batch_size")
         argv[i + 1] = str(batch)
         ck = tempfile.mkdtemp(prefix="gnnrag_e2e_") + "/"
@@ -847,8 +846,9 @@ def e2e_leg():
                 "test_f1_h1": [float(x) for x in h1[-1]] if h1 else None, "process_wall_s": wall,
                 "threads": T.get("threads") if pure else None}
 
-    out = {"entry": "unmodified gnn/main.py --is_eval via tools/run_reference.py; staged synthetic dataset (oracle/stage_ref.py: "
-                    "a relation path from the seed determines the answer; 520 test questions, subgraphs up to 2000 entities)",
+    out = {"entry": "unmodified gnn/main.py --is_eval via tools/run_reference.py; staged synthetic datasets (oracle/stage_ref.py: "
+                    "a relation path from the seed determines the answer; 520 test questions, subgraphs up to 2000 entities; 24 "
+                    "relation types for d50, 12 for d200)",
            "host_cores": ncpu}
     out["d200_batch16"] = {"gpu": run("d200", False, 16),
                            # the next batch's tuple + structure built by a worker thread on a side stream (StructurePrefetcher)
@@ -856,10 +856,10 @@ def e2e_leg():
                            # + the question encoder's nn.LSTM off MIOpen (GNNRAG_MIOPEN_RNN=0: MIOpen's RNN call is ~12 ms
                            # at these shapes, half of a batch's forward; the encoder is the reference's, a backend switch)
                            "gpu_prefetch_native_lstm": run("d200", False, 16, extra_env={"GNNRAG_PREFETCH": "1", "GNNRAG_MIOPEN_RNN": "0"}),
-                           "cpu_reference_sample32": run("d200", True, 16, sample)}
+                           "cpu_reference_sample32": run("d200", True, 16, True)}
     out["c1_d50_batch1"] = {"gpu": run("d50", False, 1),
                             "gpu_native_lstm": run("d50", False, 1, extra_env={"GNNRAG_MIOPEN_RNN": "0"}),
-                            "cpu_reference_sample32": run("d50", True, 1, sample)}
+                            "cpu_reference_sample32": run("d50", True, 1, True)}
     for k in ("d200_batch16", "c1_d50_batch1"):
         g, c = out[k]["gpu"], out[k]["cpu_reference_sample32"]
         if "questions_per_s" in g and "questions_per_s" in c:
