@@ -336,6 +336,9 @@ constexpr int kVqRowB = 2 * kVqHalf * 2;       // bytes per plane row: [relu(T) 
 #ifndef GNNRAG_UPD_ABL
 #define GNNRAG_UPD_ABL 0         // timing-only ablations of k_update_b3: 1 no LDS reads, 2 no A refills, 4 no nbr
 #endif                           // loads, 8 no stores, 16 no 3-way split
+#ifndef GNNRAG_UPD_BALANCE
+#define GNNRAG_UPD_BALANCE 0     // k_update_b3: row chunks of the two column parts balanced 7 : 6 (measured slower: DESIGN A.7; 0: equal chunks)
+#endif
 #ifndef GNNRAG_UPD_PRIO
 #define GNNRAG_UPD_PRIO 0        // k_update_b3: s_setprio level around every k block's MFMA section (experiment)
 #endif
@@ -843,14 +846,26 @@ __device__ __forceinline__ void update_b3_part(const UpdB3Args& a, unsigned char
 }
 
 template <bool FL>
-__global__ __launch_bounds__(512, 2) void k_update_b3(UpdB3Args a, int nchunks) {
+__global__ __launch_bounds__(512, 2) void k_update_b3(UpdB3Args a, int nchunks, int nchunks1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  // the two parts of a row chunk are neighbours in the grid AND on one XCD (blocks b and b + 8): block = 16*(c/8) + 8*h + c%8
   const int blk = blockIdx.x;
+  const int NT = (a.D + 15) >> 4;
+  if (nchunks1 > 0) {
+    // Round 4: the 7-tile column part costs 7/6 of the 6-tile part per row, so the parts get DIFFERENT row chunkings -
+    // nchunks workgroups for part 0, nchunks1 for part 1, in the ratio 7 : 6 (136 + 120 on 256 CUs: 412 / 400 tile-units
+    // per CU where equal chunks gave 437 / 375).  XCD x (= blk % 8) runs slots blk / 8: its first nchunks / 8 slots are the
+    // x-th eighth of part 0's chunks, the rest the x-th eighth of part 1's - both reads of a row of h stay in one XCD.
+    const int x = blk & 7, slot = blk >> 3;
+    const int p0 = nchunks >> 3, p1 = nchunks1 >> 3;
+    if (slot < p0) update_b3_part<kTabNTH, FL>(a, lds, 0, true, x * p0 + slot, nchunks);
+    else if (slot < p0 + p1 && NT - a.ct0 == 6) update_b3_part<6, FL>(a, lds, a.ct0 * 16, false, x * p1 + (slot - p0), nchunks1);
+    return;
+  }
+  // equal chunks: the two parts of a row chunk are neighbours in the grid AND on one XCD (blocks b and b + 8):
+  // block = 16*(c/8) + 8*h + c%8
   const int h = (blk >> 3) & 1;
   const int chunk = (blk >> 4) * 8 + (blk & 7);
   if (chunk >= nchunks) return;
-  const int NT = (a.D + 15) >> 4;
   if (h == 0) update_b3_part<kTabNTH, FL>(a, lds, 0, true, chunk, nchunks);
   else if (NT - a.ct0 == 6) update_b3_part<6, FL>(a, lds, a.ct0 * 16, false, chunk, nchunks);
 }
@@ -1140,8 +1155,32 @@ int update_b3_launch_f(const float* h, const float* nbr, const uint8_t* add_flag
   if (add_flag) hipLaunchKernelGGL((k_update_b3w<true, GNNRAG_UPD_WAVES>), dim3(nblk), dim3(64 * GNNRAG_UPD_WAVES), 160 * 1024, stream, a, chunks);
   else hipLaunchKernelGGL((k_update_b3w<false, GNNRAG_UPD_WAVES>), dim3(nblk), dim3(64 * GNNRAG_UPD_WAVES), 160 * 1024, stream, a, chunks);
 #else
-  if (add_flag) hipLaunchKernelGGL(k_update_b3<true>, dim3(nblk), dim3(512), 160 * 1024, stream, a, chunks);
-  else hipLaunchKernelGGL(k_update_b3<false>, dim3(nblk), dim3(512), 160 * 1024, stream, a, chunks);
+  // 7 : 6 chunk counts for the two column parts (one workgroup per CU, both counts whole XCD eighths, >= 4 tiles per wave)
+  int n0 = chunks, n1 = 0, grid = nblk;
+#if GNNRAG_UPD_BALANCE
+  if (cus >= 64 && cus % 8 == 0 && U >= (long long)cus * 16) {
+    // waves own whole tiles, so what counts is the LARGEST tile count of a wave in each part: pick the split (in whole XCD
+    // eighths) with the smallest max(ceil(ceil(U / c0) / 8) * 7, ceil(ceil(U / c1) / 8) * 6), nearest to 7 : 6 among equals
+    // (C2, 8000 tiles on 256 CUs: 144 + 112 -> 7 tiles x 7 and 9 tiles x 6 = 54 units where equal chunks need 8 x 7 = 56)
+    long long best_cost = -1, best_skew = 0;
+    for (int c0 = 8; c0 + 8 <= cus; c0 += 8) {
+      const int c1 = cus - c0;
+      const long long t0 = ((U + c0 - 1) / c0 + 7) / 8 * 7, t1 = ((U + c1 - 1) / c1 + 7) / 8 * 6;
+      const long long cost = t0 > t1 ? t0 : t1;
+      long long skew = (long long)c0 * 6 - (long long)c1 * 7;
+      if (skew < 0) skew = -skew;
+      if (best_cost < 0 || cost < best_cost || (cost == best_cost && skew < best_skew)) {
+        best_cost = cost;
+        best_skew = skew;
+        n0 = c0;
+        n1 = c1;
+      }
+    }
+    if (n1 > 0) grid = cus;
+  }
+#endif
+  if (add_flag) hipLaunchKernelGGL(k_update_b3<true>, dim3(grid), dim3(512), 160 * 1024, stream, a, n0, n1);
+  else hipLaunchKernelGGL(k_update_b3<false>, dim3(grid), dim3(512), 160 * 1024, stream, a, n0, n1);
 #endif
   GNNRAG_LAUNCH_CHECK();
   return 0;

@@ -67,6 +67,30 @@ def test_self_block_update_large_m_every_hidden_size_vs_fp64(dev, M, D, math):
     assert (got_s[~live] == np.float32(-1e11)).all()                  # fp32 add rounds to exactly -1e11
 
 
+@pytest.mark.parametrize("M", [70001, 131072 + 17])
+def test_self_block_update_very_large_ragged_rows_vs_fp64(dev, M):
+    """k_update_b3 at row counts beyond 65 536 that are not a multiple of 16 or of the chunk count (round 4; also the shape
+    class of the 7 : 6 chunking experiment, GNNRAG_UPD_BALANCE): every row and every score against float64, masked scores
+    exactly -1e11, two runs bit-identical."""
+    from gnnrag_amd import ops
+    D, I = 200, 2
+    g = torch.Generator(device="cpu").manual_seed(M)
+    r = lambda *shape: torch.randn(*shape, generator=g)
+    h, nbr, W, b, ws, bs = r(M, D), r(M, D), r(D, (2 * I + 1) * D) / np.sqrt(D), r(D), r(D), r(1)
+    mask = (torch.rand(M, generator=g) > 0.1).float()
+    args = (h.to(dev), nbr.to(dev), W.to(dev), b.to(dev), ws.to(dev), bs.to(dev), mask.to(dev), I)
+    h_out, score = ops.update_score_fused(*args, math=ops.MATH_MIXED)
+    want = np.maximum(h.double().numpy() @ W[:, :D].double().numpy().T + b.double().numpy() + nbr.double().numpy(), 0.0)
+    want_s = want @ ws.double().numpy() + float(bs)
+    got, got_s = h_out.cpu().numpy(), score.cpu().numpy()
+    assert np.abs(got - want).max() <= TOL_INTERNAL * max(1.0, np.abs(want).max())
+    live = mask.numpy() > 0
+    assert np.abs(got_s[live] - want_s[live]).max() <= TOL_STATED * max(1.0, np.abs(want_s[live]).max())
+    assert (got_s[~live] == np.float32(-1e11)).all()
+    h2, s2 = ops.update_score_fused(*args, math=ops.MATH_MIXED)
+    assert torch.equal(h_out, h2) and torch.equal(score, s2)
+
+
 @pytest.mark.parametrize("math", ["mixed", "fp32"])
 def test_c3_shape_released_checkpoint_dims(dev, math):
     """BASELINE config C3 per GPU: 32 WebQSP-shaped ragged questions, released-checkpoint dims (entity_dim 50, 2

@@ -62,6 +62,7 @@ VARIANTS = {
     # with these environment variables)
     "wr_on": {"__env__": {"GNNRAG_UPDATE_WR": "1"}},
     # k_update_b3 with the second wave of every SIMD started ~1/4, 1/2, 1 tile late (phase-locking experiment)
+    "upd_balanced": {"GNNRAG_UPD_BALANCE": 1},         # k_update_b3 with 7 : 6 row chunks for its two column parts (slower)
     "vq_order1": {"GNNRAG_VQ_ORDER": 1},     # k_tables_vq: V fragments shared by the wave's row tiles
     "prio2": {"GNNRAG_UPD_PRIO": 2}, "prio2_desync80": {"GNNRAG_UPD_PRIO": 2, "GNNRAG_UPD_DESYNC": 80},
     "desync40": {"GNNRAG_UPD_DESYNC": 40}, "desync80": {"GNNRAG_UPD_DESYNC": 80}, "desync160": {"GNNRAG_UPD_DESYNC": 160},
