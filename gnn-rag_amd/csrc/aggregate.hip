@@ -451,6 +451,194 @@ __global__ __launch_bounds__(256) void k_walk_light(const WalkArgs a) {
 }
 
 // ---- heavy rows, pass 1: one wave per 256-fact chunk -> partial sums --------------------------
+// ---- light rows, FOUR facts per step (FUSED gather walk, 128 < D <= 256, D % 4 == 0; round 4) ------------
+// k_walk_light handles one fact per step: (p, rel) go to scalar registers, the 64 lanes cover the D columns.  At
+// BASELINE config 5 that is ~12 vector and ~15 scalar instructions per fact of which two multiply - with the table
+// loads and the stores ablated, the dense-prior launch still costs 160 us more than the seed-prior one: instruction
+// issue, not memory, is what the kernel is bound by beside its gathers.  Here a wave handles four facts per step: its
+// four 16-lane groups take one fact each, a lane covers the columns 64 c + 4 l (c = 0..NCH-1, l = lane % 16) of its
+// group's fact with NCH 16-byte loads from  question table + (rel * 4 D + its column bytes)  - one 24-bit multiply per
+// step, no scalar work per fact - and keeps NCH float4 partial sums; per node (both directions) the four groups' partial
+// sums are reduced so that group g ends with column piece g (gfx950 v_permlane32_swap / v_permlane16_swap: a swap and an
+// add per register) and stores it.  A fact's 800-byte row is still read as whole 256-byte pieces.
+// Sum order: facts g, g + 4, g + 8, ... of a row in fact order per group, then (g0 + g2) + (g1 + g3): fixed.
+// A zero-prior fact multiplies its table row by 0 here (k_walk_light skips it): the reference's own 0 x value.
+#ifndef GNNRAG_LIGHT_QUAD
+#define GNNRAG_LIGHT_QUAD 1       // 0: k_walk_light for every shape
+#endif
+#ifndef GNNRAG_QUAD_MERGED
+#define GNNRAG_QUAD_MERGED 1      // both directions of a node as one run of the merged record stream
+#endif
+#ifndef GNNRAG_QUAD_STEPS
+#define GNNRAG_QUAD_STEPS 2       // steps (4 facts each) whose table-row loads are in flight together
+#endif
+// MG: the node's facts of both directions are one run of the merged record stream (gnnrag_csr::edge_m: direction 1's
+// relation index offset by the question's relation count + 1): one record batch and one prior gather per node
+// instead of two, and no half-empty step per direction (a node has ~10 forward and ~2 light inverse facts at config 5).
+template <int NCH, bool MG>
+__global__ __launch_bounds__(256) void k_walk_light_q(const WalkArgs a) {
+  constexpr int NPW = GNNRAG_LIGHT_NPW;
+  constexpr int S = GNNRAG_QUAD_STEPS;
+  constexpr int ND = MG ? 1 : 2;        // record runs per node
+  int blk = blockIdx.x;
+  if (a.bpg > 0) {                      // questions pinned to XCDs: see k_walk_light
+    const int xcd = blk & 7, slot = blk >> 3;
+    const int g = (slot / a.bpg) * 8 + xcd;
+    if (g >= a.B) return;
+    blk = g * a.bpg + slot % a.bpg;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = lane >> 4, l = lane & 15;
+  const int D = a.D;
+  const unsigned D4 = (unsigned)D * 4u;
+  unsigned cb[NCH];                     // byte offset of this lane's piece c inside a table row (clamped: loads need no mask)
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) cb[c] = 4u * (unsigned)min(64 * c + 4 * l, D - 4);
+  // structure first, as in k_walk_light: row bounds of all NPW nodes, then their first record batches, then the priors
+  int nn[NPW], beg[NPW][ND], len[NPW][ND];
+  bool live[NPW];
+#pragma unroll
+  for (int t = 0; t < NPW; ++t) {
+    int n = (blk * NPW + t) * 4 + wave;
+    live[t] = n < a.BN;
+    if (!live[t]) n = a.BN - 1;
+    nn[t] = n;
+    int rb[2], rl[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      rb[d] = a.row_ptr[d][n];
+      rl[d] = a.row_ptr[d][n + 1] - rb[d];
+    }
+    if constexpr (MG) {
+      // merged run = direction 0's facts, then direction 1's; a hub row's part is left to the hub kernels
+      const int lo = rl[0] > a.heavy_deg ? rl[0] : 0;
+      const int hi = rl[0] + (rl[1] > a.heavy_deg ? 0 : rl[1]);
+      beg[t][0] = rb[0] + rb[1] + lo;
+      len[t][0] = live[t] ? hi - lo : 0;
+    } else {
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        beg[t][d] = rb[d];
+        len[t][d] = (!live[t] || rl[d] > a.heavy_deg) ? 0 : rl[d];
+      }
+    }
+  }
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  i32x2 e0[NPW][ND];
+  float p0[NPW][ND];
+#pragma unroll
+  for (int t = 0; t < NPW; ++t)
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+      const int idx = lane < len[t][d] ? beg[t][d] + lane : 0;         // record 0 exists in every structure
+      e0[t][d] = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(MG ? a.edge_m : a.edge[d]) + idx);
+    }
+#pragma unroll
+  for (int t = 0; t < NPW; ++t)
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+      const bool fv = lane < len[t][d];
+      float p = a.dist[fv ? e0[t][d].x : 0];
+      if (!MG && a.w[d]) p *= __builtin_nontemporal_load(a.w[d] + (fv ? beg[t][d] + lane : 0));
+      p0[t][d] = fv ? p : 0.f;
+    }
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const unsigned dir1 = MG ? (unsigned)((const char*)a.T[1] - (const char*)a.T[0]) : 0u;   // (checked on the host: fits)
+#pragma unroll
+  for (int t = 0; t < NPW; ++t) {
+    const int n = nn[t];
+    const int b = n / a.N;
+    const int Rq = MG ? a.rel_off[b + 1] - a.rel_off[b] : 0;
+    f32x4 acc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc[c] = zero4;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+      const char* T = reinterpret_cast<const char*>(table_of(a, MODE_FUSED, d, b));
+      const int rowlen = __builtin_amdgcn_readfirstlane(len[t][d]);
+      for (int base = 0; base < rowlen; base += 64) {
+        float p = p0[t][d];
+        int r = e0[t][d].y;
+        if (base > 0) {
+          if constexpr (MG) load_fact<MODE_FUSED>(a.edge_m, nullptr, a.dist, beg[t][d], base + lane, rowlen, p, r);
+          else load_fact<MODE_FUSED>(a.edge[d], a.w[d], a.dist, beg[t][d], base + lane, rowlen, p, r);
+        }
+        const int cnt = min(64, rowlen - base);
+        // byte offset of the fact's table row from the question's direction-0 table (MG) / this direction's table
+        unsigned ro = MG && r > Rq ? __umul24((unsigned)(r - Rq - 1), D4) + dir1 : __umul24((unsigned)r, D4);
+        // a slot past the row's end has weight 0 and reads the row of the batch's first fact (a relation this node has)
+        if (lane >= cnt) ro = __builtin_amdgcn_readfirstlane(ro);
+        const int nsteps = (cnt + 3) >> 2;
+        // steps of four facts that all have a zero prior (a seed prior: nearly all) are not walked
+        const unsigned long long nz = __ballot(p != 0.f);
+        int s = 0;
+        for (; s + S <= nsteps; s += S) {              // S steps' table rows in flight together
+          if (((nz >> (4 * s)) & ((1ull << (4 * S)) - 1ull)) == 0) continue;
+          float pj[S];
+          f32x4 tv[S][NCH];
+#pragma unroll
+          for (int u = 0; u < S; ++u) {
+            const int src = 4 * (s + u) + grp;         // <= 63
+            pj[u] = __shfl(p, src, 64);
+            const unsigned rs = (unsigned)__shfl((int)ro, src, 64);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) tv[u][c] = *reinterpret_cast<const f32x4*>(T + (rs + cb[c]));
+          }
+#pragma unroll
+          for (int u = 0; u < S; ++u)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) acc[c] += pj[u] * tv[u][c];
+        }
+        for (; s < nsteps; ++s) {                      // the batch's last steps, one at a time
+          if (((nz >> (4 * s)) & 15ull) == 0) continue;
+          const int src = 4 * s + grp;
+          const float pj = __shfl(p, src, 64);
+          const unsigned rs = (unsigned)__shfl((int)ro, src, 64);
+          f32x4 tv[NCH];
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) tv[c] = *reinterpret_cast<const f32x4*>(T + (rs + cb[c]));
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) acc[c] += pj * tv[c];
+        }
+      }
+    }
+    // the four groups' partial sums -> group g holds piece g
+    f32x4 res;
+    if constexpr (NCH == 4) {
+      f32x4 k[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[h][e]), __float_as_uint(acc[h + 2][e]), false, false);
+          k[h][e] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);   // lanes 0-31: piece h of groups (0|1) + (2|3); 32-63: piece h + 2
+        }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(k[0][e]), __float_as_uint(k[1][e]), false, false);
+        res[e] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = acc[c][e];
+          x += __shfl_xor(x, 32, 64);
+          x += __shfl_xor(x, 16, 64);
+          acc[c][e] = x;
+        }
+      res = acc[0];
+#pragma unroll
+      for (int c = 1; c < NCH; ++c)
+        if (grp == c) res = acc[c];
+    }
+    const int col = 64 * grp + 4 * l;
+    if (live[t] && grp < NCH && col < D) *reinterpret_cast<f32x4*>(a.out + (size_t)n * D + col) = res;
+  }
+}
+
 template <int MODE, int VEC, int CPL, int NI>
 __global__ __launch_bounds__(256) void k_heavy_partial(const WalkArgs a) {
   if constexpr (MODE == MODE_FUSED) {
@@ -575,6 +763,9 @@ __global__ __launch_bounds__(256) void k_heavy_reduce(const WalkArgs a, int na) 
 #ifndef GNNRAG_HUB_W_GRID
 #define GNNRAG_HUB_W_GRID 2048   // workgroups (4 waves, a 256-fact chunk per wave and turn) of k_hub_weights per direction
 #endif
+#ifndef GNNRAG_HUB_U
+#define GNNRAG_HUB_U 0           // k_hub_dense: groups of 16 relations per register stage (0: 2, and 4 for a single hub tile)
+#endif
 #ifndef GNNRAG_HUB_KS_MAX
 #define GNNRAG_HUB_KS_MAX 8      // relation ranges per question (one k_hub_dense workgroup each) at batches of <= 32
                                  // questions; C5 aggregation, us: 4: 781, 8: 725, 16: 756, 32: 784
@@ -588,22 +779,40 @@ __global__ __launch_bounds__(256) void k_hub_zero(const WalkArgs a) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) w[i] = z;
 }
 
+constexpr int kHubOffLds = 4096;   // hubs of a direction whose chunk offsets k_hub_weights keeps in LDS (16 KB)
+// (Measured and not kept, round 4: this work inside the light-row launch - as its leading workgroups 655 us for the
+// light kernel against 579 + 51 apart, as every 8th group of 8 workgroups 829 us: DESIGN A.7.)
 __global__ __launch_bounds__(256) void k_hub_weights(const WalkArgs a) {
   if (!hub_dense_on(a)) return;
-  const int d = blockIdx.y;
+  __shared__ int32_t s_off[kHubOffLds];
+  const int d = blockIdx.y, bx = blockIdx.x, gx = gridDim.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int cnt = min(a.n_heavy[d], a.heavy_cap);
   const int nch = min(a.n_chunks[d], a.max_chunks);
   const int32_t* off = a.chunk_off[d];
   float* wdir = a.hub_w + (d ? a.hub_wbase[0][a.B] : 0);
-  for (int c = blockIdx.x * 4 + wave; c < nch; c += gridDim.x * 4) {
+  // a chunk finds its hub by bisection over the hubs' chunk offsets: ~log2(hubs) DEPENDENT loads in front of everything
+  // else the wave does - from LDS when the offsets fit (one coalesced copy per workgroup), from L2 otherwise
+  const bool staged = cnt <= kHubOffLds;
+  if (staged && bx * 4 < nch) {
+    for (int i = threadIdx.x; i < cnt; i += 256) s_off[i] = off[i];
+  }
+  __syncthreads();
+  for (int c = bx * 4 + wave; c < nch; c += gx * 4) {
     int lo = 0, hi = cnt;                       // largest e with off[e] <= c
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (off[mid] <= c) lo = mid; else hi = mid;
+    if (staged) {
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_off[mid] <= c) lo = mid; else hi = mid;
+      }
+    } else {
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= c) lo = mid; else hi = mid;
+      }
     }
     const int n = a.heavy[d][lo];
-    const int lc = c - off[lo];
+    const int lc = c - (staged ? s_off[lo] : off[lo]);
     const int beg = a.row_ptr[d][n] + lc * kHeavyDeg;
     const int len = min(kHeavyDeg, a.row_ptr[d][n + 1] - beg);
     const int q = n / a.N;
@@ -692,7 +901,7 @@ constexpr int kHubWaves = 8;   // waves of a k_hub_dense workgroup: 32 columns e
 template <int MT>
 __device__ __forceinline__ void hub_dense_tiles(const WalkArgs& a, int ks, int d, int e0, int nh, int h0,
                                                 const float* __restrict__ Wq, const float* __restrict__ Pq, int nrel,
-                                                int nrel4, int kg_beg, int kg_end) {
+                                                int nrel4, int kg_beg, int kg_end, float* __restrict__ part0) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int D = a.D;
@@ -712,36 +921,54 @@ __device__ __forceinline__ void hub_dense_tiles(const WalkArgs& a, int ks, int d
   for (int i = 0; i < MT; ++i) acc[i][0] = acc[i][1] = zero4;
   // A lane (fr, fg): weights of hub fr for the relations k .. k + 3, k = 16 kg + 4 fg (one 16-byte load).  MFMA e of a
   // group contracts the relations {16 kg + 4 fg + e}: any split of k is fine as long as A and B agree.
-  constexpr int U = MT == 1 ? 4 : 2;
-  for (int kg0 = kg_beg; kg0 < kg_end; kg0 += U) {
+  // The kernel is latency bound (the MFMAs of a range are ~15 us of its ~80): two register stages, the loads of the
+  // next U relation groups are requested before the MFMAs of the current ones.  The stages are two distinct objects
+  // and the loop is written out twice - a rotated stage would be a register copy of a load in flight, which waits for it.
+  constexpr int U = GNNRAG_HUB_U ? (MT == 1 ? 2 * GNNRAG_HUB_U : GNNRAG_HUB_U) : (MT == 1 ? 4 : 2);
+  struct Stage {
     f32x4 av[U][MT];
     f32x2 bv[U][4];
+  };
+  auto request = [&](Stage& st, int kg0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      // past the range / the question's relations the WEIGHTS are zero (select below, zeroed padding); the table rows
-      // are then read from the last row instead of being zeroed: 0 x finite
-      const bool on = kg0 + u < kg_end;
+      // past the range / the question's relations the WEIGHTS count as zero (select in `multiply`, zeroed padding); the
+      // table rows are then read from the last row instead of being zeroed: 0 x finite
       const int k = (kg0 + u) * 16 + fg * 4;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wrow[i] + min(k, nrel4 - 4));
-        av[u][i] = (on && k < nrel4) ? w4 : zero4;
-      }
+      for (int i = 0; i < MT; ++i) st.av[u][i] = *reinterpret_cast<const f32x4*>(wrow[i] + min(k, nrel4 - 4));
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        bv[u][e] = *reinterpret_cast<const f32x2*>(Pq + (size_t)min(k + e, nrel - 1) * D + cbl);
+        st.bv[u][e] = *reinterpret_cast<const f32x2*>(Pq + (size_t)min(k + e, nrel - 1) * D + cbl);
     }
-    __builtin_amdgcn_sched_barrier(0);     // all loads are requested before the first MFMA (the scheduler would
-                                           // otherwise keep three in flight to save registers)
+  };
+  auto multiply = [&](const Stage& st, int kg0) {
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int u = 0; u < U; ++u) {
+      const int k = (kg0 + u) * 16 + fg * 4;
+      const bool on = kg0 + u < kg_end && k < nrel4;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i) {
+          const float w = on ? st.av[u][i][e] : 0.f;
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
-            acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i][e], bv[u][e][nt], acc[i][nt], 0, 0, 0);
+            acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, st.bv[u][e][nt], acc[i][nt], 0, 0, 0);
+        }
+    }
+  };
+  Stage s0, s1;
+  request(s0, kg_beg);
+  for (int kg0 = kg_beg; kg0 < kg_end; kg0 += 2 * U) {
+    request(s1, kg0 + U);                  // (past the range: clamped addresses, weights not used)
+    __builtin_amdgcn_sched_barrier(0);     // requests stay ahead of the MFMAs
+    multiply(s0, kg0);
+    __builtin_amdgcn_sched_barrier(0);
+    request(s0, kg0 + 2 * U);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(s1, kg0 + U);
+    __builtin_amdgcn_sched_barrier(0);
   }
   // C layout: lane (fr, fg) holds hubs 4 fg + r of column slot fr, i.e. column c0 + 2 fr + nt of tile nt
 #pragma unroll
@@ -751,7 +978,7 @@ __device__ __forceinline__ void hub_dense_tiles(const WalkArgs& a, int ks, int d
       const int m = h0 + i * 16 + fg * 4 + rr;
       if (m < nh && cok) {
         const f32x2 o = {acc[i][0][rr], acc[i][1][rr]};
-        *reinterpret_cast<f32x2*>(hub_part(a, ks, d, e0 + m) + cb) = o;
+        *reinterpret_cast<f32x2*>(part0 + (size_t)(e0 + m) * D + cb) = o;
       }
     }
 }
@@ -773,11 +1000,12 @@ __global__ __launch_bounds__(64 * kHubWaves) void k_hub_dense(const WalkArgs a) 
   const int nkg = (nrel4 + 15) >> 4;
   const int per = (nkg + a.hub_ks - 1) / a.hub_ks;
   const int kg_beg = min(ks * per, nkg), kg_end = min(kg_beg + per, nkg);     // (an empty range still writes its zero rows)
+  float* part0 = hub_part(a, ks, d, 0);      // partial row of this range and direction for hub entry 0 (sizes read once)
   for (int h0 = 0; h0 < nh; h0 += 48) {
     const int left = nh - h0;
-    if (left > 32) hub_dense_tiles<3>(a, ks, d, e0, nh, h0, Wq, Pq, nrel, nrel4, kg_beg, kg_end);
-    else if (left > 16) hub_dense_tiles<2>(a, ks, d, e0, nh, h0, Wq, Pq, nrel, nrel4, kg_beg, kg_end);
-    else hub_dense_tiles<1>(a, ks, d, e0, nh, h0, Wq, Pq, nrel, nrel4, kg_beg, kg_end);
+    if (left > 32) hub_dense_tiles<3>(a, ks, d, e0, nh, h0, Wq, Pq, nrel, nrel4, kg_beg, kg_end, part0);
+    else if (left > 16) hub_dense_tiles<2>(a, ks, d, e0, nh, h0, Wq, Pq, nrel, nrel4, kg_beg, kg_end, part0);
+    else hub_dense_tiles<1>(a, ks, d, e0, nh, h0, Wq, Pq, nrel, nrel4, kg_beg, kg_end, part0);
   }
 }
 
@@ -1608,7 +1836,24 @@ static int launch_one(WalkArgs a, hipStream_t stream) {
     nblk = 8 * ((a.B + 7) / 8) * a.bpg;
   }
   if (!a.heavy_only) {
-    hipLaunchKernelGGL((k_walk_light<MODE, VEC, LPN, CPL, NI>), dim3(nblk), dim3(256), 0, stream, a);
+    bool quad = false;
+    if constexpr (MODE == MODE_FUSED && VEC == 4 && LPN == 64 && CPL == 1) {
+      // four facts per step (k_walk_light_q); rel * 4 D must fit the 24-bit multiply and 32-bit offsets
+      quad = GNNRAG_LIGHT_QUAD && a.D > 128 && a.R1 < (1 << 20);
+      if (quad) {
+        // both directions as one merged run: no per-fact weights, both tables within 32-bit byte offsets of the first
+        const long long span = ((const char*)a.T[1] - (const char*)a.T[0]) + (long long)(a.R1 + 1) * a.D * 4;
+        const bool mg = GNNRAG_QUAD_MERGED && a.merged && !a.w[0] && !a.w[1] && a.T[1] > a.T[0] && span < (1ll << 32);
+        if (a.D > 192) {
+          if (mg) hipLaunchKernelGGL((k_walk_light_q<4, true>), dim3(nblk), dim3(256), 0, stream, a);
+          else hipLaunchKernelGGL((k_walk_light_q<4, false>), dim3(nblk), dim3(256), 0, stream, a);
+        } else {
+          if (mg) hipLaunchKernelGGL((k_walk_light_q<3, true>), dim3(nblk), dim3(256), 0, stream, a);
+          else hipLaunchKernelGGL((k_walk_light_q<3, false>), dim3(nblk), dim3(256), 0, stream, a);
+        }
+      }
+    }
+    if (!quad) hipLaunchKernelGGL((k_walk_light<MODE, VEC, LPN, CPL, NI>), dim3(nblk), dim3(256), 0, stream, a);
     GNNRAG_LAUNCH_CHECK();
   }
   // heavy rows (count lives on the device: fixed grids, grid-stride loops, no host sync)

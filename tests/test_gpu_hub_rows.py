@@ -62,10 +62,9 @@ def _graph_blocks_do_not_fit(seed=4):
     return B, N, R, h[p], r[p], t[p]
 
 
-def _run(dev, graph=None, want_form=None):
+def _run(dev, graph=None, want_form=None, D=200):
     from gnnrag_amd import ops
     B, N, R, h, r, t = (graph or _graph)()
-    D = 200
     plan = ops.CsrPlan(h, r, t, B, N, R, dev)
     assert ops.aggregate_fused_variant(plan, D) == ops.WALK_L2_GATHER
     got_plan = plan.to_host()
@@ -100,6 +99,16 @@ def test_hub_rows_dense_form():
     import gnnrag_amd  # noqa: F401
     dev = torch.device("cuda", 0)
     out, want, scale, _ = _run(dev)         # asserts HUB_FORM_DENSE as read back from the device
+    assert np.abs(out - want).max() <= 2e-5 * scale, np.abs(out - want).max() / scale
+
+
+@pytest.mark.parametrize("D", [132, 160, 192, 196, 256])
+def test_light_rows_four_facts_per_step_at_other_widths(D):
+    """k_walk_light_q (round 4: four facts per step, a lane covers the columns 64 c + 4 l) with three column pieces
+    (128 < D <= 192) and four (D <= 256), a last piece of a single float4 (132, 196), full pieces (192, 256); the same
+    graph: light rows of 1 .. 256 facts (four 64-fact batches), hub rows beside them."""
+    import gnnrag_amd  # noqa: F401
+    out, want, scale, _ = _run(torch.device("cuda", 0), D=D)
     assert np.abs(out - want).max() <= 2e-5 * scale, np.abs(out - want).max() / scale
 
 

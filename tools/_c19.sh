@@ -1,0 +1,5 @@
+#!/bin/bash
+R=$PWD; OUT=$R/gpurun_out/r4c19; mkdir -p $OUT
+timeout 900 python -m pytest tests/test_gpu_hub_rows.py -x -q -m gpu > $OUT/tests.log 2>&1; tail -3 $OUT/tests.log
+GNNRAG_TUNE_WORKLOAD=C5 timeout 1200 python tools/tune_variants.py --run default hub_side hub_side_wg512 hub_side_wg256 quad_off default > $OUT/tune_C5.txt 2>&1
+cat $OUT/tune_C5.txt

@@ -1,0 +1,6 @@
+#!/bin/bash
+R=$PWD; OUT=$R/gpurun_out/r4c20; mkdir -p $OUT
+timeout 900 python -m pytest tests/test_gpu_hub_rows.py tests/test_gpu_baseline_shapes.py -x -q -m gpu > $OUT/tests.log 2>&1; tail -3 $OUT/tests.log
+GNNRAG_LIB=$R/gnn-rag_amd/lib/exp_quad_unmerged.so timeout 900 python -m pytest tests/test_gpu_hub_rows.py -x -q -m gpu > $OUT/tests_unmerged.log 2>&1; tail -3 $OUT/tests_unmerged.log
+GNNRAG_TUNE_WORKLOAD=C5 timeout 1200 python tools/tune_variants.py --run default quad_unmerged quad_off default > $OUT/tune_C5.txt 2>&1
+cat $OUT/tune_C5.txt
