@@ -462,7 +462,12 @@ __global__ __launch_bounds__(256) void k_walk_light(const WalkArgs a) {
 // sums are reduced so that group g ends with column piece g (gfx950 v_permlane32_swap / v_permlane16_swap: a swap and an
 // add per register) and stores it.  A fact's 800-byte row is still read as whole 256-byte pieces.
 // Sum order: facts g, g + 4, g + 8, ... of a row in fact order per group, then (g0 + g2) + (g1 + g3): fixed.
-// A zero-prior fact multiplies its table row by 0 here (k_walk_light skips it): the reference's own 0 x value.
+// A zero-prior fact in a step with a live one multiplies its table row by 0 (k_walk_light skips it): the reference's own
+// 0 x value; steps whose four priors are all zero are skipped.
+// Measured beside it (config 5, dense-prior launch, us): k_walk_light 729; this kernel with a run per direction 714,
+// merged runs 681, one step in flight instead of two 662 (50 registers: 8 waves per SIMD); a packed form with 5 facts
+// per four loads (slot k = 64 i + lane -> fact k / 50, piece k % 50, partial sums through LDS) 657 against 655: the
+// number of load instructions is not what bounds the gather, the 6.5 GB that pass through L1 are (DESIGN A.7).
 #ifndef GNNRAG_LIGHT_QUAD
 #define GNNRAG_LIGHT_QUAD 1       // 0: k_walk_light for every shape
 #endif
@@ -470,7 +475,7 @@ __global__ __launch_bounds__(256) void k_walk_light(const WalkArgs a) {
 #define GNNRAG_QUAD_MERGED 1      // both directions of a node as one run of the merged record stream
 #endif
 #ifndef GNNRAG_QUAD_STEPS
-#define GNNRAG_QUAD_STEPS 2       // steps (4 facts each) whose table-row loads are in flight together
+#define GNNRAG_QUAD_STEPS 1       // steps (4 facts each) whose table-row loads are in flight together
 #endif
 // MG: the node's facts of both directions are one run of the merged record stream (gnnrag_csr::edge_m: direction 1's
 // relation index offset by the question's relation count + 1): one record batch and one prior gather per node
