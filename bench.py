@@ -853,12 +853,12 @@ def e2e_leg():
     out["d200_batch16"] = {"gpu": run("d200", False, 16),
                            # the next batch's tuple + structure built by a worker thread on a side stream (StructurePrefetcher)
                            "gpu_prefetch": run("d200", False, 16, extra_env={"GNNRAG_PREFETCH": "1"}),
-                           # + the question encoder's nn.LSTM off MIOpen (GNNRAG_MIOPEN_RNN=0: MIOpen's RNN call is ~12 ms
-                           # at these shapes, half of a batch's forward; the encoder is the reference's, a backend switch)
-                           "gpu_prefetch_native_lstm": run("d200", False, 16, extra_env={"GNNRAG_PREFETCH": "1", "GNNRAG_MIOPEN_RNN": "0"}),
+                           # the same with the question encoder's nn.LSTM left to torch / MIOpen (GNNRAG_HIP_LSTM=0: MIOpen's
+                           # RNN call is ~12 ms at these shapes, twice per batch; default: gnnrag_lstm_forward)
+                           "gpu_prefetch_miopen_lstm": run("d200", False, 16, extra_env={"GNNRAG_PREFETCH": "1", "GNNRAG_HIP_LSTM": "0"}),
                            "cpu_reference_sample32": run("d200", True, 16, True)}
     out["c1_d50_batch1"] = {"gpu": run("d50", False, 1),
-                            "gpu_native_lstm": run("d50", False, 1, extra_env={"GNNRAG_MIOPEN_RNN": "0"}),
+                            "gpu_miopen_lstm": run("d50", False, 1, extra_env={"GNNRAG_HIP_LSTM": "0"}),
                             "cpu_reference_sample32": run("d50", True, 1, True)}
     for k in ("d200_batch16", "c1_d50_batch1"):
         g, c = out[k]["gpu"], out[k]["cpu_reference_sample32"]

@@ -128,4 +128,12 @@ def swap(model, args: dict):
         j += 1
     if hasattr(model, "get_rel_feature"):
         cache_rel_features(model)
+    swap_lstm(model)
     return model
+
+
+def swap_lstm(model) -> int:
+    """The question encoder's ``nn.LSTM`` (lstm_encoder.py:27-30) -> ``HipLSTM`` (same parameters, shared); works on a model
+    built either way (install() or the reference's own modules).  Returns the number of LSTMs replaced."""
+    from .modules.question_encoding.lstm import swap_lstm as _swap
+    return _swap(model)

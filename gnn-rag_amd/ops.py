@@ -973,6 +973,40 @@ class LayerStack:
             pass
 
 
+_lstm_ws = {}
+
+
+def lstm_forward(x, w_ih, w_hh, b_ih=None, b_hh=None, h0=None, c0=None):
+    """One-layer batch_first LSTM, torch.nn.LSTM semantics (lstm_encoder.py:27-36): x [B,T,E], w_ih [4H,E], w_hh [4H,H],
+    biases [4H] or None, h0 / c0 [B,H] or None (zeros).  Returns (out [B,T,H], h_n [B,H], c_n [B,H])."""
+    lib = _lib.load()
+    x = _chk(x, "x")
+    if x.dim() != 3:
+        raise ValueError("x must be [B,T,E]")
+    B, T, E = x.shape
+    w_ih = _chk(w_ih.detach(), "w_ih")
+    H = w_ih.shape[0] // 4
+    w_ih = _chk(w_ih, "w_ih", shape=(4 * H, E))
+    w_hh = _chk(w_hh.detach(), "w_hh", shape=(4 * H, H))
+    b_ih = None if b_ih is None else _chk(b_ih.detach(), "b_ih", shape=(4 * H,))
+    b_hh = None if b_hh is None else _chk(b_hh.detach(), "b_hh", shape=(4 * H,))
+    h0 = None if h0 is None else _chk(h0, "h0", shape=(B, H))
+    c0 = None if c0 is None else _chk(c0, "c0", shape=(B, H))
+    dev = x.device
+    out = torch.empty((B, T, H), dtype=torch.float32, device=dev)
+    h_n = torch.empty((B, H), dtype=torch.float32, device=dev)
+    c_n = torch.empty((B, H), dtype=torch.float32, device=dev)
+    need = lib.gnnrag_lstm_workspace_bytes(E, H)
+    ws = _lstm_ws.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = _lstm_ws[dev] = torch.empty(need, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gnnrag_lstm_forward(x.data_ptr(), w_ih.data_ptr(), w_hh.data_ptr(), _ptr(b_ih), _ptr(b_hh), _ptr(h0),
+                                           _ptr(c0), out.data_ptr(), h_n.data_ptr(), c_n.data_ptr(), B, T, E, H,
+                                           ws.data_ptr(), ws.numel(), _stream()), "gnnrag_lstm_forward")
+    return out, h_n, c_n
+
+
 def seed_retrieve(seed_info: torch.Tensor, ent_emb: torch.Tensor) -> torch.Tensor:
     """sum_n seed_info[b,n] * ent_emb[b,n,:]  ->  [B,D] (query_update.py:40), reading only flagged rows."""
     lib = _lib.load()

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GNNRAG_ABI_VERSION 13
+#define GNNRAG_ABI_VERSION 14
 
 #define GNNRAG_E_BADARG      (-1)  /* null pointer / negative size / inconsistent sizes   */
 #define GNNRAG_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set (see DESIGN)  */
@@ -466,6 +466,17 @@ int gnnrag_topp_candidates_ws(const float* pred_dist, const uint8_t* eligible, i
  * read, in ascending n.  seed_info [B,N], ent_emb [B,N,D], out [B,D]. */
 int gnnrag_seed_retrieve(const float* seed_info, const float* ent_emb, float* out, int32_t B, int32_t N,
                          int32_t D, gnnrag_stream_t stream);
+
+/* The question encoder's LSTM (the instruction path): one layer, one direction, batch_first,
+ * torch.nn.LSTM semantics and parameter layout (gate order i, f, g, o) - what
+ * gnn/modules/question_encoding/lstm_encoder.py:27-36 builds and calls as
+ *   query_hidden_emb, (h_n, c_n) = self.node_encoder(x, (h0, c0))          x [B, T, E], h0 = c0 = zeros [1, B, H]
+ * x [B,T,E], w_ih [4H,E], w_hh [4H,H], b_ih / b_hh [4H] or NULL, h0 / c0 [B,H] or NULL (zeros); out [B,T,H], h_n and
+ * c_n [B,H].  4 H <= 1024.  workspace: gnnrag_lstm_workspace_bytes(E, H) bytes (transposed weights). */
+size_t gnnrag_lstm_workspace_bytes(int32_t E, int32_t H);
+int gnnrag_lstm_forward(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                        const float* h0, const float* c0, float* out, float* h_n, float* c_n, int32_t B, int32_t T,
+                        int32_t E, int32_t H, void* workspace, size_t workspace_bytes, gnnrag_stream_t stream);
 
 /* Plain HBM copy kernel (float4 per lane) used by bench.py to measure the achievable
  * streaming ceiling next to the 8 TB/s spec.  n = number of floats (multiple of 4). */

@@ -107,6 +107,16 @@ def main():
     if not os.environ.get("GNNRAG_NO_EVAL_PATCH"):
         from gnnrag_amd import eval_tail
         eval_tail.patch_evaluator_class(evaluate.Evaluator)
+    if os.environ.get("GNNRAG_HIP_LSTM", "1") != "0":
+        # the question encoder's nn.LSTM -> HipLSTM (same parameters, shared; inference calls only): the model is built
+        # by the reference's own code, the Evaluator's constructor is the first place that sees it
+        _ev_init0 = evaluate.Evaluator.__init__
+
+        def _init_lstm(self, *a, **kw):
+            _ev_init0(self, *a, **kw)
+            install.swap_lstm(self.model)
+
+        evaluate.Evaluator.__init__ = _init_lstm
     if world > 1 or force_dist:
         from gnnrag_amd import shard
         _ev_init = evaluate.Evaluator.__init__
