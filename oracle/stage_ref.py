@@ -300,7 +300,36 @@ def staged() -> bool:
     return open(os.path.join(DATA, "VERSION")).readline().strip() == DATASET_VERSION
 
 
+GOLDEN_CKPT = os.path.join(os.path.dirname(HERE), "tests", "golden", "ckpt")
+
+
+def _golden_checkpoint(variant):
+    """tests/golden/ckpt/<name>: the checkpoint THIS script's make_checkpoint wrote (the reference's trainer on CPU,
+    8 / 12 epochs: 3 / 26 minutes), committed so that staging in a fresh container is dataset generation + the CPU
+    reference's evaluation only.  Valid for the dataset version it was trained on; GNNRAG_STAGE_RETRAIN=1 trains anew."""
+    path = os.path.join(GOLDEN_CKPT, ckpt_name(variant))
+    ver = os.path.join(GOLDEN_CKPT, "DATASET_VERSION")
+    if os.environ.get("GNNRAG_STAGE_RETRAIN") == "1" or not os.path.isfile(path) or not os.path.isfile(ver):
+        return None
+    return path if open(ver).read().strip() == DATASET_VERSION else None
+
+
+def save_golden():
+    os.makedirs(GOLDEN_CKPT, exist_ok=True)
+    for v in VARIANTS:
+        if VARIANTS[v]["epochs"]:
+            shutil.copyfile(os.path.join(CKPT, ckpt_name(v)), os.path.join(GOLDEN_CKPT, ckpt_name(v)))
+    with open(os.path.join(GOLDEN_CKPT, "DATASET_VERSION"), "w") as f:
+        f.write(DATASET_VERSION + "\n")
+
+
 def _train_in_subprocess(variant):
+    golden = _golden_checkpoint(variant)
+    if golden:
+        os.makedirs(CKPT, exist_ok=True)
+        shutil.copyfile(golden, os.path.join(CKPT, ckpt_name(variant)))
+        print("stage_ref[%s]: checkpoint from tests/golden/ckpt (trained by this script's make_checkpoint)" % variant, flush=True)
+        return
     # own process: the reference's modules must not leak into the caller's sys.modules / logging setup
     r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import stage_ref; stage_ref.make_checkpoint(%r)"
                         % (HERE, variant)],
@@ -342,7 +371,9 @@ def restage_variant(v):
 
 
 if __name__ == "__main__":
-    if "--variant" in sys.argv:
+    if "--save-golden" in sys.argv:
+        save_golden()
+    elif "--variant" in sys.argv:
         restage_variant(sys.argv[sys.argv.index("--variant") + 1])
     else:
         main(force="--force" in sys.argv)

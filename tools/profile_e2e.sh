@@ -23,6 +23,9 @@ st = pstats.Stats(out); st.sort_stats("cumulative")
 import io
 buf = io.StringIO(); st.stream = buf; st.print_stats(70)
 txt = buf.getvalue()
+st2 = pstats.Stats(out); st2.sort_stats("tottime")
+buf2 = io.StringIO(); st2.stream = buf2; st2.print_stats(60)
+txt = txt + "\n\n==== by own time ====\n" + buf2.getvalue()
 open(out.replace(".prof", ".txt"), "w").write(txt)
 print("\n".join(l[:150] for l in txt.splitlines()[:90]))
 PY
