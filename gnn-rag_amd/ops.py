@@ -487,7 +487,7 @@ def relation_tables(plan: CsrPlan, T_fwd: torch.Tensor, T_inv: torch.Tensor, ins
 
 
 WALK_L2_GATHER, WALK_LDS_16, WALK_LDS_32 = 0, 1, 2
-WALK_KERNEL_NAMES = {WALK_L2_GATHER: "k_walk_light<FUSED> (table rows gathered from L2)",
+WALK_KERNEL_NAMES = {WALK_L2_GATHER: "k_walk_light_q / k_walk_light<FUSED> + hub kernels (table rows gathered from L2)",
                      WALK_LDS_16: "k_fact_prior_merged + k_walk_slice<FUSED,1> (16-column table slices in LDS, merged rows)",
                      WALK_LDS_32: "k_fact_prior_merged + k_walk_slice<FUSED,2> (32-column table slices in LDS, merged rows)"}
 
