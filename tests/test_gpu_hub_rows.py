@@ -62,7 +62,7 @@ def _graph_blocks_do_not_fit(seed=4):
     return B, N, R, h[p], r[p], t[p]
 
 
-def _run(dev, graph=None, want_form=None, D=200):
+def _run(dev, graph=None, want_form=None, D=200, weights=False):
     from gnnrag_amd import ops
     B, N, R, h, r, t = (graph or _graph)()
     plan = ops.CsrPlan(h, r, t, B, N, R, dev)
@@ -76,6 +76,10 @@ def _run(dev, graph=None, want_form=None, D=200):
         want_form = ops.HUB_FORM_NONE if os.environ.get("GNNRAG_HUB_DENSE") == "0" else ops.HUB_FORM_DENSE
     assert form["form"] == want_form and form["hubs"] == (got_plan["n_heavy"][0], got_plan["n_heavy"][1]), form
     rng = np.random.default_rng(9)
+    wfact = None
+    if weights:                                    # normalized_gnn: per-fact weights, used squared (base_gnn.py:38-47)
+        wfact = (0.5 + rng.random(len(h))).astype(np.float32)
+        plan.attach_w_gnn(wfact)
     dist = rng.random((B, N)).astype(np.float32)
     dist[:, ::3] = 0.0
     P = (rng.standard_normal((2, plan.rel_total, D)) * 0.3).astype(np.float32)
@@ -89,8 +93,9 @@ def _run(dev, graph=None, want_form=None, D=200):
     row_of = np.searchsorted(key, q * (R + 1) + r)
     want = np.zeros((B * N, D))
     d64 = dist.reshape(-1).astype(np.float64)
-    np.add.at(want, t, d64[h][:, None] * P[0][row_of].astype(np.float64))
-    np.add.at(want, h, d64[t][:, None] * P[1][row_of].astype(np.float64))
+    w2 = np.ones(len(h)) if wfact is None else wfact.astype(np.float64) ** 2
+    np.add.at(want, t, (w2 * d64[h])[:, None] * P[0][row_of].astype(np.float64))
+    np.add.at(want, h, (w2 * d64[t])[:, None] * P[1][row_of].astype(np.float64))
     scale = np.abs(want).max()
     return out, want, scale, rel_off
 
@@ -109,6 +114,15 @@ def test_light_rows_four_facts_per_step_at_other_widths(D):
     graph: light rows of 1 .. 256 facts (four 64-fact batches), hub rows beside them."""
     import gnnrag_amd  # noqa: F401
     out, want, scale, _ = _run(torch.device("cuda", 0), D=D)
+    assert np.abs(out - want).max() <= 2e-5 * scale, np.abs(out - want).max() / scale
+
+
+@pytest.mark.parametrize("D", [200, 160])
+def test_gather_walk_with_per_fact_weights(D):
+    """normalized_gnn weights on the gather walk: the light rows then take the run-per-direction form of k_walk_light_q
+    (the merged record stream carries no weights), the hub rows their weighted sums."""
+    import gnnrag_amd  # noqa: F401
+    out, want, scale, _ = _run(torch.device("cuda", 0), D=D, weights=True)
     assert np.abs(out - want).max() <= 2e-5 * scale, np.abs(out - want).max() / scale
 
 
