@@ -53,7 +53,7 @@ VARIANTS = {
     "light_npw1": {"GNNRAG_LIGHT_NPW": 1}, "light_npw2": {"GNNRAG_LIGHT_NPW": 2}, "light_npw8": {"GNNRAG_LIGHT_NPW": 8},
     "heavy_grid512": {"GNNRAG_HEAVY_GRID": 512}, "heavy_grid2048": {"GNNRAG_HEAVY_GRID": 2048},
     "light_nogather": {"GNNRAG_LIGHT_ABL": 1}, "light_nostore": {"GNNRAG_LIGHT_ABL": 2}, "light_l2hit": {"GNNRAG_LIGHT_ABL": 4},
-    "quad_off": {"GNNRAG_LIGHT_QUAD": 0}, "quad_s3": {"GNNRAG_QUAD_STEPS": 3}, "quad_s4": {"GNNRAG_QUAD_STEPS": 4}, "quad_s1": {"GNNRAG_QUAD_STEPS": 1},
+    "quad_off": {"GNNRAG_LIGHT_QUAD": 0}, "quad_s2": {"GNNRAG_QUAD_STEPS": 2}, "quad_s3": {"GNNRAG_QUAD_STEPS": 3}, "quad_s4": {"GNNRAG_QUAD_STEPS": 4},
     "quad_npw1": {"GNNRAG_LIGHT_NPW": 1}, "quad_npw4": {"GNNRAG_LIGHT_NPW": 4},
     "quad_unmerged": {"GNNRAG_QUAD_MERGED": 0},
     "hub_u4": {"GNNRAG_HUB_U": 4}, "hub_u3": {"GNNRAG_HUB_U": 3}, "hub_ks16": {"GNNRAG_HUB_KS_MAX": 16},
