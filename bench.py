@@ -857,6 +857,8 @@ def e2e_leg():
                            # RNN call is ~12 ms at these shapes, twice per batch; default: gnnrag_lstm_forward)
                            "gpu_prefetch_miopen_lstm": run("d200", False, 16, extra_env={"GNNRAG_PREFETCH": "1", "GNNRAG_HIP_LSTM": "0"}),
                            "cpu_reference_sample32": run("d200", True, 16, True)}
+    # BASELINE config 2's batch (64 questions per forward): the host's per-batch costs spread over four times the questions
+    out["d200_batch64"] = {"gpu": run("d200", False, 64)}
     out["c1_d50_batch1"] = {"gpu": run("d50", False, 1),
                             "gpu_miopen_lstm": run("d50", False, 1, extra_env={"GNNRAG_HIP_LSTM": "0"}),
                             "cpu_reference_sample32": run("d50", True, 1, True)}
