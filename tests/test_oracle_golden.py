@@ -196,3 +196,18 @@ def test_oracle_closed_loop_reproduces_the_reference_forward():
                                    rf[j]["fusion.r.weight"], rf[j]["fusion.g.weight"]) for j in range(I)]
         assert np.abs(dist.numpy() - g("pred_dist")).max() <= 1e-6
         assert np.array_equal(dist.argmax(1).numpy(), g("pred"))
+
+
+def test_lstm_oracle_matches_the_live_reference_encoder():
+    """oracle/lstm_np64.py against what the LIVE reference's LSTMInstruction.encode_question produced
+    (tests/golden/lstm_encoder.npz, tests/golden/make_golden_lstm.py): hidden states of every token and the final
+    (h_n, c_n), ragged questions padded with the pad word; fp32 reference vs float64 restatement."""
+    import oracle.lstm_np64 as lstm_np64
+    g = np.load(os.path.join(GOLDEN, "lstm_encoder.npz"))
+    for tag in ("d50", "d128"):
+        P = {k.split(".param.")[1]: g[k] for k in g.files if k.startswith(tag + ".param.")}
+        out, h, c = lstm_np64.lstm_forward(g[tag + ".word_emb"], P["node_encoder.weight_ih_l0"], P["node_encoder.weight_hh_l0"],
+                                           P["node_encoder.bias_ih_l0"], P["node_encoder.bias_hh_l0"])
+        assert np.abs(out - g[tag + ".query_hidden_emb"]).max() <= 2e-6
+        assert np.abs(h - g[tag + ".h_n"]).max() <= 2e-6 and np.abs(c - g[tag + ".c_n"]).max() <= 4e-6
+        assert np.array_equal(g[tag + ".query_node_emb"][:, 0], g[tag + ".h_n"])           # lstm_encoder.py:40
