@@ -65,10 +65,9 @@ def main():
         dist.init_process_group("nccl")
         atexit.register(lambda: dist.is_initialized() and dist.destroy_process_group())
 
-    # GNNRAG_MIOPEN_RNN=0: the reference's question encoder is an nn.LSTM over a handful of tokens; MIOpen's RNN call takes
-    # ~12 ms per call at these shapes on the MI355X (half of an evaluation batch's forward, tools/profile_e2e.sh) - with
-    # the cudnn/MIOpen backend off torch runs its own per-step kernels.  A backend setting, no reference code is touched;
-    # the encoder itself is out of this package's scope.
+    # GNNRAG_MIOPEN_RNN=0: torch's cudnn / MIOpen backend off, i.e. torch's own per-step kernels for any nn.LSTM that is NOT
+    # replaced by HipLSTM below (GNNRAG_HIP_LSTM=0, or a multi-layer / bidirectional encoder): MIOpen's RNN call takes ~12 ms
+    # per call at the question encoder's shapes on the MI355X (tools/profile_e2e.sh).  A backend setting only.
     if os.environ.get("GNNRAG_MIOPEN_RNN") == "0":
         import torch
         torch.backends.cudnn.enabled = False
