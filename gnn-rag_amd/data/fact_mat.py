@@ -67,6 +67,36 @@ def build_fact_mat(loader, sample_ids, fact_dropout):
     return batch_heads, batch_rels, batch_tails, batch_ids, fact_ids, weight_list, weight_rel_list
 
 
+class _QuestionFacts:
+    """One question's facts: ``[0]`` the [3, F] int32 id block, ``[1]`` / ``[2]`` the two per-fact weights
+    (``dataset_load.py:509-517``) - computed when first asked for: only ``normalized_gnn`` / ``norm_rel`` models read them,
+    and the pair count behind the second is a sort over the question's facts."""
+
+    __slots__ = ("blk", "_w", "_wr")
+
+    def __init__(self, blk):
+        self.blk, self._w, self._wr = blk, None, None
+
+    def __getitem__(self, k):
+        if k == 0:
+            return self.blk
+        h, r = self.blk[0], self.blk[1]
+        if k == 1:
+            if self._w is None:
+                self._w = 1.0 / np.bincount(h)[h] if len(h) else np.zeros(0)            # :509-511
+            return self._w
+        if k == 2:
+            if self._wr is None:
+                if len(h):
+                    key = h.astype(np.int64) * (int(r.max()) + 1) + r
+                    _, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
+                    self._wr = 1.0 / cnt[inv]                                              # :513-517
+                else:
+                    self._wr = np.zeros(0)
+            return self._wr
+        raise IndexError(k)
+
+
 class FactCache:
     """Per-question fact arrays built ONCE: typed edges followed by the self
     loops, local node ids, with both per-fact weights - everything ``_build_fact_mat`` recomputes for
@@ -101,14 +131,7 @@ class FactCache:
                 h = np.concatenate([h, ent])
                 t = np.concatenate([t, ent])
                 r = np.concatenate([r, np.full(len(ent), ld.num_kb_relation - 1, dtype=np.int32)])
-            if len(h):
-                w = 1.0 / np.bincount(h)[h]                                   # :509-511
-                key = h.astype(np.int64) * (int(r.max()) + 1) + r
-                _, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
-                wr = 1.0 / cnt[inv]                                           # :513-517
-            else:
-                w = wr = np.zeros(0)
-            q = (np.stack([h, r, t]), w, wr)
+            q = _QuestionFacts(np.stack([h, r, t]))
             if len(self._q) < self.max_questions:
                 self._q[sample_id] = q
         return q
