@@ -93,9 +93,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` as the driver may call it: launch the N ranks ourselves (one process per GPU,
+        # rendezvous on 127.0.0.1); rank 0 prints the one JSON line, the other ranks stay silent, the exit code is theirs
+        return self_launch(args.gpus)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (args.gpus, world))
     if args.dry_run_cpu:
         return dry_run_cpu(args, world, rank)
     if not torch.cuda.is_available():
@@ -301,7 +304,9 @@ def main():
 
     out = {
         "metric": "kg_edges_aggregated_per_sec", "value": value, "unit": "typed-edge*layers/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "n_gpus": world, "n_ranks_seen": (dist.get_world_size() if distributed else 1),
+        "rccl_version": (".".join(str(x) for x in torch.cuda.nccl.version()) if distributed else None),
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "%s: synthetic Freebase-shaped subgraphs, %d nodes / %d typed edges (+%d self loops) "
@@ -354,6 +359,24 @@ def main():
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
         print(json.dumps(out))
+
+
+def self_launch(n):
+    """``python bench.py --gpus N`` without a launcher: run the same command line under ``torch.distributed.run``
+    (one rank per GPU, rendezvous on 127.0.0.1 at a free port).  stdout / stderr are the children's, the return code too."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit(rc)
 
 
 def cached_structure_ms(batch, dev, ops):
@@ -479,6 +502,8 @@ def dry_run_cpu(args, world, rank):
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
+    if os.environ.get("GNNRAG_DRYRUN_FAIL") == "1" and rank == world - 1:      # CI: a rank that dies fails the launcher
+        raise SystemExit(7)
     gcfg = synth.GraphConfig(name="dry", B=6, N=24, E=60, R=5, D=16, I=2, L=2, T=1, seed=9, n_real_min=3)
     gbatch, gfeats = synth.make_batch(gcfg), synth.make_features(gcfg)
     params = synth.make_layer_params(gcfg)
@@ -512,7 +537,9 @@ def dry_run_cpu(args, world, rank):
         full = otorch.run_stack(gbatch, gfeats, params)["dist"][-1]
         ok = bool(np.array_equal(last.numpy(), full))
     out = {"metric": "kg_edges_aggregated_per_sec", "value": global_B * gcfg.E * gcfg.L / (elapsed / args.steps),
-           "unit": "typed-edge*layers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "unit": "typed-edge*layers/s", "n_gpus": world,
+           "n_ranks_seen": (dist.get_world_size() if world > 1 else 1), "collective_backend": "gloo",
+           "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "dry run on CPU (gloo): NOT a measurement"}, "gathered_matches_unsharded": ok}

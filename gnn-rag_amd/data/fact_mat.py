@@ -218,6 +218,34 @@ class BatchFacts:
         return BatchFacts(hrt, self._sizes[lo:hi], self._parts[lo:hi], self._N)
 
 
+class ShardedFacts:
+    """``kb_adj_mat`` of a batch of which THIS RANK built only its own questions (``patch_loader(..., shard=(rank,
+    world))``): under question sharding (``shard.shard_model``) a rank's forward reads the facts of its contiguous
+    question range only, so building the global batch's tuple on every rank and dropping (world - 1) / world of it is
+    wasted host time.  ``facts_per_question`` (all B questions: known from the loader without building
+    anything) and ``ranges`` (the fact-balanced split every rank derives identically) are what ``shard.shard_ranges``
+    reads; ``shard(lo, hi)`` hands out the local tuple for this rank's own range and refuses any other.  Anything that
+    indexes it like the reference's 7-tuple is told what it is holding."""
+
+    def __init__(self, local, facts_per_question, ranges, rank):
+        self.local, self.facts_per_question, self.ranges, self.rank = local, facts_per_question, ranges, rank
+
+    def __len__(self):
+        return 7
+
+    def shard(self, lo: int, hi: int):
+        if (lo, hi) != tuple(self.ranges[self.rank]):
+            raise ValueError("rank-local batch: rank %d built questions [%d, %d) only, [%d, %d) was asked for"
+                             % ((self.rank,) + tuple(self.ranges[self.rank]) + (lo, hi)))
+        return self.local
+
+    def __getitem__(self, k):
+        raise TypeError("rank-local batch (fact_mat.ShardedFacts): only this rank's questions were built - run the model "
+                        "through shard.shard_model, or patch the loader without shard=")
+
+    __iter__ = None
+
+
 def _cat_blocks(blocks, sizes, N):
     """Per-question [3, F_g] int32 blocks (question-local node ids) -> the batch's [3, F] block with node offsets."""
     import torch
@@ -394,8 +422,19 @@ class StructurePrefetcher:
         return bf
 
 
+def question_fact_counts(loader, sample_ids) -> np.ndarray:
+    """F_g of every question of a batch WITHOUT building its tuple: stored facts + self loops
+    (``dataset_load.py:486,499-506``).  ``data_eff`` loaders build a question's facts on the fly - None (no cheap count)."""
+    if loader.data_eff:
+        return None
+    n = np.array([len(loader.kb_adj_mats[int(s)][0]) for s in sample_ids], dtype=np.int64)
+    if loader.use_self_loop:
+        n += np.array([len(loader.global2local_entity_maps[int(s)]) for s in sample_ids], dtype=np.int64)
+    return n
+
+
 def patch_loader(loader, cache: bool = False, keep_rng_stream: bool = False, device=None, structures: bool = False,
-                 prefetch: bool = False):
+                 prefetch: bool = False, shard=None):
     """Rebinds ``loader._build_fact_mat`` to the vectorised builder (the reference file is untouched).
     ``cache=True`` additionally serves ``fact_dropout == 0`` batches from a :class:`FactCache`.  The cached
     path does not draw the per-question ``np.random.permutation`` the reference draws even without dropout
@@ -407,7 +446,9 @@ def patch_loader(loader, cache: bool = False, keep_rng_stream: bool = False, dev
     the MI355X modules only).  ``structures`` (with ``device``): also cache every question's sorted structure on the GPU,
     so that a batch's structure is a concatenation (:class:`DeviceStructureCache`).  ``prefetch`` (with ``device``): the
     next batch's tuple and structure are built by a worker thread on a side stream while the current batch runs
-    (:class:`StructurePrefetcher`)."""
+    (:class:`StructurePrefetcher`).  ``shard=(rank, world)`` (with ``cache``; evaluation under ``shard.shard_model``):
+    a ``fact_dropout == 0`` batch of at least ``world`` questions is built for THIS RANK's fact-balanced question range
+    only and handed out as :class:`ShardedFacts`."""
     fc = None
     if cache:
         if device is not None and structures:
@@ -423,6 +464,13 @@ def patch_loader(loader, cache: bool = False, keep_rng_stream: bool = False, dev
                 for sample_id in sample_ids:
                     n = len(self.create_kb_adj_mats(sample_id)[0]) if self.data_eff else len(self.kb_adj_mats[sample_id][0])
                     np.random.permutation(n)                                   # dataset_load.py:489
+            if shard is not None and len(sample_ids) >= shard[1]:
+                counts = question_fact_counts(self, sample_ids)
+                if counts is not None:
+                    from ..shard import balanced_ranges
+                    ranges = balanced_ranges(counts, shard[1])
+                    lo, hi = ranges[shard[0]]
+                    return ShardedFacts(fc.batch(sample_ids[lo:hi]), counts, ranges, shard[0])
             if pf is not None:
                 return pf.get(sample_ids)
             return fc.batch(sample_ids)

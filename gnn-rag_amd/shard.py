@@ -58,6 +58,9 @@ def balanced_ranges(weights, world: int):
 
 def facts_per_question(edge_tuple, B: int) -> np.ndarray:
     """F_g: facts (typed edges + self loops) of every question of a batch tuple."""
+    known = getattr(edge_tuple, "facts_per_question", None)       # data/fact_mat.ShardedFacts: counted, not built
+    if known is not None:
+        return np.asarray(known)[:B]
     return np.bincount(np.asarray(edge_tuple[3]).astype(np.int64), minlength=B)[:B]
 
 
@@ -84,6 +87,9 @@ def shard_ranges(batch: tuple, world: int, balance: str = "facts"):
     (every rank derives the same split from the batch tuple it already holds - no communication), ``"count"`` the
     number of questions."""
     B = batch[0].shape[0]
+    decided = getattr(batch[2], "ranges", None)        # data/fact_mat.ShardedFacts: the loader already split this batch
+    if decided is not None and len(decided) == world:
+        return [tuple(r) for r in decided]
     if balance == "count":
         return [question_range(B, r, world) for r in range(world)]
     if balance != "facts":

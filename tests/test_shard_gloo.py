@@ -143,6 +143,26 @@ def test_bench_distributed_skeleton_world2():
     assert out["gathered_matches_unsharded"] is True
 
 
+def test_bench_self_launches_its_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` as the driver may call it - no torchrun, WORLD_SIZE unset: bench.py starts its two
+    ranks itself (torch.distributed.run on 127.0.0.1), rank 0 prints the ONE JSON line, the return code is the ranks'."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--dry-run-cpu", "--scaling", "strong"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["gathered_matches_unsharded"] is True
+    # a failing rank must fail the launcher (rc propagates)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--dry-run-cpu", "--workload", "no-such-workload-for-rc"], env=dict(env, GNNRAG_DRYRUN_FAIL="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+
+
 REF = "/root/reference/gnn"
 
 
@@ -188,6 +208,66 @@ def test_sharded_reference_model_world2():
         assert p.exitcode == 0
     for rank, ok, err in res:
         assert ok, "rank %d: sharded forward differs (max err %g)" % (rank, err)
+
+
+def _rank_local_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        import test_dropin_with_reference as td
+        from gnnrag_amd import shard
+        from gnnrag_amd.data import fact_mat
+        args, dataset, model = td.build_reference_setup()
+        test = dataset["test"]
+        test.reset_batches(is_sequential=True)
+        fact_mat.patch_loader(test, cache=True)
+        full_batch = test.get_batch(0, 5, fact_dropout=0.0, test=True)
+        with torch.no_grad():
+            loss_ref, pred_ref, dist_ref, _ = model(full_batch[:-1])
+        fact_mat.patch_loader(test, cache=True, shard=(rank, world))
+        batch = test.get_batch(0, 5, fact_dropout=0.0, test=True)
+        sf = batch[2]
+        lo, hi = sf.ranges[rank]
+        built = len(sf.local[0])
+        want = int(shard.facts_per_question(full_batch[2], 5)[lo:hi].sum())
+        try:
+            sf[0]
+            refused = False
+        except TypeError:
+            refused = True
+        with torch.no_grad():
+            shard.shard_model(model)
+            loss, pred, full, _ = model(batch[:-1])
+        ok = (isinstance(sf, fact_mat.ShardedFacts) and built == want and refused
+              and np.array_equal(sf.facts_per_question, shard.facts_per_question(full_batch[2], 5))
+              and float((full - dist_ref).abs().max()) <= 1e-6 and torch.equal(pred, pred_ref)
+              and abs(float(loss) - float(loss_ref)) <= 1e-5 * max(1.0, abs(float(loss_ref))))
+        q.put((rank, bool(ok), float((full - dist_ref).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="live reference not available")
+def test_rank_builds_only_its_own_questions_world2():
+    """`patch_loader(..., shard=(rank, world))`: every rank builds the tuple of ITS fact-balanced question range only
+    (`fact_mat.ShardedFacts`: exactly that range's facts, the whole batch's counts known without building), and the live
+    reference ReaRev behind `shard.shard_model` returns the unsharded pred_dist / pred / loss on both gloo ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_local_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, err in res:
+        assert ok, "rank %d: rank-local batch differs (max err %g)" % (rank, err)
 
 
 def _train_worker(rank, world, port, q):
