@@ -77,8 +77,9 @@ def main():
     ap.add_argument("--launch", choices=["eager", "graph"], default="eager",
                     help="eager: one gnnrag_reason_stack call per step; graph: the step captured once as a hipGraph "
                          "(gnnrag_reason_stack_capture) and replayed")
-    ap.add_argument("--cpu-sample-b", type=int, default=16,
-                    help="questions of the CPU-baseline sample (the reference's own layer on the host cores; 64 = the full C2 batch)")
+    ap.add_argument("--cpu-sample-b", type=int, default=None,
+                    help="questions of the CPU-baseline sample (the reference's own layer on the host cores); default: the "
+                         "workload's whole per-GPU batch up to 64 questions of C2 size (C2: all 64), 4 for the larger shapes")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the end-to-end block (unmodified main.py --is_eval on the staged dataset, GPU and CPU)")
     ap.add_argument("--clock-ramp-ms", type=float, default=600.0,
@@ -293,7 +294,7 @@ def main():
     # (single process only: `step` enqueues the ranks' all-gather when a process group is up - rank 0 alone must not call it)
     if rank == 0 and not distributed and graph is None and not strong and not os.environ.get("BENCH_SKIP_STRUCTURE_TIMING"):
         try:
-            overlapped = overlapped_build_ms(batch, dev, step, 48)
+            overlapped = build_plus_step_ms(batch, dev, step, 48)
         except Exception as e:                       # never fail the bench on the side measurement
             overlapped = {"error": repr(e)[:300]}
 
@@ -327,11 +328,11 @@ def main():
         # host-buffer boundary: int64 tuple -> int32 upload over PCIe + device structure build, once per batch,
         # amortised over ONE step (a ReaRev forward runs num_iter steps on the same structure); never `value`
         "value_incl_upload_and_build": typed_edges / (elapsed / args.steps + csr_build_ms * 1e-3),
-        # the same with the next batch's structure built by a worker thread on a side stream
-        # while this batch's step runs (device fact cache, a fresh structure every step)
-        "structure_build_overlapped": overlapped,
-        "value_incl_overlapped_build": (typed_edges / (overlapped["ms_per_build_plus_step_prefetched"] * 1e-3)
-                                        if overlapped and "ms_per_build_plus_step_prefetched" in overlapped else None),
+        # a fresh structure every step, built in line from the device fact cache WITHOUT a stream wait (the cache knows the
+        # relation counts): build + step in one loop
+        "structure_build_in_line": overlapped,
+        "value_incl_device_cache_build": (typed_edges / (overlapped["ms_per_build_plus_step"] * 1e-3)
+                                          if overlapped and "ms_per_build_plus_step" in overlapped else None),
         "dense_math": math_name,
         "pre_run": ("%.0f ms of HBM copy kernels and dummy matrix products before the warm-up steps (clock ramp of an idle chip; not steps, nothing of "
                     "the workload is computed or cached)" % args.clock_ramp_ms) if args.clock_ramp_ms > 0 else None,
@@ -344,7 +345,10 @@ def main():
     if rank == 0:
         out.update(roofline_leg(cfg, layer, devin, ops, F_g, args.steps))
         if not args.no_cpu_baseline and world == 1:     # rank 0 at N = 1 only (the other ranks would idle)
-            out["cpu_baseline"] = cpu_baseline_leg(cfg, args.cpu_sample_b)
+            sample_b = args.cpu_sample_b
+            if sample_b is None:     # ~0.8 M facts per pass is ~10 s on the host cores: C2's whole batch, 4 questions of C5
+                sample_b = max(1, min(cfg.B, int(64 * 12000 // max(F_g, 1)), 64))
+            out["cpu_baseline"] = cpu_baseline_leg(cfg, min(sample_b, cfg.B))
         if not args.no_e2e and not args.no_cpu_baseline and world == 1:
             try:
                 out["e2e"] = e2e_leg()
@@ -403,7 +407,9 @@ def cached_structure_ms(batch, dev, ops):
     t0 = time.perf_counter()
     for _ in range(3):
         bf = fc.batch(ids)
-        ops.CsrPlan(bf[0], bf[1], bf[2], cfg.B, cfg.N, cfg.R1, dev, validate=False, hrt_device=bf.hrt_device)
+        ops.CsrPlan(bf[0], bf[1], bf[2], cfg.B, cfg.N, cfg.R1, dev, validate=False, hrt_device=bf.hrt_device,
+                    rel_counts=bf.rel_counts)
+    cached_host_ms = (time.perf_counter() - t0) * 1e3 / 3   # the call no longer waits for its stream: host time to enqueue
     torch.cuda.synchronize()
     cached_ms = (time.perf_counter() - t0) * 1e3 / 3
     # per-question sorted STRUCTURES on the GPU, batch = concatenation with offsets (gnnrag_csr_concat)
@@ -418,15 +424,14 @@ def cached_structure_ms(batch, dev, ops):
     host_ms = (time.perf_counter() - t0) * 1e3 / 5      # the call does not wait for the stream: host time to enqueue
     torch.cuda.synchronize()
     wall_ms = (time.perf_counter() - t0) * 1e3 / 5
-    return cached_ms, {"host_enqueue_ms": host_ms, "wall_ms_incl_device": wall_ms}
+    return {"host_enqueue_ms": cached_host_ms, "wall_ms_incl_device": cached_ms}, {"host_enqueue_ms": host_ms, "wall_ms_incl_device": wall_ms}
 
 
-def overlapped_build_ms(batch, dev, step, steps):
-    """First-pass structure build OFF the critical path (``data/fact_mat.StructurePrefetcher``): while the step of batch k
-    runs, a worker thread assembles batch k + 1's tuple from the device-resident fact cache and builds its structure on a
-    side stream; the caller only waits for the build's event.  Every iteration requests a NEW batch from the loader (all
-    cache hits on the questions' id blocks, never on a structure): wall clock per (build + step) pair, and the same loop
-    with the build in line for comparison."""
+def build_plus_step_ms(batch, dev, step, steps):
+    """A fresh structure for EVERY step, built in line from the device-resident fact cache (what an evaluation run's first
+    pass over a split pays per batch): the cache knows each question's relation count, so the build is told the counts and
+    only ENQUEUES its kernels (gnnrag_csr_build_counts: no wait for the stream) - the host runs ahead of the GPU and the
+    build's kernels queue behind the previous step's.  Wall clock per (build + step) pair."""
     import torch
     from gnnrag_amd.data import fact_mat
     from gnnrag_amd.modules.kg_reasoning.base_gnn import plan_for
@@ -444,26 +449,23 @@ def overlapped_build_ms(batch, dev, step, steps):
         num_data = cfg.B * reps
         batches = np.arange(cfg.B * reps)
 
-    out = {}
-    for mode in ("in_line", "prefetched"):
-        ld = _Loader()
-        fact_mat.patch_loader(ld, cache=True, device=dev, prefetch=(mode == "prefetched"))
-        for r in range(reps):                          # first use uploads the questions' blocks
-            ld._build_fact_mat(np.arange(r * cfg.B, (r + 1) * cfg.B), 0.0)
-        torch.cuda.synchronize()
-        n = 0
-        t0 = time.perf_counter()
-        for _ in range(max(1, steps // reps)):
-            for r in range(reps):
-                bf = ld._build_fact_mat(np.arange(r * cfg.B, (r + 1) * cfg.B), 0.0)
-                plan_for(bf, cfg.B, cfg.N, cfg.R1, dev)
-                step()
-                n += 1
-        torch.cuda.synchronize()
-        out[mode] = (time.perf_counter() - t0) * 1e3 / n
-    return {"ms_per_build_plus_step_in_line": out["in_line"], "ms_per_build_plus_step_prefetched": out["prefetched"],
-            "note": "device-resident fact cache; every iteration builds a fresh structure; prefetched = worker thread + side "
-                    "stream one batch ahead (GNNRAG_PREFETCH=1 in tools/run_reference.py)"}
+    ld = _Loader()
+    fact_mat.patch_loader(ld, cache=True, device=dev)
+    for r in range(reps):                              # first use uploads the questions' blocks
+        ld._build_fact_mat(np.arange(r * cfg.B, (r + 1) * cfg.B), 0.0)
+    torch.cuda.synchronize()
+    n = 0
+    t0 = time.perf_counter()
+    for _ in range(max(1, steps // reps)):
+        for r in range(reps):
+            bf = ld._build_fact_mat(np.arange(r * cfg.B, (r + 1) * cfg.B), 0.0)
+            plan_for(bf, cfg.B, cfg.N, cfg.R1, dev)
+            step()
+            n += 1
+    torch.cuda.synchronize()
+    return {"ms_per_build_plus_step": (time.perf_counter() - t0) * 1e3 / n,
+            "note": "device-resident fact cache; every iteration builds a fresh structure in line; the build is told the "
+                    "relation counts (gnnrag_csr_build_counts) and does not wait for its stream"}
 
 
 def strong_shard(gbatch, gfeats, rank, world):
@@ -878,11 +880,9 @@ def e2e_leg():
                     "relation types for d50, 12 for d200)",
            "host_cores": ncpu}
     out["d200_batch16"] = {"gpu": run("d200", False, 16),
-                           # the next batch's tuple + structure built by a worker thread on a side stream (StructurePrefetcher)
-                           "gpu_prefetch": run("d200", False, 16, extra_env={"GNNRAG_PREFETCH": "1"}),
                            # the same with the question encoder's nn.LSTM left to torch / MIOpen (GNNRAG_HIP_LSTM=0: MIOpen's
                            # RNN call is ~12 ms at these shapes, twice per batch; default: gnnrag_lstm_forward)
-                           "gpu_prefetch_miopen_lstm": run("d200", False, 16, extra_env={"GNNRAG_PREFETCH": "1", "GNNRAG_HIP_LSTM": "0"}),
+                           "gpu_miopen_lstm": run("d200", False, 16, extra_env={"GNNRAG_HIP_LSTM": "0"}),
                            "cpu_reference_sample32": run("d200", True, 16, True)}
     # BASELINE config 2's batch (64 questions per forward): the host's per-batch costs spread over four times the questions
     out["d200_batch64"] = {"gpu": run("d200", False, 64)}
@@ -937,7 +937,7 @@ def reference_cpu_leg(cfg, sample_b):
 
     ncpu = os.cpu_count() or 1
     best = None
-    for nt in sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu}):
+    for nt in sorted({c for c in (16, 32, 64) if c <= ncpu} or {ncpu}):
         torch.set_num_threads(nt)
         _, dt = one_pass()
         if best is None or dt < best[0]:
@@ -1009,7 +1009,7 @@ def port_cpu_leg(cfg, sample_b):
     # torch-CPU does not scale to every core of a big host (256 threads ran 2x slower than 32 on
     # the GPU box): probe a few thread counts on one pass each and keep the fastest
     best = None
-    for nt in sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu}):
+    for nt in sorted({c for c in (16, 32, 64) if c <= ncpu} or {ncpu}):
         torch.set_num_threads(nt)
         t0 = time.perf_counter()
         one_pass()

@@ -55,6 +55,9 @@ SIGNATURES = {
     "gnnrag_csr_scratch_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "gnnrag_csr_build": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                    _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(CsrStruct), _VP]),
+    "gnnrag_csr_build_counts": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                          C.c_int32, _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(CsrStruct), _VP]),
+    "gnnrag_csr_status": (C.c_int, [C.POINTER(CsrStruct), _VP]),
     "gnnrag_csr_concat": (C.c_int, [C.POINTER(C.POINTER(CsrStruct)), C.c_int32, C.c_int32, C.c_int32, _VP, C.c_size_t,
                                     C.POINTER(CsrStruct), _VP]),
     "gnnrag_narrow_tuple": (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, C.c_int32]),
@@ -125,7 +128,7 @@ SIGNATURES = {
     "gnnrag_error_string": (C.c_char_p, [C.c_int]),
 }
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 PATH_AUTO, PATH_UNFUSED, PATH_FUSED = 0, 1, 2
 PATH_ONLY_FWD, PATH_ONLY_INV = 0x10, 0x20        # OR-ed into the path: one-direction layers (NSM)
 PATH_SEED_PRIOR = 0x40                           # OR-ed into the path: the (first layer's) prior is a seed distribution

@@ -1107,6 +1107,9 @@ __global__ __launch_bounds__(1024) void k_hub_finish(const WalkArgs a) {
 #define GNNRAG_SLICE_ABL 0      // timing-only ablations of k_walk_slice (wrong results): 1 no table staging loads,
 #endif                          // 2 no output stores, 8 no (p, rel) pair loads
 constexpr int kSliceW = 16;                 // floats per slice (4 lanes x float4)
+#ifndef GNNRAG_SLICE_NAMED
+#define GNNRAG_SLICE_NAMED 0          // 1: three named pipeline stages, the set loop written out three times (no stage copies)
+#endif
 #ifndef GNNRAG_SLICE_THREADS
 #define GNNRAG_SLICE_THREADS 1024     // threads per LDS-walk workgroup (two workgroups per CU either way: the table slices fill its LDS)
 #endif
@@ -1498,7 +1501,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? GNNRAG_SLICE_W
   // pipelined three deep: while set i is walked, the first pairs of set i+1 and the row pointers of
   // set i+2 are in flight.  A row is walked 8 facts per step (two 32-byte coalesced accesses per
   // group), the next step requested before the current one is consumed.
-  auto next_set = [&]() {
+  auto next_set = [&]() __attribute__((always_inline)) {
     for (;;) {
       int t = 0;
       if (lane == 0) t = atomicAdd(&ctl[0], 1);
@@ -1525,29 +1528,20 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? GNNRAG_SLICE_W
       }
     }
   };
-  SetRows s0, s1, s2;
-  int t0 = next_set();
-  set_load_rows<MG>(s0, a, g, t0, nsets, grp);
-  int t1 = t0 < nsets ? next_set() : nsets;
-  set_load_rows<MG>(s1, a, g, t1, nsets, grp);
-  set_load_first<MG>(s0, prd, sub, Rg);
-  while (t0 < nsets) {
-    const int t2 = t1 < nsets ? next_set() : nsets;
-    set_load_rows<MG>(s2, a, g, t2, nsets, grp);
-    set_load_first<MG>(s1, prd, sub, Rg);
-
-    if (s0.valid && s0.big && nlist == 0) {     // no list for this question: the owner group walks it
-      s0.big = false;
-      set_load_first<MG>(s0, prd, sub, Rg);
+  // the walk of one light set
+  auto walk_set = [&](SetRows& c) __attribute__((always_inline)) {
+    if (c.valid && c.big && nlist == 0) {     // no list for this question: the owner group walks it
+      c.big = false;
+      set_load_first<MG>(c, prd, sub, Rg);
     }
-    if (s0.valid && !s0.big) {
+    if (c.valid && !c.big) {
       Acc acc;
       acc.zero();
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
         if (MG && d == 1) continue;             // merged rows: one run per node
-        const int beg = s0.beg[d], len = s0.len[d];
-        int2 c0 = s0.first[d][0], c1 = s0.first[d][1];
+        const int beg = c.beg[d], len = c.len[d];
+        int2 c0 = c.first[d][0], c1 = c.first[d][1];
         int j = 0;
         if (MG) {
           // first step peeled: its successor's pairs are already here (set_load_first requested them a set ago)
@@ -1555,8 +1549,8 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? GNNRAG_SLICE_W
             slice_fma4<MODE, NI>(acc, c0, Td[d], q);
             if (!GNNRAG_SLICE_HALFSTEP || __ballot(4 < len)) slice_fma4<MODE, NI>(acc, c1, Td[d], q);
           }
-          c0 = s0.second[0];
-          c1 = s0.second[1];
+          c0 = c.second[0];
+          c1 = c.second[1];
           j = 8;
         }
         for (; j < len; j += 8) {
@@ -1574,14 +1568,53 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? GNNRAG_SLICE_W
 #pragma unroll
           for (int i = 0; i < NA; ++i)
             if (col_ok[i] && (!(GNNRAG_SLICE_ABL & 2) || acc.v[i][0] == 1234.5f))
-              *reinterpret_cast<f32x4*>(slice_out<MODE>(a, s0.n, i, d, col0 + Acc::coff(i) + 4 * sub)) = acc.v[i];
+              *reinterpret_cast<f32x4*>(slice_out<MODE>(a, c.n, i, d, col0 + Acc::coff(i) + 4 * sub)) = acc.v[i];
           acc.zero();
         }
       }
     }
+  };
+#if GNNRAG_SLICE_NAMED
+  // Three NAMED pipeline stages, the set loop written out three times with the roles rotated: no stage is ever copied
+  // into another (round 4 found every vector-memory wait of this kernel to be vmcnt(0) because `s0 = s1; s1 = s2` copies
+  // registers whose loads are still in flight, which makes the compiler wait for all of them).
+  SetRows sa, sb, sc;
+  int ta = next_set();
+  set_load_rows<MG>(sa, a, g, ta, nsets, grp);
+  int tb = ta < nsets ? next_set() : nsets;
+  set_load_rows<MG>(sb, a, g, tb, nsets, grp);
+  set_load_first<MG>(sa, prd, sub, Rg);
+  int tc = nsets;
+  auto stage = [&](SetRows& cur, SetRows& nxt, SetRows& nn, const int tnxt, int& tnn) __attribute__((always_inline)) {
+    tnn = tnxt < nsets ? next_set() : nsets;
+    set_load_rows<MG>(nn, a, g, tnn, nsets, grp);
+    set_load_first<MG>(nxt, prd, sub, Rg);
+    walk_set(cur);
+  };
+  for (;;) {
+    if (ta >= nsets) break;
+    stage(sa, sb, sc, tb, tc);
+    if (tb >= nsets) break;
+    stage(sb, sc, sa, tc, ta);
+    if (tc >= nsets) break;
+    stage(sc, sa, sb, ta, tb);
+  }
+#else
+  SetRows s0, s1, s2;
+  int t0 = next_set();
+  set_load_rows<MG>(s0, a, g, t0, nsets, grp);
+  int t1 = t0 < nsets ? next_set() : nsets;
+  set_load_rows<MG>(s1, a, g, t1, nsets, grp);
+  set_load_first<MG>(s0, prd, sub, Rg);
+  while (t0 < nsets) {
+    const int t2 = t1 < nsets ? next_set() : nsets;
+    set_load_rows<MG>(s2, a, g, t2, nsets, grp);
+    set_load_first<MG>(s1, prd, sub, Rg);
+    walk_set(s0);
     s0 = s1; t0 = t1;
     s1 = s2; t1 = t2;
   }
+#endif
 }
 
 

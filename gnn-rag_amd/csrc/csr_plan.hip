@@ -784,6 +784,24 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
                                 const float* w_gnn, const float* w_rel, int64_t F, int32_t B, int32_t N,
                                 int32_t R1, void* csr_mem, size_t csr_bytes, void* scratch,
                                 size_t scratch_bytes, gnnrag_csr* out, gnnrag_stream_t stream_) {
+  return gnnrag_csr_build_counts(heads, rels, tails, w_gnn, w_rel, F, B, N, R1, -1, -1, csr_mem, csr_bytes, scratch,
+                                 scratch_bytes, out, stream_);
+}
+
+extern "C" int gnnrag_csr_status(const gnnrag_csr* csr, gnnrag_stream_t stream_) {
+  if (!csr || !csr->n_heavy) return GNNRAG_E_BADARG;
+  int32_t stats[3] = {0, 0, 0};     // rel_total, rel_max, validation error bits (as the build left them on the device)
+  GNNRAG_HIP(hipMemcpyAsync(stats, csr->n_heavy + 4, sizeof(stats), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+  GNNRAG_HIP(hipStreamSynchronize((hipStream_t)stream_));
+  if (stats[2]) return GNNRAG_E_TUPLE;
+  if (csr->F > 0 && (stats[0] != csr->rel_total || stats[1] != csr->rel_max)) return GNNRAG_E_BADARG;
+  return 0;
+}
+
+extern "C" int gnnrag_csr_build_counts(const int32_t* heads, const int32_t* rels, const int32_t* tails,
+                                       const float* w_gnn, const float* w_rel, int64_t F, int32_t B, int32_t N,
+                                       int32_t R1, int32_t rel_total, int32_t rel_max, void* csr_mem, size_t csr_bytes,
+                                       void* scratch, size_t scratch_bytes, gnnrag_csr* out, gnnrag_stream_t stream_) {
   if (!out || !csr_mem || B <= 0 || N <= 0 || R1 <= 0 || F < 0) return GNNRAG_E_BADARG;
   if (F > 0 && (!heads || !rels || !tails || !scratch)) return GNNRAG_E_BADARG;
   const int64_t BN = (int64_t)B * N;
@@ -915,7 +933,14 @@ extern "C" int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const
   hipLaunchKernelGGL(k_csr_big, dim3((int)((BN + 255) / 256)), dim3(256), 0, stream, out->row_ptr[0],
                      out->row_ptr[1], BN, N, (int32_t)kBigDeg, out->big_cnt, out->big_nodes);
   GNNRAG_LAUNCH_CHECK();
-  // the relation counts size the fused path's tables and launches: hand them to the host
+  // the relation counts size the fused path's tables and launches.  A caller that knows them (the per-question counts of
+  // a fact cache: sum and maximum) passes them in and the build does NOT wait for its stream; the device-side copies and
+  // the validation bits stay behind the structure for gnnrag_csr_status.
+  if (rel_total >= 0 && rel_max >= 0) {
+    out->rel_total = rel_total;
+    out->rel_max = rel_max;
+    return 0;
+  }
   int32_t stats[3] = {0, 0, 0};     // rel_total, rel_max, validation error bits
   GNNRAG_HIP(hipMemcpyAsync(stats, rel_stats, sizeof(stats), hipMemcpyDeviceToHost, stream));
   GNNRAG_HIP(hipStreamSynchronize(stream));

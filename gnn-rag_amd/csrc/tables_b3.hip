@@ -1119,6 +1119,10 @@ int update_b3_launch_f(const float* h, const float* nbr, const uint8_t* add_flag
                        int32_t D, int32_t ldw, hipStream_t stream, bool score_zeroed) {
   if (!update_b3_shape_ok(BN, D, ldw)) return GNNRAG_E_UNSUPPORTED;
   if ((((uintptr_t)h | (uintptr_t)nbr | (uintptr_t)W | (uintptr_t)h_out) & 15) != 0) return GNNRAG_E_UNSUPPORTED;
+  {   // hidden size 200: the 32x32x16 form (update_x32.hip)
+    const int rc = update_x32_launch_f(h, nbr, add_flag, W, b, w_s, b_s, mask, h_out, score, BN, D, ldw, stream, score_zeroed);
+    if (rc != GNNRAG_E_UNSUPPORTED) return rc;
+  }
   {   // hidden size 200: the register-resident form (update_wr.hip); it needs no zeroed score
     const int rc = update_wr_launch_f(h, nbr, add_flag, W, b, w_s, b_s, mask, h_out, score, BN, D, ldw, stream);
     if (rc != GNNRAG_E_UNSUPPORTED) return rc;

@@ -72,10 +72,13 @@ class _QuestionFacts:
     (``dataset_load.py:509-517``) - computed when first asked for: only ``normalized_gnn`` / ``norm_rel`` models read them,
     and the pair count behind the second is a sort over the question's facts."""
 
-    __slots__ = ("blk", "_w", "_wr")
+    __slots__ = ("blk", "_w", "_wr", "nrel")
 
     def __init__(self, blk):
         self.blk, self._w, self._wr = blk, None, None
+        # distinct relation ids among the question's facts (self loops included): what the device structure build counts
+        # per question - known here, so a batch's build can be told the counts instead of waiting for them
+        self.nrel = int(len(np.unique(blk[1]))) if blk.shape[1] else 0
 
     def __getitem__(self, k):
         if k == 0:
@@ -158,15 +161,16 @@ class BatchFacts:
     ``norm_rel``).  The reference's own modules cannot consume it (they build ``torch.LongTensor`` from numpy arrays):
     it is handed out only by ``patch_loader(..., device=...)``, i.e. next to ``install.swap``-ed modules."""
 
-    def __init__(self, hrt_device, sizes, parts, N, plans=None, make_hrt=None):
+    def __init__(self, hrt_device, sizes, parts, N, plans=None, make_hrt=None, checked=False):
         self._hrt, self._make_hrt = hrt_device, make_hrt
         self._sizes, self._parts, self._N = sizes, parts, N
+        # (rel_total, rel_max) of the batch for ops.CsrPlan(rel_counts=): only when every question's ids were range-checked
+        # on the host as it was cached (the build then skips its wait AND its read-back of the device-side validation)
+        self.rel_counts = ((sum(p.nrel for p in parts), max([p.nrel for p in parts] or [0])) if checked and parts else None)
         self._lazy = {}
         # DeviceStructureCache: the questions' cached single-question structures (ops.CsrPlan, B = 1), in batch order -
         # the modules then assemble the batch structure by concatenation (ops.CsrPlan.concat) instead of sorting
         self.plans = plans
-        # StructurePrefetcher: (finished ops.CsrPlan of this batch, the event recorded behind its build, (B, N, R1))
-        self.prebuilt = None
 
     @property
     def hrt_device(self):
@@ -215,7 +219,7 @@ class BatchFacts:
         if lo:
             hrt[0] -= lo * self._N
             hrt[2] -= lo * self._N
-        return BatchFacts(hrt, self._sizes[lo:hi], self._parts[lo:hi], self._N)
+        return BatchFacts(hrt, self._sizes[lo:hi], self._parts[lo:hi], self._N, checked=self.rel_counts is not None)
 
 
 class ShardedFacts:
@@ -282,7 +286,13 @@ class DeviceFactCache(FactCache):
             q = self._question(s_)
             d = self._dev.get(s_)
             if d is None:
-                d = torch.from_numpy(np.ascontiguousarray(q[0])).to(self.device)
+                blk = q[0]
+                if blk.shape[1] and (int(blk[0].min()) < 0 or int(blk[2].min()) < 0 or int(blk[1].min()) < 0
+                                     or int(blk[0].max()) >= N or int(blk[2].max()) >= N
+                                     or int(blk[1].max()) > self.loader.num_kb_relation):
+                    raise ValueError("question %d: node ids must lie in [0, %d), relation ids in [0, %d]"
+                                     % (s_, N, self.loader.num_kb_relation))
+                d = torch.from_numpy(np.ascontiguousarray(blk)).to(self.device)
                 if len(self._dev) < self.max_questions:
                     self._dev[s_] = d
             parts.append(q)
@@ -292,7 +302,7 @@ class DeviceFactCache(FactCache):
             hrt = _cat_blocks(blocks, sizes, N)
         else:
             hrt = torch.zeros((3, 0), dtype=torch.int32, device=self.device)
-        return BatchFacts(hrt, sizes, parts, N)
+        return BatchFacts(hrt, sizes, parts, N, checked=True)
 
 
 class DeviceStructureCache(DeviceFactCache):
@@ -350,78 +360,6 @@ class DeviceStructureCache(DeviceFactCache):
                           make_hrt=lambda: _cat_blocks([p._hrt[:, : p.F] for p in plans], sizes, N).to(self.device))
 
 
-class StructurePrefetcher:
-    """First-pass structure build OFF the critical path: while the GPU runs batch k, a worker
-    thread assembles batch k + 1's device-resident tuple and builds its structure on a SIDE STREAM (the build's one wait
-    for its stream - it hands the relation counts to the host - then blocks the worker, not the caller).  The batch
-    handed out carries the finished structure (``BatchFacts.prebuilt``); ``plan_for`` makes the caller's stream wait for
-    the build's event and uses it.  Evaluation order is known (``loader.batches``, dataset_load.py:599-603), so the next
-    batch is the next slice of the same size; anything else (a different slice, fact dropout) is simply built in line.
-    One batch ahead, one worker: results are bit-identical to the in-line build (same kernels, same inputs)."""
-
-    def __init__(self, loader, cache, device):
-        import concurrent.futures
-        import threading
-        import torch
-        self.loader, self.cache, self.device = loader, cache, torch.device(device)
-        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="gnnrag-prefetch")
-        self.lock = threading.Lock()
-        self.side = None
-        self.pending = None              # (key, future)
-        self.hits = self.misses = 0
-
-    @staticmethod
-    def _key(sample_ids):
-        return np.asarray(sample_ids, dtype=np.int64).tobytes()
-
-    def _build(self, sample_ids):
-        import torch
-        from .. import ops
-        with torch.cuda.device(self.device):
-            if self.side is None:
-                self.side = torch.cuda.Stream()
-            with torch.cuda.stream(self.side):
-                with self.lock:
-                    bf = self.cache.batch(sample_ids)
-                N = self.loader.max_local_entity
-                R1 = self.loader.num_kb_relation + 1
-                if bf.plans is not None:
-                    plan = ops.CsrPlan.concat(bf.plans, N, R1, self.device)
-                else:
-                    plan = ops.CsrPlan(None, None, None, len(sample_ids), N, R1, self.device, hrt_device=bf.hrt_device)
-                ev = torch.cuda.Event()
-                ev.record(self.side)
-        bf.prebuilt = (plan, ev, (len(sample_ids), N, R1))
-        return bf
-
-    def get(self, sample_ids):
-        key = self._key(sample_ids)
-        bf = None
-        if self.pending is not None:
-            pkey, fut = self.pending
-            self.pending = None
-            if pkey == key:
-                bf = fut.result()
-                self.hits += 1
-            else:
-                fut.result()                                   # an unexpected order: drop it (its device work first)
-                if self.side is not None:
-                    self.side.synchronize()
-        if bf is None:
-            self.misses += 1
-            with self.lock:
-                bf = self.cache.batch(sample_ids)
-        # the next slice of loader.batches, same size
-        ld = self.loader
-        batches = np.asarray(ld.batches)
-        n = len(sample_ids)
-        pos = np.flatnonzero(batches == sample_ids[0]) if n else np.zeros(0, np.int64)
-        if len(pos) and np.array_equal(batches[pos[0]: pos[0] + n], np.asarray(sample_ids)) and pos[0] + n < len(batches):
-            nxt = batches[pos[0] + n: pos[0] + 2 * n].copy()
-            self.pending = (self._key(nxt), self.pool.submit(self._build, nxt))
-        return bf
-
-
 def question_fact_counts(loader, sample_ids) -> np.ndarray:
     """F_g of every question of a batch WITHOUT building its tuple: stored facts + self loops
     (``dataset_load.py:486,499-506``).  ``data_eff`` loaders build a question's facts on the fly - None (no cheap count)."""
@@ -434,7 +372,7 @@ def question_fact_counts(loader, sample_ids) -> np.ndarray:
 
 
 def patch_loader(loader, cache: bool = False, keep_rng_stream: bool = False, device=None, structures: bool = False,
-                 prefetch: bool = False, shard=None):
+                 shard=None):
     """Rebinds ``loader._build_fact_mat`` to the vectorised builder (the reference file is untouched).
     ``cache=True`` additionally serves ``fact_dropout == 0`` batches from a :class:`FactCache`.  The cached
     path does not draw the per-question ``np.random.permutation`` the reference draws even without dropout
@@ -444,9 +382,7 @@ def patch_loader(loader, cache: bool = False, keep_rng_stream: bool = False, dev
     at the cost of most of the caching gain).  Use the plain cache for evaluation-only runs.  ``device``: keep the
     per-question id blocks on that GPU (:class:`DeviceFactCache`; the tuple is then a :class:`BatchFacts`, readable by
     the MI355X modules only).  ``structures`` (with ``device``): also cache every question's sorted structure on the GPU,
-    so that a batch's structure is a concatenation (:class:`DeviceStructureCache`).  ``prefetch`` (with ``device``): the
-    next batch's tuple and structure are built by a worker thread on a side stream while the current batch runs
-    (:class:`StructurePrefetcher`).  ``shard=(rank, world)`` (with ``cache``; evaluation under ``shard.shard_model``):
+    so that a batch's structure is a concatenation (:class:`DeviceStructureCache`).  ``shard=(rank, world)`` (with ``cache``; evaluation under ``shard.shard_model``):
     a ``fact_dropout == 0`` batch of at least ``world`` questions is built for THIS RANK's fact-balanced question range
     only and handed out as :class:`ShardedFacts`."""
     fc = None
@@ -455,8 +391,6 @@ def patch_loader(loader, cache: bool = False, keep_rng_stream: bool = False, dev
             fc = DeviceStructureCache(loader, device)
         else:
             fc = DeviceFactCache(loader, device) if device is not None else FactCache(loader)
-    pf = StructurePrefetcher(loader, fc, device) if (prefetch and fc is not None and device is not None) else None
-    loader._gnnrag_prefetcher = pf
 
     def build(self, sample_ids, fact_dropout):
         if fc is not None and fact_dropout == 0:
@@ -471,8 +405,6 @@ def patch_loader(loader, cache: bool = False, keep_rng_stream: bool = False, dev
                     ranges = balanced_ranges(counts, shard[1])
                     lo, hi = ranges[shard[0]]
                     return ShardedFacts(fc.batch(sample_ids[lo:hi]), counts, ranges, shard[0])
-            if pf is not None:
-                return pf.get(sample_ids)
             return fc.batch(sample_ids)
         return build_fact_mat(self, sample_ids, fact_dropout)
 

@@ -27,42 +27,44 @@ TOPP_MAX_N = 1 << 24    # the kernel takes any N (questions with > 16384 slots f
                         # workspace); beyond 2^24 slots the batch is left as it is and the reference's own loop walks it
 
 
+def _retrieved_arrays(pred_dist: torch.Tensor, local_entity: np.ndarray, query_entities: np.ndarray, pad_ent_id: int,
+                      ignore_prob: float, eps: float):
+    """One kernel, two small device -> host copies: (entity ids [B, K], probabilities [B, K] as a CPU tensor, retrieved
+    count [B], filter survivors [B]) with K = the largest retrieved count of the batch; slots behind a question's
+    count hold (pad entity, 0.0)."""
+    local_entity = np.asarray(local_entity)
+    # evaluate.py:177,198-205: the seed flags are compared after a cast to int64
+    eligible = (np.asarray(query_entities).astype(np.int64) != 1) & (local_entity != pad_ent_id)
+    el = torch.from_numpy(eligible.astype(np.uint8)).to(pred_dist.device)
+    pred_dist = pred_dist.detach().float().contiguous()
+    slots, cnt = ops.topp_candidates(pred_dist, el, ignore_prob, eps)
+    cnt_h = cnt.cpu().numpy()
+    K = max(1, int(cnt_h[:, 1].max()) if len(cnt_h) else 1)
+    head = slots[:, :K].long().clamp_(min=0)
+    live = torch.arange(K, device=pred_dist.device)[None, :] < cnt[:, 1:2].long()
+    probs = torch.where(live, torch.gather(pred_dist, 1, head), torch.zeros((), device=pred_dist.device)).cpu()
+    head_h, live_h = head.cpu().numpy(), (np.arange(K)[None, :] < cnt_h[:, 1:2])
+    ents = np.where(live_h, np.take_along_axis(local_entity, head_h, axis=1), pad_ent_id).astype(local_entity.dtype)
+    return ents, probs, cnt_h[:, 1].astype(np.int64), cnt_h[:, 0].astype(np.int64)
+
+
 def retrieved_candidates(pred_dist: torch.Tensor, local_entity: np.ndarray, query_entities: np.ndarray,
                          pad_ent_id: int, ignore_prob: float, eps: float):
     """Per question the list ``[(entity id, prob), ...]`` that ``f1_and_hits`` would retrieve, best first,
     and the number of candidates that passed the filter.  ``pred_dist`` stays on the GPU."""
-    # evaluate.py:177,198-205: the seed flags are compared after a cast to int64
-    eligible = (np.asarray(query_entities).astype(np.int64) != 1) & (np.asarray(local_entity) != pad_ent_id)
-    el = torch.from_numpy(eligible.astype(np.uint8)).to(pred_dist.device)
-    pred_dist = pred_dist.detach().float().contiguous()
-    slots, cnt = ops.topp_candidates(pred_dist, el, ignore_prob, eps)
-    cnt = cnt.cpu().numpy()
-    width = int(cnt[:, 1].max()) if len(cnt) else 0
-    head = slots[:, :max(width, 1)].long().clamp_(min=0)
-    probs = torch.gather(pred_dist, 1, head).cpu().numpy()                  # the few retrieved entries only
-    head = head.cpu().numpy()
-    out = []
-    for b in range(len(cnt)):
-        k = int(cnt[b, 1])
-        ids = np.asarray(local_entity)[b, head[b, :k]]
-        out.append(([(int(c), float(p)) for c, p in zip(ids, probs[b, :k])], int(cnt[b, 0])))
-    return out
+    ents, probs, k, passed = _retrieved_arrays(pred_dist, local_entity, query_entities, pad_ent_id, ignore_prob, eps)
+    probs = probs.numpy()
+    return [(list(zip(ents[b, :k[b]].tolist(), probs[b, :k[b]].tolist())), int(passed[b])) for b in range(len(k))]
 
 
 def compact_batch(pred_dist: torch.Tensor, local_entity: np.ndarray, query_entities: np.ndarray, pad_ent_id: int,
                   ignore_prob: float, eps: float):
     """(local_entity', query_entities', pred_dist') of width K = the largest retrieved count of the batch: per question
     the retrieved slots best first, then pad entities with probability 0 (the reference's filter skips them,
-    evaluate.py:201-202).  pred_dist' is a CPU tensor (the reference calls ``.tolist()`` on its rows)."""
-    picked = retrieved_candidates(pred_dist, local_entity, query_entities, pad_ent_id, ignore_prob, eps)
-    K = max(1, max(len(c) for c, _ in picked))
-    ents = np.full((len(picked), K), pad_ent_id, dtype=np.asarray(local_entity).dtype)
-    probs = torch.zeros((len(picked), K), dtype=torch.float32)
-    for b, (cand, _) in enumerate(picked):
-        if cand:
-            ents[b, :len(cand)] = [c for c, _ in cand]
-            probs[b, :len(cand)] = torch.tensor([p for _, p in cand], dtype=torch.float32)
-    return ents, np.zeros((len(picked), K), dtype=np.asarray(query_entities).dtype), probs
+    evaluate.py:201-202).  pred_dist' is a CPU tensor (the reference calls ``.tolist()`` on its rows).  No per-question
+    Python: one gather on the device, one ``take_along_axis`` on the host."""
+    ents, probs, _, _ = _retrieved_arrays(pred_dist, local_entity, query_entities, pad_ent_id, ignore_prob, eps)
+    return ents, np.zeros(ents.shape, dtype=np.asarray(query_entities).dtype), probs
 
 
 class _CompactingModel:

@@ -23,16 +23,6 @@ def plan_for(edge_list, B: int, N: int, R1: int, device) -> "ops.CsrPlan":
     key = (id(edge_list), B, N, R1, str(device))
     if _last_plan["key"] == key and _last_plan["tuple"] is edge_list:
         return _last_plan["plan"]
-    pre = getattr(edge_list, "prebuilt", None)            # data/fact_mat.StructurePrefetcher: built a batch ahead
-    if pre is not None and pre[2] == (B, N, R1):
-        plan, ev, _ = pre
-        cur = torch.cuda.current_stream(plan.device)
-        cur.wait_event(ev)                                # the side stream's build is ordered before this stream's use
-        for t in (plan._mem, getattr(plan, "_hrt_lazy", None)):
-            if t is not None:
-                t.record_stream(cur)                      # allocated under the side stream, used (and freed) under this one
-        _last_plan.update(key=key, plan=plan, tuple=edge_list)
-        return plan
     plans = getattr(edge_list, "plans", None)             # data/fact_mat.DeviceStructureCache: per-question structures
     hrt = None if plans is not None else getattr(edge_list, "hrt_device", None)   # BatchFacts: the id block is on the GPU
     if plans is not None and len(plans) == B and all(p.N == N and p.R1 == R1 for p in plans):
@@ -41,7 +31,9 @@ def plan_for(edge_list, B: int, N: int, R1: int, device) -> "ops.CsrPlan":
         hrt = edge_list.hrt_device
         plan = ops.CsrPlan(None, None, None, B, N, R1, hrt.device, hrt_device=hrt)
     elif hrt is not None:
-        plan = ops.CsrPlan(None, None, None, B, N, R1, hrt.device, hrt_device=hrt)
+        # a device fact cache knows every question's relation count: the build is told them and does not wait
+        rc = getattr(edge_list, "rel_counts", None) if R1 > 0 else None
+        plan = ops.CsrPlan(None, None, None, B, N, R1, hrt.device, hrt_device=hrt, rel_counts=rc)
     else:
         plan = ops.CsrPlan(edge_list[0], edge_list[1], edge_list[2], B, N, R1, device)
     _last_plan.update(key=key, plan=plan, tuple=edge_list)

@@ -88,7 +88,11 @@ class CsrPlan:
     Replaces ``BaseGNNLayer.build_matrix`` (``base_gnn.py:19-51``)."""
 
     def __init__(self, heads, rels, tails, B: int, N: int, R1: int, device, validate: bool = True,
-                 hrt_device: Optional[torch.Tensor] = None):
+                 hrt_device: Optional[torch.Tensor] = None, rel_counts=None):
+        """``rel_counts = (rel_total, rel_max)``: the sum and the maximum over the questions of the distinct relation ids
+        among a question's facts, when the caller knows them (a fact cache does: data/fact_mat.BatchFacts.rel_counts) -
+        the build then does NOT wait for its stream (``gnnrag_csr_build_counts``); ``status()`` runs the deferred
+        device-side validation whenever wanted."""
         lib = _lib.load()
         if hrt_device is not None:
             # the batch builder's [3, F] int32 block is already on the GPU (data/fact_mat.DeviceFactCache)
@@ -158,10 +162,13 @@ class CsrPlan:
             scratch = torch.empty(max(sbytes, 256), dtype=torch.uint8, device=self.device)
             self.c = _lib.CsrStruct()
             row = self._hrt
-            rc = lib.gnnrag_csr_build(
+            rt, rm = (-1, -1) if rel_counts is None else (int(rel_counts[0]), int(rel_counts[1]))
+            rc = lib.gnnrag_csr_build_counts(
                 row[0].data_ptr(), row[1].data_ptr(), row[2].data_ptr(), None, None,
-                F, B, N, R1, self._mem.data_ptr(), self._mem.numel(),
+                F, B, N, R1, rt, rm, self._mem.data_ptr(), self._mem.numel(),
                 scratch.data_ptr(), scratch.numel(), C.byref(self.c), _stream())
+            if rel_counts is not None:
+                scratch.record_stream(torch.cuda.current_stream())      # the build has not run yet: keep its scratch
             if rc == _lib.E_TUPLE:
                 raise ValueError("edge tuple out of range: node ids must lie in [0, B*N), relation ids in [0, R1), "
                                  "and a fact may not connect two different questions")
@@ -170,6 +177,15 @@ class CsrPlan:
         self._w = {}
         # compact relation rows: question b's tables are rows rel_off[b] : rel_off[b+1] of P[d]
         self.rel_total, self.rel_max = int(self.c.rel_total), int(self.c.rel_max)
+
+    def status(self) -> None:
+        """The deferred check of a structure built with ``rel_counts`` (waits for the stream once): raises ``ValueError``
+        for an invalid tuple, ``GnnragError`` when the counts passed in differ from what the device counted."""
+        rc = _lib.load().gnnrag_csr_status(C.byref(self.c), _stream())
+        if rc == _lib.E_TUPLE:
+            raise ValueError("edge tuple out of range: node ids must lie in [0, B*N), relation ids in [0, R1), "
+                             "and a fact may not connect two different questions")
+        _lib.check(rc, "gnnrag_csr_status (relation counts passed to the build differ from the device's)")
 
     @classmethod
     def concat(cls, parts, N: int, R1: int, device) -> "CsrPlan":

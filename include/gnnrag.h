@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GNNRAG_ABI_VERSION 14
+#define GNNRAG_ABI_VERSION 15
 
 #define GNNRAG_E_BADARG      (-1)  /* null pointer / negative size / inconsistent sizes   */
 #define GNNRAG_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set (see DESIGN)  */
@@ -117,6 +117,22 @@ int gnnrag_csr_build(const int32_t* heads, const int32_t* rels, const int32_t* t
                      int64_t F, int32_t B, int32_t N, int32_t R1,
                      void* csr_mem, size_t csr_bytes, void* scratch, size_t scratch_bytes,
                      gnnrag_csr* out, gnnrag_stream_t stream);
+
+/* gnnrag_csr_build WITHOUT the wait for the stream: the caller passes what the build would otherwise read back -
+ * rel_total = sum over the questions of the distinct relation ids among a question's facts, rel_max = the largest such
+ * count (a fact cache knows both per question when it caches it).  Everything is enqueued and
+ * the call returns; the tuple's validation bits and the device-side counts stay behind the structure and
+ * gnnrag_csr_status reads them back (one stream wait) whenever the caller wants the check.  Wrong counts are the
+ * caller's error: a too small rel_total makes the fused path's tables too short.  rel_total < 0 or rel_max < 0: the
+ * waiting form (= gnnrag_csr_build).  Replaces the same reference code (base_gnn.py:19-51). */
+int gnnrag_csr_build_counts(const int32_t* heads, const int32_t* rels, const int32_t* tails,
+                            const float* w_gnn, const float* w_rel,
+                            int64_t F, int32_t B, int32_t N, int32_t R1, int32_t rel_total, int32_t rel_max,
+                            void* csr_mem, size_t csr_bytes, void* scratch, size_t scratch_bytes,
+                            gnnrag_csr* out, gnnrag_stream_t stream);
+/* 0 when the structure's tuple passed the device-side validation and its relation counts equal the device's;
+ * GNNRAG_E_TUPLE / GNNRAG_E_BADARG otherwise.  Waits for `stream`. */
+int gnnrag_csr_status(const gnnrag_csr* csr, gnnrag_stream_t stream);
 
 /* The structure of a batch as the CONCATENATION of per-question structures that are already on the device (SURVEY.md
  * section 8 f-1: "cached per-question int32 CSR built once at load time, batch = concatenation with offsets").

@@ -148,37 +148,41 @@ def test_batch_structure_as_concatenation_of_cached_question_structures(shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("structures", [False, True], ids=["fact_cache", "structure_cache"])
-def test_prefetched_structure_is_the_in_line_structure(structures):
-    """First-pass structure build off the critical path (StructurePrefetcher): walking the loader's batches in order, every
-    batch after the first arrives with a structure a worker thread built on a side stream - bit-identical to the structure
-    built in line from the same tuple, and ``plan_for`` hands out exactly that object; an out-of-order request is built in
-    line (and still correct)."""
+def test_build_told_the_relation_counts_does_not_wait_and_is_the_same_structure():
+    """`gnnrag_csr_build_counts` (ABI 15): a device fact cache knows every question's distinct-relation count, so the
+    batch's build is told (rel_total, rel_max) and returns without waiting for its stream - bit-identical to the waiting
+    build of the same tuple (`plan_for` takes that form for a `BatchFacts`), `status()` confirms tuple and counts on the
+    device; wrong counts and an invalid tuple are reported by `status()`."""
     import torch
     import gnnrag_amd  # noqa: F401
-    from gnnrag_amd import ops
-    from gnnrag_amd.data.fact_mat import FactCache, patch_loader
+    from gnnrag_amd import _lib, ops
+    from gnnrag_amd.data.fact_mat import DeviceFactCache, FactCache
     from gnnrag_amd.modules.kg_reasoning.base_gnn import plan_for
     dev = torch.device("cuda", 0)
-    ld = _StubLoader(np.random.default_rng(21), n_q=23, N=400, num_rel=30)
-    ld.num_data = 23
-    ld.batches = np.arange(23)
-    host = FactCache(ld)
-    patch_loader(ld, cache=True, device=dev, structures=structures, prefetch=True)
-    N, R1, bs = ld.max_local_entity, ld.num_kb_relation + 1, 4
-    order = [list(range(s, min(s + bs, 23))) for s in range(0, 23, bs)]
-    for k, ids in enumerate(order + [order[2], order[0]]):                    # then two out-of-order requests
-        bf = ld._build_fact_mat(np.asarray(ids), 0.0)
-        a = host.batch(ids)
-        want = ops.CsrPlan(a[0], a[1], a[2], len(ids), N, R1, dev).to_host()
-        got_plan = plan_for(bf, len(ids), N, R1, dev)
-        if 0 < k < len(order):
-            assert bf.prebuilt is not None and got_plan is bf.prebuilt[0]     # built ahead by the worker
-        got = got_plan.to_host()
-        for key in want:
-            if key == "big":
-                assert all(np.array_equal(x, y) for x, y in zip(want[key], got[key]))
-            else:
-                np.testing.assert_array_equal(want[key], got[key], err_msg="%s (batch %d)" % (key, k))
-    pf = ld._gnnrag_prefetcher
-    assert pf.hits == len(order) - 1 and pf.misses == 3, (pf.hits, pf.misses)
+    ld = _StubLoader(np.random.default_rng(5), n_q=9, N=300, num_rel=40)
+    host, devc = FactCache(ld), DeviceFactCache(ld, dev)
+    N, R1 = ld.max_local_entity, ld.num_kb_relation + 1
+    ids = [0, 3, 3, 8, 5]
+    a, bf = host.batch(ids), devc.batch(ids)
+    want_plan = ops.CsrPlan(a[0], a[1], a[2], len(ids), N, R1, dev)
+    assert bf.rel_counts == (want_plan.rel_total, want_plan.rel_max)
+    got_plan = plan_for(bf, len(ids), N, R1, dev)
+    got_plan.status()
+    want, got = want_plan.to_host(), got_plan.to_host()
+    assert (got_plan.rel_total, got_plan.rel_max) == (want_plan.rel_total, want_plan.rel_max)
+    for key in want:
+        if key == "big":
+            assert all(np.array_equal(x, y) for x, y in zip(want[key], got[key]))
+        else:
+            np.testing.assert_array_equal(want[key], got[key], err_msg=key)
+    # counts that are not the device's
+    bad = ops.CsrPlan(None, None, None, len(ids), N, R1, dev, hrt_device=bf.hrt_device,
+                      rel_counts=(bf.rel_counts[0] + 1, bf.rel_counts[1]))
+    with pytest.raises(_lib.GnnragError):
+        bad.status()
+    # an invalid tuple (a fact across two questions) passes the no-wait build and fails the deferred check
+    hrt = bf.hrt_device.clone()
+    hrt[2, 0] = N + 1
+    bad = ops.CsrPlan(None, None, None, len(ids), N, R1, dev, hrt_device=hrt, rel_counts=bf.rel_counts)
+    with pytest.raises(ValueError):
+        bad.status()

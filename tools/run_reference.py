@@ -94,12 +94,10 @@ def main():
                         dev = torch.device("cuda", torch.cuda.current_device())
                     # GNNRAG_DEVICE_STRUCTURES=1: additionally every question's sorted structure stays on the GPU and a
                     # batch's structure is their concatenation (no per-batch sort)
-                    # GNNRAG_PREFETCH=1: the next batch's tuple + structure are built on a side stream by a worker thread
                     # more than one rank: a rank builds the tuple of ITS questions only (fact_mat.ShardedFacts)
                     rk = (int(os.environ.get("RANK", "0")), world) if (world > 1 and is_eval and split != "train") else None
                     patch_loader(dataset[split], cache=(split != "train"), keep_rng_stream=not is_eval, device=dev,
                                  structures=bool(os.environ.get("GNNRAG_DEVICE_STRUCTURES")) and dev is not None,
-                                 prefetch=os.environ.get("GNNRAG_PREFETCH") == "1" and dev is not None and rk is None,
                                  shard=rk)
             return dataset
 

@@ -72,6 +72,16 @@ VARIANTS = {
     "prio2": {"GNNRAG_UPD_PRIO": 2}, "prio2_desync80": {"GNNRAG_UPD_PRIO": 2, "GNNRAG_UPD_DESYNC": 80},
     "desync40": {"GNNRAG_UPD_DESYNC": 40}, "desync80": {"GNNRAG_UPD_DESYNC": 80}, "desync160": {"GNNRAG_UPD_DESYNC": 160},
     "split_trunc": {"GNNRAG_SPLIT_RN": 0},      # the truncation form of the exact 3-way bf16 split (rounds 1-2)
+    # round 5: the LDS walk with three named pipeline stages (no stage copies) at 1024 / 768 / 640 threads per workgroup
+    # (two workgroups per CU: 8 / 6 / 5 waves per SIMD, 64 / 80 / 96 registers)
+    "sl_named": {"GNNRAG_SLICE_NAMED": 1},
+    "sl_named_t768": {"GNNRAG_SLICE_NAMED": 1, "GNNRAG_SLICE_THREADS": 768, "GNNRAG_SLICE_WPE": 6},
+    "sl_named_t640": {"GNNRAG_SLICE_NAMED": 1, "GNNRAG_SLICE_THREADS": 640, "GNNRAG_SLICE_WPE": 5},
+    "sl_named_t640_g2": {"GNNRAG_SLICE_NAMED": 1, "GNNRAG_SLICE_THREADS": 640, "GNNRAG_SLICE_WPE": 5, "GNNRAG_SLICE_BL_GROUP": 2},
+    "sl_t768": {"GNNRAG_SLICE_THREADS": 768, "GNNRAG_SLICE_WPE": 6},
+    "sl_t640": {"GNNRAG_SLICE_THREADS": 640, "GNNRAG_SLICE_WPE": 5},
+    # round 5: the self-block update on 32x32x16 MFMAs (update_x32.hip) switched off at run time
+    "x32_off": {"__env__": {"GNNRAG_UPDATE_X32": "0"}},
     "vq_nolds": {"GNNRAG_VQ_ABL": 1}, "vq_noa": {"GNNRAG_VQ_ABL": 2}, "vq_nostage": {"GNNRAG_VQ_ABL": 4},
     "upd_nolds": {"GNNRAG_UPD_ABL": 1}, "upd_noa": {"GNNRAG_UPD_ABL": 2}, "upd_noadd": {"GNNRAG_UPD_ABL": 4},
     "upd_nostore": {"GNNRAG_UPD_ABL": 8}, "upd_nosplit": {"GNNRAG_UPD_ABL": 16}, "upd_mfma_only": {"GNNRAG_UPD_ABL": 31},
