@@ -82,6 +82,10 @@ VARIANTS = {
     "sl_t640": {"GNNRAG_SLICE_THREADS": 640, "GNNRAG_SLICE_WPE": 5},
     # round 5: the self-block update on 32x32x16 MFMAs (update_x32.hip) switched off at run time
     "x32_off": {"__env__": {"GNNRAG_UPDATE_X32": "0"}},
+    "x32_f1": {"__env__": {"GNNRAG_UPDATE_X32": "1"}},       # form 1: two waves per SIMD
+    "x32_f2": {"__env__": {"GNNRAG_UPDATE_X32": "2"}},       # form 2: one wave per SIMD, source-pipelined, pinned interleave
+    "x1_valu2": {"GNNRAG_X1_VALU": 2, "GNNRAG_X32_DEFAULT": 2}, "x1_valu4": {"GNNRAG_X1_VALU": 4, "GNNRAG_X32_DEFAULT": 2},
+    "x1_valu6": {"GNNRAG_X1_VALU": 6, "GNNRAG_X32_DEFAULT": 2},
     "vq_nolds": {"GNNRAG_VQ_ABL": 1}, "vq_noa": {"GNNRAG_VQ_ABL": 2}, "vq_nostage": {"GNNRAG_VQ_ABL": 4},
     "upd_nolds": {"GNNRAG_UPD_ABL": 1}, "upd_noa": {"GNNRAG_UPD_ABL": 2}, "upd_noadd": {"GNNRAG_UPD_ABL": 4},
     "upd_nostore": {"GNNRAG_UPD_ABL": 8}, "upd_nosplit": {"GNNRAG_UPD_ABL": 16}, "upd_mfma_only": {"GNNRAG_UPD_ABL": 31},
