@@ -19,7 +19,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libgnnrag_hip.so")
 ARCH = "gfx950"
-SOURCES = ["csr_plan.hip", "aggregate.hip", "aggregate_bwd.hip", "gemm_f32.hip", "tables_b3.hip", "update_wr.hip", "update_x32.hip", "softmax_layer.hip", "rel_transform.hip", "gemm_tn.hip", "eval_tail.hip", "query_update.hip", "frontier.hip", "lstm.hip"]
+SOURCES = ["csr_plan.hip", "aggregate.hip", "aggregate_bwd.hip", "gemm_f32.hip", "tables_b3.hip", "softmax_layer.hip", "rel_transform.hip", "gemm_tn.hip", "eval_tail.hip", "query_update.hip", "frontier.hip", "lstm.hip"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(REPO, "include"),
          "-I" + CSRC, "-Wno-unused-result"]
 

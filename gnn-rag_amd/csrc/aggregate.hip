@@ -45,9 +45,6 @@
                                  // (4 per node and slice) lose to the gather walk's full 3200-byte rows, so it is off
 #endif
 
-#ifndef GNNRAG_LIGHT_ABL
-#define GNNRAG_LIGHT_ABL 0        // timing-only ablations of the gather walk (results wrong on purpose): 1 no table
-#endif                            // gathers, 2 no output stores, 4 all gathers from table rows 0..63 (L2 hits)
 #ifndef GNNRAG_SLICE_WIDE
 #define GNNRAG_SLICE_WIDE 1         // LDS walk: 32-column slices for questions whose tables allow two of them per CU
 #endif
@@ -134,9 +131,6 @@ struct WalkArgs {
                               // (gnnrag_csr::edge_m); direction 1's pairs carry table rows offset by Rg + 1
   const int2* edge_m;
   const int32_t* m_from;
-  const int32_t* m_dst;       // streaming walk: destination node of every merged record
-  float* stream_scratch;      // streaming walk: [workgroups][256 quads][2][16 NI] head / tail partial sums
-  size_t stream_scratch_bytes;
 };
 
 template <int MODE, int NI> struct AccN { static constexpr int n = (MODE == MODE_REASON) ? NI : 1; };
@@ -169,7 +163,7 @@ __device__ __forceinline__ void consume_batch(float p, int r, int cnt, const flo
   if constexpr (LPN == 64) {
     // one node per wave: (p, rel) of a fact are wave-uniform -> scalar control flow
     // The kernel is bound by the CU's vector-memory path (64 B / clk: an 800-byte table row is ~13 clocks of it, hit or
-    // miss - GNNRAG_LIGHT_ABL: all rows from L2-resident lines saves 10 %, no row loads 50 %), so a slot of the last,
+    // miss - timing ablations: all rows from L2-resident lines saves 10 %, no row loads 50 %), so a slot of the last,
     // partial round must not load anything: its load is skipped by a scalar branch, not fed a duplicate row.
     unsigned long long live = __ballot(p != 0.f);
     while (live) {
@@ -184,7 +178,6 @@ __device__ __forceinline__ void consume_batch(float p, int r, int cnt, const flo
           live &= live - 1;
           pj[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), j));
           rj[u] = __builtin_amdgcn_readlane(r, j);
-          if (GNNRAG_LIGHT_ABL & 4) rj[u] &= 63;
         } else {
           pj[u] = 0.f;          // padding: +0 * 0 leaves the sum unchanged
           rj[u] = 0;
@@ -195,13 +188,9 @@ __device__ __forceinline__ void consume_batch(float p, int r, int cnt, const flo
       for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int m = 0; m < CPL; ++m) {
-          if (GNNRAG_LIGHT_ABL & 1) {
-            t[u][m] = vsplat1(__int_as_float(rj[u]), V());
-          } else {
-            t[u][m] = vzero<VEC>();
-            if (lv[u]) {
-              if (cv[m]) t[u][m] = vload<VEC>(T + (size_t)rj[u] * D + col[m]);
-            }
+          t[u][m] = vzero<VEC>();
+          if (lv[u]) {
+            if (cv[m]) t[u][m] = vload<VEC>(T + (size_t)rj[u] * D + col[m]);
           }
         }
 #pragma unroll
@@ -440,7 +429,7 @@ __global__ __launch_bounds__(256) void k_walk_light(const WalkArgs a) {
         const bool fin = !(heavy[t][0] || heavy[t][1]);
 #pragma unroll
         for (int m = 0; m < CPL; ++m)
-          if (cv[m] && (!(GNNRAG_LIGHT_ABL & 2) || vfirst(acc[0][m]) == 12345.f)) {
+          if (cv[m]) {
             V v = acc[0][m];
             if (MODE == MODE_TYPE && fin) v = vrelu(v);
             vstore<VEC>(a.out + (size_t)n * D + col[m], v);   // (non-temporal stores: no difference, 756 vs 757 us at C5)
@@ -1103,13 +1092,7 @@ __global__ __launch_bounds__(1024) void k_hub_finish(const WalkArgs a) {
 #ifndef GNNRAG_SLICE_BL_GROUP
 #define GNNRAG_SLICE_BL_GROUP 1
 #endif
-#ifndef GNNRAG_SLICE_ABL
-#define GNNRAG_SLICE_ABL 0      // timing-only ablations of k_walk_slice (wrong results): 1 no table staging loads,
-#endif                          // 2 no output stores, 8 no (p, rel) pair loads
 constexpr int kSliceW = 16;                 // floats per slice (4 lanes x float4)
-#ifndef GNNRAG_SLICE_NAMED
-#define GNNRAG_SLICE_NAMED 0          // 1: three named pipeline stages, the set loop written out three times (no stage copies)
-#endif
 #ifndef GNNRAG_SLICE_THREADS
 #define GNNRAG_SLICE_THREADS 1024     // threads per LDS-walk workgroup (two workgroups per CU either way: the table slices fill its LDS)
 #endif
@@ -1206,7 +1189,7 @@ __device__ __forceinline__ void set_load_first(SetRows& s, const int2* const (&p
 #pragma unroll
     for (int h = 0; h < 2; ++h)
       s.first[d][h] = (s.valid && !s.big && 4 * h + sub < s.len[d])
-                          ? ((GNNRAG_SLICE_ABL & 8) ? make_int2(0x3f800000, sub) : prd[d][s.beg[d] + 4 * h + sub])
+                          ? prd[d][s.beg[d] + 4 * h + sub]
                           : make_int2(0, zr);          // no fact: prior 0, the table's zero row
   if (MG) {
     // a merged run holds ~12 records on average: nearly every 16-node set has a node with more than 8, and the second
@@ -1432,7 +1415,7 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? GNNRAG_SLICE_W
         dst[u] = live ? (int)(((size_t)d * (Rg + 1) + r) * SW + 4 * k) : -1;
         v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const float* tab = a.T[d] + (size_t)roff * D;
-        if (live && !(GNNRAG_SLICE_ABL & 1) && col0 + 4 * k < D) v[u] = *reinterpret_cast<const f32x4*>(tab + (size_t)r * D + col0 + 4 * k);
+        if (live && col0 + 4 * k < D) v[u] = *reinterpret_cast<const f32x4*>(tab + (size_t)r * D + col0 + 4 * k);
       }
 #pragma unroll
       for (int u = 0; u < UN; ++u)
@@ -1555,8 +1538,8 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? GNNRAG_SLICE_W
         }
         for (; j < len; j += 8) {
           int2 n0 = make_int2(0, Rg), n1 = make_int2(0, Rg);
-          if (!(GNNRAG_SLICE_ABL & 8) && j + 8 + sub < len) n0 = prd[d][beg + j + 8 + sub];
-          if (!(GNNRAG_SLICE_ABL & 8) && j + 12 + sub < len) n1 = prd[d][beg + j + 12 + sub];
+          if (j + 8 + sub < len) n0 = prd[d][beg + j + 8 + sub];
+          if (j + 12 + sub < len) n1 = prd[d][beg + j + 12 + sub];
           slice_fma4<MODE, NI>(acc, c0, Td[d], q);
           // second half of the step only if some node of the set still has facts there (most rows of the
           // inverse direction hold one or two facts)
@@ -1567,39 +1550,13 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? GNNRAG_SLICE_W
         if (ND == 2 || d == 1 || MG) {
 #pragma unroll
           for (int i = 0; i < NA; ++i)
-            if (col_ok[i] && (!(GNNRAG_SLICE_ABL & 2) || acc.v[i][0] == 1234.5f))
+            if (col_ok[i])
               *reinterpret_cast<f32x4*>(slice_out<MODE>(a, c.n, i, d, col0 + Acc::coff(i) + 4 * sub)) = acc.v[i];
           acc.zero();
         }
       }
     }
   };
-#if GNNRAG_SLICE_NAMED
-  // Three NAMED pipeline stages, the set loop written out three times with the roles rotated: no stage is ever copied
-  // into another (round 4 found every vector-memory wait of this kernel to be vmcnt(0) because `s0 = s1; s1 = s2` copies
-  // registers whose loads are still in flight, which makes the compiler wait for all of them).
-  SetRows sa, sb, sc;
-  int ta = next_set();
-  set_load_rows<MG>(sa, a, g, ta, nsets, grp);
-  int tb = ta < nsets ? next_set() : nsets;
-  set_load_rows<MG>(sb, a, g, tb, nsets, grp);
-  set_load_first<MG>(sa, prd, sub, Rg);
-  int tc = nsets;
-  auto stage = [&](SetRows& cur, SetRows& nxt, SetRows& nn, const int tnxt, int& tnn) __attribute__((always_inline)) {
-    tnn = tnxt < nsets ? next_set() : nsets;
-    set_load_rows<MG>(nn, a, g, tnn, nsets, grp);
-    set_load_first<MG>(nxt, prd, sub, Rg);
-    walk_set(cur);
-  };
-  for (;;) {
-    if (ta >= nsets) break;
-    stage(sa, sb, sc, tb, tc);
-    if (tb >= nsets) break;
-    stage(sb, sc, sa, tc, ta);
-    if (tc >= nsets) break;
-    stage(sc, sa, sb, ta, tb);
-  }
-#else
   SetRows s0, s1, s2;
   int t0 = next_set();
   set_load_rows<MG>(s0, a, g, t0, nsets, grp);
@@ -1614,33 +1571,9 @@ __global__ __launch_bounds__(kSliceThreads, (MODE == MODE_FUSED ? GNNRAG_SLICE_W
     s0 = s1; t0 = t1;
     s1 = s2; t1 = t2;
   }
-#endif
 }
 
 
-// ---- the streaming form of the fused LDS walk ---------------------------------------------------------------------------
-// k_walk_slice gives every node to a 4-lane group and walks 16 nodes of a wave in lockstep: a set's steps are set by its
-// longest row (half of the fact slots idle at Zipf degrees), every set costs a dependent chain ticket -> row pointers
-// -> pairs, and hub rows need two more code paths (whole wave / whole workgroup).  Here the question's merged record
-// stream itself is cut into EQUAL fact ranges, one per 4-lane group: a group streams its ~94 records (coalesced 32-byte
-// pieces, a group of 4 ahead), adds p * table row into one accumulator and, where the destination node changes, stores the
-// finished row.  Rows cut by a range boundary leave a head / tail partial; after one barrier the group in whose range a cut
-// row ENDS adds the partials in position order (tail of the range it started in, the whole-range partials of the ranges it
-// covers, its own head) and stores it.  No degree classes, no idle slots, no ticket; hubs are just rows cut many times.
-// Row sums keep one fixed order: position order inside a range (= k_walk_slice's order for rows that are not cut), range
-// order across ranges.
-//   pr: (p bits, table row | local destination node << 12) per merged record, written by k_fact_prior_packed.
-// MEASURED AND NOT THE DEFAULT (round 3, C2, dense prior; tools/pmc_walk.sh): 113 us per launch against the set walk's 93.
-// The ranges do remove the idle slots and the hub paths (LDS instructions 2.9 M -> 1.5 M per launch), but every fact
-// now carries the row-boundary logic (destination compare, address select, predicated store, accumulator reset): 36 M
-// VALU wave-instructions per launch against 26 M, and a store INSTRUCTION wherever any of a wave's 16 groups ends a row
-// (756 k against 122 k per launch: ~18 us of address-unit time).  Kept behind GNNRAG_WALK_STREAM=1 (environment) with its
-// parity tests; what it needs to win is fewer instructions per fact (row ends known per 8-record step at plan time,
-// finished rows parked and stored once per step).
-#ifndef GNNRAG_WALK_STREAM
-#define GNNRAG_WALK_STREAM 1     // compiled in; chosen at run time by the environment variable only
-#endif
-constexpr int kStreamRowBits = 12;          // table rows of both directions incl. the zero rows: 2 (Rg + 1) <= 4096
 // GNNRAG_HUB_DENSE=0 in the environment keeps the chunked hub kernels (A/B, tests of both forms)
 static bool hub_dense_enabled() {
   static const bool on = [] {
@@ -1648,203 +1581,6 @@ static bool hub_dense_enabled() {
     return GNNRAG_HUB_DENSE && !(e && e[0] == '0');
   }();
   return on;
-}
-
-static bool walk_stream_enabled() {
-  const char* e = getenv("GNNRAG_WALK_STREAM");
-  return e && e[0] == '1';
-}
-
-__global__ __launch_bounds__(256) void k_fact_prior_packed(const int2* __restrict__ em, const int32_t* __restrict__ from,
-                                                           const int32_t* __restrict__ mdst, const float* __restrict__ w0,
-                                                           const float* __restrict__ w1, const float* __restrict__ dist,
-                                                           int64_t F, int N, int2* __restrict__ pr) {
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= 2 * F) return;
-  typedef int i32x2 __attribute__((ext_vector_type(2)));
-  const i32x2 e = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(em) + j);
-  float p = dist[e.x];
-  if (w0) {
-    const int f = from[j];
-    p *= f < F ? w0[f] : w1[f - F];
-  }
-  const int dl = __builtin_nontemporal_load(mdst + j) % N;
-  pr[j] = make_int2(__float_as_int(p), e.y | (dl << kStreamRowBits));
-}
-
-template <int NI>
-__global__ __launch_bounds__(kSliceThreads, 8) void k_walk_stream(const WalkArgs a, const int2* __restrict__ pr, int nslice,
-                                                                  int nfull, int pl) {
-  constexpr int SW = kSliceW * NI;                     // floats per staged table row
-  constexpr int NQ = kSliceThreads / 4;                // 4-lane groups per workgroup
-  extern __shared__ __attribute__((aligned(16))) float s_mem[];
-  float* Ts = s_mem;                                   // [2][Rg + 1][SW]; row Rg of each direction is zero
-  int* kind = reinterpret_cast<int*>(s_mem + (size_t)2 * (a.R1 + 1) * SW);      // [NQ] head kind | tail flag << 8
-  // work item = (question, slice[, node-range part]) - same XCD-aware order as k_walk_slice
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  int item = slot, part = 0, nparts = 1;
-  if (pl > 0) {
-    item = slot >> pl;
-    part = slot & ((1 << pl) - 1);
-    nparts = 1 << pl;
-  } else if (slot >= nfull) {
-    const int hslot = slot - nfull;
-    item = nfull + (hslot >> 1);
-    part = hslot & 1;
-    nparts = 2;
-  }
-  const int g = (item / nslice) * 8 + xcd;
-  if (g >= a.B) return;
-  const int c = item % nslice;
-  const int col0 = c * SW;
-  const int D = a.D, N = a.N;
-  const int roff = a.rel_off[g], Rg = a.rel_off[g + 1] - roff;
-  const int tid = threadIdx.x;
-  // stage the two table slices
-  constexpr int GR = SW / 4;
-  for (int idx = tid; idx < 2 * Rg * GR; idx += kSliceThreads) {
-    const int d = idx >= Rg * GR;
-    const int rem = idx - d * (Rg * GR);
-    const int r = rem / GR, k = rem % GR;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    const float* tab = a.T[d] + (size_t)roff * D;
-    if (col0 + 4 * k < D) v = *reinterpret_cast<const f32x4*>(tab + (size_t)r * D + col0 + 4 * k);
-    *reinterpret_cast<f32x4*>(Ts + ((size_t)d * (Rg + 1) + r) * SW + 4 * k) = v;
-  }
-  if (tid < 2 * GR) {
-    const int d = tid / GR, k = tid % GR;
-    *reinterpret_cast<f32x4*>(Ts + ((size_t)d * (Rg + 1) + Rg) * SW + 4 * k) = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-  // this part's nodes and its range of the merged stream (parts are cut at node boundaries: no row spans two workgroups)
-  const int nlo = (int)((long long)N * part / nparts), nhi = (int)((long long)N * (part + 1) / nparts);
-  const int nb = g * N;
-  const int ms = a.row_ptr[0][nb + nlo] + a.row_ptr[1][nb + nlo], me = a.row_ptr[0][nb + nhi] + a.row_ptr[1][nb + nhi];
-  const int q = tid >> 2, sub = tid & 3;
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  bool col_ok[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) col_ok[i] = col0 + kSliceW * i + 4 * sub < D;
-  // nodes without a fact: their rows are zero (nobody else writes them; coalesced row-pointer reads, rare stores)
-  for (int n = nlo + tid; n < nhi; n += kSliceThreads) {
-    const int b0 = a.row_ptr[0][nb + n] + a.row_ptr[1][nb + n], b1 = a.row_ptr[0][nb + n + 1] + a.row_ptr[1][nb + n + 1];
-    if (b0 == b1) {
-      for (int k = 0; k < GR; ++k)
-        if (col0 + 4 * k < D) *reinterpret_cast<f32x4*>(a.out + (size_t)(nb + n) * D + col0 + 4 * k) = zero4;
-    }
-  }
-  // equal fact ranges (a multiple of 8 records each)
-  const int L = me - ms;
-  int C = (L + NQ - 1) / NQ;
-  C = (C + 7) & ~7;
-  const int s0 = ms + q * C;
-  const int e0 = min(me, s0 + C);
-  float* scr = a.stream_scratch + ((size_t)blockIdx.x * NQ + q) * (2 * SW) + 4 * sub;     // head at [0], tail at [SW]
-  const float* Tq = Ts + 4 * sub;
-  float* orow = a.out + (size_t)nb * D + col0 + 4 * sub;                     // + node * D (+ 16 i): this lane's output piece
-  int hk = 0;                  // head kind: 0 none, 1 | node << 2: the cut row ends in this range, 2: the range is one piece
-  if (s0 < e0) {
-    // does the range start inside a row?  (the record in front of it has the same destination)
-    bool first = s0 > ms && (pr[s0 - 1].y >> kStreamRowBits) == (pr[s0].y >> kStreamRowBits);
-    f32x4 acc[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) acc[i] = zero4;
-    const int2 none = make_int2(0, (int)((unsigned)Rg | (0xffffffffu << kStreamRowBits)));   // p = 0, zero row, destination -1
-    // 8 records per step, two per lane (one 16-byte load: 64 contiguous bytes per lane group), requested TWO steps
-    // (16 records) ahead of their use - the stream comes from L2 at ~1 us per round trip, a step's arithmetic is shorter
-    const int4 none4 = make_int4(none.x, none.y, none.x, none.y);
-    auto load2 = [&](int j) -> int4 {                     // records j, j + 1 (j even relative to an 8-byte aligned base)
-      if (j + 1 < me) return *reinterpret_cast<const int4*>(pr + j);
-      int4 v = none4;
-      if (j < me) { const int2 r0 = pr[j]; v.x = r0.x; v.y = r0.y; }
-      return v;
-    };
-    int4 cur = load2(s0 + 2 * sub);
-    int4 nxt = load2(s0 + 8 + 2 * sub);
-    int dlast = -1;
-    for (int i = s0; i < e0; i += 8) {
-      const int4 nn = load2(i + 16 + 2 * sub);
-      int yk[9];
-      float pk[8];
-      pk[0] = __int_as_float(quad_bcast<0>(cur.x)); yk[0] = quad_bcast<0>(cur.y);
-      pk[1] = __int_as_float(quad_bcast<0>(cur.z)); yk[1] = quad_bcast<0>(cur.w);
-      pk[2] = __int_as_float(quad_bcast<1>(cur.x)); yk[2] = quad_bcast<1>(cur.y);
-      pk[3] = __int_as_float(quad_bcast<1>(cur.z)); yk[3] = quad_bcast<1>(cur.w);
-      pk[4] = __int_as_float(quad_bcast<2>(cur.x)); yk[4] = quad_bcast<2>(cur.y);
-      pk[5] = __int_as_float(quad_bcast<2>(cur.z)); yk[5] = quad_bcast<2>(cur.w);
-      pk[6] = __int_as_float(quad_bcast<3>(cur.x)); yk[6] = quad_bcast<3>(cur.y);
-      pk[7] = __int_as_float(quad_bcast<3>(cur.z)); yk[7] = quad_bcast<3>(cur.w);
-      yk[8] = quad_bcast<0>(nxt.y);
-#pragma unroll
-      for (int h = 0; h < 8; h += 4) {                     // the table rows of four records requested together
-        f32x4 t[4][NI];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-          for (int ii = 0; ii < NI; ++ii)
-            t[k][ii] = *reinterpret_cast<const f32x4*>(Tq + (size_t)(yk[h + k] & ((1 << kStreamRowBits) - 1)) * SW + kSliceW * ii);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          // (records past the part's end are `none`: p = 0, the zero row, destination -1 - they add nothing, end no row)
-          const int dk = yk[h + k] >> kStreamRowBits, dn = yk[h + k + 1] >> kStreamRowBits;
-#pragma unroll
-          for (int ii = 0; ii < NI; ++ii) acc[ii] += pk[h + k] * t[k][ii];
-          const bool ends = dn != dk && dk >= 0;                           // the row of this record ends here
-          // a finished row goes to its place in `out`; the head piece of a row that started in an earlier range goes to
-          // the scratch (ONE predicated store either way: the address is selected, not the code path)
-          float* dstp = first ? scr : orow + (size_t)dk * D;
-#pragma unroll
-          for (int ii = 0; ii < NI; ++ii)
-            if (ends && (first || col_ok[ii])) *reinterpret_cast<f32x4*>(dstp + kSliceW * ii) = acc[ii];
-          hk = (ends && first) ? (1 | (dk << 2)) : hk;
-          first = ends ? false : first;
-#pragma unroll
-          for (int ii = 0; ii < NI; ++ii) acc[ii] = ends ? zero4 : acc[ii];
-          dlast = dk >= 0 ? dk : dlast;
-        }
-      }
-      cur = nxt;
-      nxt = nn;
-    }
-    // the range ends inside a row (the next range's first record has the same destination): an open piece is left
-    const int dnext = quad_bcast<0>(cur.y) >> kStreamRowBits;              // cur = the records at e0 .. now
-    if (e0 < me && dnext == dlast) {
-      float* dstp = first ? scr : scr + SW;
-#pragma unroll
-      for (int ii = 0; ii < NI; ++ii) *reinterpret_cast<f32x4*>(dstp + kSliceW * ii) = acc[ii];
-      if (first) hk = 2;
-    }
-  }
-  if (sub == 0) kind[q] = hk;
-  __syncthreads();
-  // cut rows: the group in whose range the row ends adds the pieces in position order
-  if ((hk & 3) == 1) {
-    int j = q - 1;
-    while (j > 0 && (kind[j] & 3) == 2) --j;            // whole-range pieces in between
-    const float* sj = a.stream_scratch + ((size_t)blockIdx.x * NQ + j) * (2 * SW) + 4 * sub;
-    f32x4 tot[NI];
-#pragma unroll
-    for (int ii = 0; ii < NI; ++ii) tot[ii] = *reinterpret_cast<const f32x4*>(sj + SW + kSliceW * ii);      // the tail it started with
-    // (a hub row is cut dozens of times: the pieces are requested eight at a time and added in position order)
-    for (int jj = j + 1; jj <= q; jj += 8) {
-      f32x4 v[8][NI];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float* sh = a.stream_scratch + ((size_t)blockIdx.x * NQ + min(jj + u, q)) * (2 * SW) + 4 * sub;
-#pragma unroll
-        for (int ii = 0; ii < NI; ++ii) v[u][ii] = *reinterpret_cast<const f32x4*>(sh + kSliceW * ii);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (jj + u <= q) {
-#pragma unroll
-          for (int ii = 0; ii < NI; ++ii) tot[ii] += v[u][ii];
-        }
-    }
-    const int dn = hk >> 2;
-#pragma unroll
-    for (int ii = 0; ii < NI; ++ii)
-      if (col_ok[ii]) *reinterpret_cast<f32x4*>(a.out + (size_t)(nb + dn) * D + col0 + kSliceW * ii + 4 * sub) = tot[ii];
-  }
 }
 
 // ---- dispatch -------------------------------------------------------------------------------
@@ -1965,19 +1701,6 @@ static size_t partial_bytes(const gnnrag_csr* csr, int D, int na) {
 static size_t prior_bytes(const gnnrag_csr* csr) {
   return align_up((size_t)2 * (size_t)(csr->F > 0 ? csr->F : 1) * sizeof(int2), 256);
 }
-// head / tail partials of the streaming walk: one pair per 4-lane group of every workgroup
-static size_t stream_scratch_bytes(int nblk, int sw) { return (size_t)nblk * (kSliceThreads / 4) * 2 * sw * sizeof(float); }
-// upper bound of the streaming walk's workgroups for this structure and hidden size (launch_slice: <= 2 per (question,
-// slice) item rounded up to whole XCD rounds, <= 8 parts per item for batches of <= 8 questions)
-static size_t stream_scratch_max(const gnnrag_csr* csr, int D) {
-  const int nslice = (D + kSliceW - 1) / kSliceW;
-  const size_t items = (size_t)8 * ((csr->B + 7) / 8) * nslice;
-  const int nslice2 = (D + 2 * kSliceW - 1) / (2 * kSliceW);                         // wide (32-column) slices
-  const size_t items2 = (size_t)8 * ((csr->B + 7) / 8) * nslice2;
-  const int parts = csr->B <= 8 ? 8 : 2;
-  const size_t a = stream_scratch_bytes((int)(items * parts), kSliceW), b = stream_scratch_bytes((int)(items2 * parts), 2 * kSliceW);
-  return a > b ? a : b;
-}
 static size_t slice_lds_bytes(int R1, int na = 3, int width = kSliceW) {
   return (size_t)2 * (R1 + 1) * width * sizeof(float) + (16 + 5 * kSliceBigCap) * sizeof(int) +
          (size_t)na * 16 * 16 * sizeof(float);
@@ -2022,15 +1745,7 @@ static int launch_slice(const WalkArgs& a, const gnnrag_csr* csr, void* workspac
   if (workspace_bytes < partial_bytes(csr, D, na_ws) + prior_bytes(csr)) return GNNRAG_E_WORKSPACE;
   int2* pr = (int2*)((char*)workspace + partial_bytes(csr, D, na_ws));
   const int64_t F = csr->F;
-  // the streaming form: fused walk over merged rows (both directions), table rows and local node ids packable
-  const bool streaming = GNNRAG_WALK_STREAM && MODE == MODE_FUSED && a.merged && a.m_dst && a.stream_scratch &&
-                      2 * (a.R1 + 1) <= (1 << kStreamRowBits) && a.N < (1 << (31 - kStreamRowBits)) &&
-                      walk_stream_enabled();
-  if (F > 0 && a.i0 == 0 && streaming) {
-    hipLaunchKernelGGL(k_fact_prior_packed, dim3((unsigned)((2 * F + 255) / 256)), dim3(256), 0, stream, a.edge_m,
-                       a.m_from, a.m_dst, a.w[0], a.w[1], a.dist, F, a.N, pr);
-    GNNRAG_LAUNCH_CHECK();
-  } else if (F > 0 && a.i0 == 0) {     // the (p, rel) pairs do not depend on the instruction pass
+  if (F > 0 && a.i0 == 0) {     // the (p, rel) pairs do not depend on the instruction pass
     if (a.merged)
       hipLaunchKernelGGL(k_fact_prior_merged, dim3((unsigned)((2 * F + 255) / 256)), dim3(256), 0, stream, a.edge_m,
                          a.m_from, a.w[0], a.w[1], a.dist, F, pr);
@@ -2071,19 +1786,6 @@ static int launch_slice(const WalkArgs& a, const gnnrag_csr* csr, void* workspac
     if (pl < 2) pl = 0;       // halves are what the tail split above already gives
     if (pl) nblk = 8 * (items_x << pl);
   }
-  if constexpr (MODE == MODE_FUSED) {
-    if (streaming) {
-      if (stream_scratch_bytes(nblk, SW) > a.stream_scratch_bytes) return GNNRAG_E_WORKSPACE;
-      static DeviceMask cap_s;
-      {
-        const int rc = raise_lds_cap(k_walk_stream<NI>, cap_s);
-        if (rc) return rc;
-      }
-      hipLaunchKernelGGL((k_walk_stream<NI>), dim3(nblk), dim3(kSliceThreads), lds, stream, a, (const int2*)pr, nslice, nfull, pl);
-      GNNRAG_LAUNCH_CHECK();
-      return 0;
-    }
-  }
   if (MODE == MODE_FUSED && a.merged) {
     if constexpr (MODE == MODE_FUSED)
       hipLaunchKernelGGL((k_walk_slice<MODE, NI, true>), dim3(nblk), dim3(kSliceThreads), lds, stream, a, (const int2*)pr, F,
@@ -2102,7 +1804,7 @@ using namespace gnnrag;
 
 extern "C" size_t gnnrag_aggregate_workspace_bytes(const gnnrag_csr* csr, int32_t D, int32_t I) {
   if (!csr || D <= 0 || I <= 0) return 0;
-  return partial_bytes(csr, D, I < 3 ? I : 3) + prior_bytes(csr) + (slice_walk_fits(csr->rel_max, D) ? stream_scratch_max(csr, D) : 0);
+  return partial_bytes(csr, D, I < 3 ? I : 3) + prior_bytes(csr);
 }
 
 extern "C" int gnnrag_aggregate(const gnnrag_csr* csr, const float* dist, const float* ins,
@@ -2169,14 +1871,6 @@ static int prepare_fused(WalkArgs& a, const gnnrag_csr* csr, const float* dist, 
   a.merged = (GNNRAG_SLICE_MERGED && skip_dir == 0 && csr->edge_m && csr->m_from) ? 1 : 0;
   a.edge_m = (const int2*)csr->edge_m;
   a.m_from = csr->m_from;
-  a.m_dst = csr->m_dst;
-  {   // the streaming walk's partial-sum scratch sits behind the heavy-chunk partials and the prior pairs
-    const size_t used = partial_bytes(csr, D, 1) + prior_bytes(csr);
-    if (workspace_bytes > used) {
-      a.stream_scratch = (float*)((char*)workspace + used);
-      a.stream_scratch_bytes = workspace_bytes - used;
-    }
-  }
   const int variant = gnnrag_aggregate_fused_variant(csr, D);
   if (variant == GNNRAG_WALK_L2_GATHER && (D & 3) == 0 && D <= 32 * kHubWaves && hub_dense_enabled() && csr->hub_sorted &&
       csr->hub_q_off[0] && csr->hub_wbase[0]) {

@@ -31,17 +31,6 @@ int update_b3_launch_f(const float* h, const float* nbr, const uint8_t* add_flag
 bool update_rows_supported(const float* h, const float* nbr, const float* W, const float* h_out, int64_t BN, int32_t D,
                            int32_t I, int32_t math);
 bool update_b3_shape_ok(int64_t BN, int32_t D, int32_t ldw);
-// update_wr.hip: the same update with the weight planes in registers (hidden size 200); GNNRAG_E_UNSUPPORTED otherwise
-int update_wr_launch_f(const float* h, const float* nbr, const uint8_t* add_flag, const float* W, const float* b,
-                       const float* w_s, const float* b_s, const float* mask, float* h_out, float* score, int64_t BN,
-                       int32_t D, int32_t ldw, hipStream_t stream);
-
-// update_x32.hip: the same update on v_mfma_f32_32x32x16_bf16 (hidden size 200, >= 8192 rows); GNNRAG_E_UNSUPPORTED
-// otherwise or when GNNRAG_UPDATE_X32=0 is in the environment
-int update_x32_launch_f(const float* h, const float* nbr, const uint8_t* add_flag, const float* W, const float* b,
-                        const float* w_s, const float* b_s, const float* mask, float* h_out, float* score, int64_t BN,
-                        int32_t D, int32_t ldw, hipStream_t stream, bool score_zeroed);
-
 // frontier.hip: relation tables of small batches on the one-workgroup-per-tile, split-k kernel (exact fp32)
 int tables_small_launch(const gnnrag_csr* csr, const float* T_fwd, const float* T_inv, const float* ins, const float* W,
                         float* P, int32_t D, int32_t I, hipStream_t stream);

@@ -42,20 +42,9 @@
 #ifndef GNNRAG_UPDATE_SKINNY
 #define GNNRAG_UPDATE_SKINNY 1   // self-block update of small batches (< 4096 rows) on the one-wave-per-tile kernel
 #endif
-#ifndef GNNRAG_GEMM_ABL
-#define GNNRAG_GEMM_ABL 0        // timing-only ablation builds (tools/tune_variants.py): 1 no MFMA, 2 no epilogue
-                                 // traffic, 4 no global loads in the k loop, 8 no LDS restaging in the k loop
-#endif
-
-#ifndef GNNRAG_GEMM_TIMING
-#define GNNRAG_GEMM_TIMING 0     // profiling builds only: per-workgroup phase stamps (s_memtime) into a debug buffer
-#endif
 
 namespace gnnrag {
 
-#if GNNRAG_GEMM_TIMING
-__device__ long long* g_tbuf = nullptr;     // [waves][32] stamps; set by gnnrag_debug_set_timing_buffer (timing builds only)
-#endif
 
 constexpr int kBK = 32;    // k per LDS tile
 constexpr int kSkinnyMaxM = 16384;   // up to here a problem runs on k_gemm_skinny (one wave per 16 x 64 tile, no LDS)
@@ -294,10 +283,8 @@ void k_gemm_f32(GemmArgs g) {
   const int fr = lane & 15;  // fragment row (A) / column (W) inside a 16x16 tile
   const int fg = lane >> 4;  // k group
   for (int t = 0; t < nT; ++t) {
-    if (t + 1 < nT && !(GNNRAG_GEMM_ABL & 4)) gload(t + 1);      // tile t+1 is in flight while tile t (in LDS) is multiplied
-    if constexpr (GNNRAG_GEMM_ABL & 1) {
-      acc[0][0][0] += As[(wave * 16 * MT + fr) * kLS + fg * 4 + (t & 3)];
-    } else if constexpr (MATH == 0) {
+    if (t + 1 < nT) gload(t + 1);      // tile t+1 is in flight while tile t (in LDS) is multiplied
+    if constexpr (MATH == 0) {
 #pragma unroll
       for (int c = 0; c < kBK / 16; ++c) {
         f32x4 a[MT];
@@ -351,22 +338,11 @@ void k_gemm_f32(GemmArgs g) {
                                                                            acc[mt][nt0 + q], 0, 0, 0);
       }
     }
-    if constexpr (!(GNNRAG_GEMM_ABL & 8)) {
     __syncthreads();
     if (t + 1 < nT) {
       sstore();
       __syncthreads();
     }
-    }
-  }
-  if constexpr ((GNNRAG_GEMM_ABL & 2) != 0) {
-    float sacc = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) sacc += acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2] + acc[mt][nt][3];
-    if (sacc == 12345.678f) g.C[tid] = sacc;
-    return;
   }
 
   // ---- epilogue -------------------------------------------------------------------------------
@@ -544,9 +520,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_wres(GemmArgs g, int S, int LR)
   const int fr = lane & 15, fg = lane >> 4;
   const int K = g.K, KC = K >> 2, Nout = g.Nout;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-#if GNNRAG_GEMM_TIMING
-  const long long t_entry = __builtin_amdgcn_s_memtime();
-#endif
 
   // W -> LDS (float4 copies; row j lands at LDS row ColMap::lds_row(j)).  Twenty requests per thread are in flight
   // before the first one is written (a one-at-a-time copy of 160 KB cost ~25 us of exposed L2 latency per launch).
@@ -613,23 +586,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_wres(GemmArgs g, int S, int LR)
   // AFL: the four row gates of a lane's `add` rows (one dword), requested a tile ahead like the A fragments
   unsigned fl_next = 0x01010101u;
   if (AFL && t < tend) fl_next = *reinterpret_cast<const unsigned*>(g.add_flag + (size_t)t * 16 + 4 * fg);
-#if GNNRAG_GEMM_TIMING
-  long long* tb = g_tbuf ? g_tbuf + ((size_t)blockIdx.x * 8 + wave) * 32 : nullptr;
-  int stamp = 0;
-  if (tb && lane == 0) tb[stamp] = __builtin_amdgcn_s_memtime();
-  ++stamp;
-#endif
   __syncthreads();
-#if GNNRAG_GEMM_TIMING
-  if (tb && lane == 0) { tb[stamp] = __builtin_amdgcn_s_memtime(); tb[30] = __builtin_amdgcn_s_getreg((31 << 11) | 4); tb[31] = t_entry; }
-  ++stamp;
-#endif
 
   for (; t < tend; t = tnext_c) {
-#if GNNRAG_GEMM_TIMING
-    if (tb && lane == 0 && stamp < 28) tb[stamp] = __builtin_amdgcn_s_memtime();
-    ++stamp;
-#endif
     const int rbase = t * 16 + 4 * fg;                             // C layout: this lane's rows rbase + q
     const unsigned fl = fl_next;
     if (AFL) fl_next = *reinterpret_cast<const unsigned*>(g.add_flag + (size_t)(t + 1 < tend ? t + 1 : t) * 16 + 4 * fg);
@@ -687,10 +646,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_wres(GemmArgs g, int S, int LR)
       }
       ra[c] = a_frag(tload, c);                                    // refill: the next tile's k group c
     }
-#if GNNRAG_GEMM_TIMING
-    if (tb && lane == 0 && stamp < 28) tb[stamp] = __builtin_amdgcn_s_memtime();
-    ++stamp;
-#endif
     // epilogue from the registers: 4 consecutive columns per lane and column group
     float part[4] = {0.f, 0.f, 0.f, 0.f};
     f32x4 ws4[CM::NGRP], bias4[CM::NGRP];        // this lane's columns of bias / score weights (from LDS)
@@ -741,9 +696,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_wres(GemmArgs g, int S, int LR)
       if (fr < 4 && srow < g.M) g.score[srow] = (tot + bs) + (1.0f - mrow) * kVeryNeg;
     }
   }
-#if GNNRAG_GEMM_TIMING
-  if (tb && lane == 0 && stamp < 30) tb[stamp] = __builtin_amdgcn_s_memtime();
-#endif
 }
 
 // applicability of k_gemm_wres and its LDS row stride (float4 chunks): S >= K/4 with S % 4 == 2 keeps the
@@ -1033,12 +985,6 @@ static int launch_gemm(GemmArgs g, hipStream_t stream, int math) {
 
 using namespace gnnrag;
 
-#if GNNRAG_GEMM_TIMING
-extern "C" int gnnrag_debug_set_timing_buffer(long long* buf) {
-  GNNRAG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tbuf), &buf, sizeof(buf)));
-  return 0;
-}
-#endif
 
 extern "C" int gnnrag_linear(const float* A, int64_t M, int32_t K, const float* W, const float* bias,
                              const float* add, int64_t add_rows, int relu, float* C, int32_t Nout,

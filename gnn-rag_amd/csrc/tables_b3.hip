@@ -333,26 +333,8 @@ constexpr int kVqRowB = 2 * kVqHalf * 2;       // bytes per plane row: [relu(T) 
 #ifndef GNNRAG_VQ_TPW
 #define GNNRAG_VQ_TPW 5
 #endif
-#ifndef GNNRAG_UPD_ABL
-#define GNNRAG_UPD_ABL 0         // timing-only ablations of k_update_b3: 1 no LDS reads, 2 no A refills, 4 no nbr
-#endif                           // loads, 8 no stores, 16 no 3-way split
-#ifndef GNNRAG_UPD_BALANCE
-#define GNNRAG_UPD_BALANCE 0     // k_update_b3: row chunks of the two column parts balanced 7 : 6 (measured slower: DESIGN A.7; 0: equal chunks)
-#endif
-#ifndef GNNRAG_UPD_PRIO
-#define GNNRAG_UPD_PRIO 0        // k_update_b3: s_setprio level around every k block's MFMA section (experiment)
-#endif
-#ifndef GNNRAG_UPD_DESYNC
-#define GNNRAG_UPD_DESYNC 0      // k_update_b3: 64-cycle sleeps of waves 4..7 before their first tile (experiment)
-#endif
-#ifndef GNNRAG_VQ_ABL
-#define GNNRAG_VQ_ABL 0          // timing-only ablations (wrong results): 1 no LDS fragment reads, 2 no A refills,
-#endif                           // 4 no V staging, 8 no epilogue stores
 #ifndef GNNRAG_VQ_UN
 #define GNNRAG_VQ_UN 3
-#endif
-#ifndef GNNRAG_VQ_ORDER
-#define GNNRAG_VQ_ORDER 0       // 1: column-tile pairs outer, row tiles inner (V fragments read once per k block and pair)
 #endif
 constexpr int kVqTPW = GNNRAG_VQ_TPW;          // row tiles per wave and pass
 
@@ -460,17 +442,18 @@ __device__ __forceinline__ void tables_vq_part(const VqArgs& a, unsigned char* l
 #pragma unroll
       for (int nt = 0; nt < CTN; ++nt) acc[j][nt] = zero4;
     // this lane's plane row of every tile (rows past the question / the wave's run read a valid row, never stored)
-    int aoff[kVqTPW];
+    unsigned aoff[kVqTPW];     // 32-bit byte offsets from the planes' (uniform) bases: scalar base + lane offset + immediate
 #pragma unroll
     for (int j = 0; j < kVqTPW; ++j) {
       const int m = min(r0 + (tbase + (j < ntile ? j : 0)) * 16 + fr, r1 - 1);
-      aoff[j] = a.rows[m].y * kVqRowB + fg * 16;
+      aoff[j] = (unsigned)a.rows[m].y * (unsigned)kVqRowB + (unsigned)fg * 16u;
     }
+    const unsigned char* const plane_base[3] = {planes, planes + plane_stride, planes + 2 * plane_stride};
 
     for (int s = 0; s < 2; ++s) {           // (rolled: the peeled form spills ~300 registers)
       __syncthreads();                                        // q rows staged / the previous half's fragment reads done
       // ---- V planes of this half ----
-      if (!(GNNRAG_VQ_ABL & 4)) vq_stage<CTN, GNNRAG_VQ_UN>(a, lds, qarea, col0, ncol, d, s);
+      vq_stage<CTN, GNNRAG_VQ_UN>(a, lds, qarea, col0, ncol, d, s);
       __syncthreads();
 
       // ---- MFMA phase: a tile's A fragments of k block kb + 1 are requested as soon as its MFMAs of kb are issued,
@@ -480,49 +463,7 @@ __device__ __forceinline__ void tables_vq_part(const VqArgs& a, unsigned char* l
       for (int j = 0; j < kVqTPW; ++j)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-          ap[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(planes + pl * plane_stride + aoff[j] +
-                                                                                 s * (kVqHalf * 2)));
-#if GNNRAG_VQ_ORDER == 1
-      // Round 4 experiment: column-tile pairs OUTER, row tiles INNER - a pair's six V fragments are read from LDS once and
-      // multiplied against all of the wave's row tiles (5 x fewer ds_read_b128: 24 instead of 120 per k block); a tile's A
-      // fragments of the next k block are requested right after its last products of this one, i.e. ~48 MFMAs ahead
-      for (int kb = 0; kb < NKB; ++kb) {
-        const int kbn = min(kb + 1, NKB - 1);
-        const unsigned char* wb = lds + fr * RB + kb * 64 + fg * 16;
-        constexpr int PA[6] = {1, 2, 0, 1, 0, 0};
-        constexpr int PB[6] = {1, 0, 2, 0, 1, 0};
-#pragma unroll
-        for (int nt = 0; nt < CTN; nt += 2) {
-          bf16x8 b0[3], b1[3];
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) {
-            b0[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + nt * 16 * RB));
-            b1[pl] = b0[pl];
-            if (nt + 1 < CTN)
-              b1[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + (nt + 1) * 16 * RB));
-          }
-#pragma unroll
-          for (int j = 0; j < kVqTPW; ++j) {
-            if (j < ntile) {                                  // wave-uniform
-#pragma unroll
-              for (int p = 0; p < 6; ++p) {
-                acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[j][PA[p]], b0[PB[p]], acc[j][nt], 0, 0, 0);
-                if (nt + 1 < CTN)
-                  acc[j][nt + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[j][PA[p]], b1[PB[p]], acc[j][nt + 1], 0, 0, 0);
-              }
-            }
-            if (nt + 2 >= CTN) {                              // the k block's last pair: this tile's fragments of the next one
-#pragma unroll
-              for (int pl = 0; pl < 3; ++pl)
-                ap[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(planes + pl * plane_stride + aoff[j] +
-                                                                                       s * (kVqHalf * 2) + kbn * 64));
-            }
-          }
-        }
-      }
-    }
-
-#else
+          ap[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(plane_base[pl] + (aoff[j] + (unsigned)(s * (kVqHalf * 2)))));
       for (int kb = 0; kb < NKB; ++kb) {        // (not unrolled: register pressure)
         const int kbn = min(kb + 1, NKB - 1);   // (the last block requests itself again: no branch around a load)
         const unsigned char* wb = lds + fr * RB + kb * 64 + fg * 16;
@@ -536,15 +477,10 @@ __device__ __forceinline__ void tables_vq_part(const VqArgs& a, unsigned char* l
               bf16x8 b0[3], b1[3];
 #pragma unroll
               for (int pl = 0; pl < 3; ++pl) {
-#if GNNRAG_VQ_ABL & 1
-                b0[pl] = ap[j][pl];
-                b1[pl] = ap[j][(pl + 1) % 3];
-#else
                 b0[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + nt * 16 * RB));
                 b1[pl] = b0[pl];
                 if (nt + 1 < CTN)
                   b1[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + (nt + 1) * 16 * RB));
-#endif
               }
 #pragma unroll
               for (int p = 0; p < 6; ++p) {
@@ -554,17 +490,13 @@ __device__ __forceinline__ void tables_vq_part(const VqArgs& a, unsigned char* l
               }
             }
           }
-#if !(GNNRAG_VQ_ABL & 2)
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl)                      // refill: this tile's fragments of the next k block
-            ap[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(planes + pl * plane_stride + aoff[j] +
-                                                                                   s * (kVqHalf * 2) + kbn * 64));
-#endif
+            ap[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(plane_base[pl] + (aoff[j] + (unsigned)(s * (kVqHalf * 2) + kbn * 64))));
         }
       }
     }
 
-#endif
     // ---- epilogue: the pass's tiles leave the registers (C layout: rows 4 fg + q, column slot fr) ----
 #pragma unroll
     for (int j = 0; j < kVqTPW; ++j) {
@@ -573,7 +505,7 @@ __device__ __forceinline__ void tables_vq_part(const VqArgs& a, unsigned char* l
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int row = rbase + q;
-          if (row < r1 && (!(GNNRAG_VQ_ABL & 8) || acc[j][0][q] == 1234.5f)) {
+          if (row < r1) {
             float* prow = P + (size_t)row * D + col0;
             static_assert(CTN >= 4, "a column part holds at least the interleaved group");
             {
@@ -694,32 +626,43 @@ __device__ __forceinline__ void update_b3_part(const UpdB3Args& a, unsigned char
   int t = c0 + (int)((long long)nch * wave / 8);
   const int tend = c0 + (int)((long long)nch * (wave + 1) / 8);
   const int kmax = D - 8;
+  // Addresses (round 5).  PMC showed the VALU pipe as busy as the matrix pipe (14.9 M VALU against 4.4 M MFMA instructions
+  // per launch, profiles/r05c_pmc_update_b3.txt), and the ISA showed why: ~40 % of the loop's VALU instructions were
+  // 64-bit address arithmetic the compiler rematerialised per access (v_lshl_add_u64, v_mad_i64_i32, clamps) and v_add_u32
+  // for LDS offsets beyond the 16-bit immediate.  Now every global access is SCALAR BASE + 32-BIT LANE OFFSET + immediate
+  // (the launcher admits (M + 1) * D * 4 < 2^32): one row offset per tile, lane constants for the column pieces; the
+  // three LDS planes have one base register each, so that every fragment offset fits the immediate.
+  const unsigned char* Ab = reinterpret_cast<const unsigned char*>(a.A);
+  const unsigned char* addb = reinterpret_cast<const unsigned char*>(a.add);
+  unsigned char* Cb = reinterpret_cast<unsigned char*>(a.C);
+  const unsigned rowB = (unsigned)D * 4u;
+  const unsigned k6B = (unsigned)min(32 * (NKB - 1) + 8 * fg, kmax) * 4u;      // the last k block's (clamped) piece
+  auto a_rowoff = [&](int tile) -> unsigned { return (unsigned)min(tile * 16 + fr, a.M - 1) * rowB; };
   // raw A pieces of a tile: per k block two float4 (k = 32 kb + 8 fg .. + 7), unconditional (clamped addresses)
-  auto a_piece = [&](int tile, int kb, int half) -> f32x4 {
-    const int row = min(tile * 16 + fr, a.M - 1);
-    const int k = min(32 * kb + 8 * fg, kmax) + 4 * half;
-    return *reinterpret_cast<const f32x4*>(a.A + (size_t)row * D + k);
+  auto a_piece = [&](unsigned rowoff, int kb, int half) -> f32x4 {
+    const unsigned off = kb < NKB - 1 ? rowoff + 32u * (unsigned)fg + (unsigned)(128 * kb + 16 * half)
+                                      : rowoff + k6B + (unsigned)(16 * half);
+    return *reinterpret_cast<const f32x4*>(Ab + off);
   };
   f32x4 ra[NKB][2];
   if (t < tend) {
+    const unsigned ro = a_rowoff(t);
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      ra[kb][0] = a_piece(t, kb, 0);
-      ra[kb][1] = a_piece(t, kb, 1);
+      ra[kb][0] = a_piece(ro, kb, 0);
+      ra[kb][1] = a_piece(ro, kb, 1);
     }
   }
   const float bs = a.b_s[0];
+  // lane constants of the epilogue's column pieces (bytes inside a row of nbr / h')
+  const unsigned cgB = (unsigned)(col0 + min(4 * fr, ncol - 4)) * 4u;
+  unsigned ctB[CTN > 4 ? CTN - 4 : 1];
+#pragma unroll
+  for (int nt = 4; nt < CTN; ++nt) ctB[nt - 4] = (unsigned)(col0 + min(nt * 16 + fr, ncol - 1)) * 4u;
   // FL: the four row gates of a lane's rows (one dword), requested a tile ahead like the A pieces
   unsigned fl_next = 0x01010101u;
   if (FL && t < tend) fl_next = *reinterpret_cast<const unsigned*>(a.add_flag + (size_t)t * 16 + 4 * fg);
   __syncthreads();
-#if GNNRAG_UPD_DESYNC > 0
-  // experiment (round 4): the two waves of a SIMD (w and w + 4) run identical code from the same start and stay in phase -
-  // both split, both read fragments, both issue MFMAs at the same time; a one-time offset of about half a tile for the
-  // second wave would let one wave's VALU / LDS phases fall under the other's MFMAs (no barrier follows)
-  if (wave >= 4)
-    for (int i = 0; i < GNNRAG_UPD_DESYNC; ++i) __builtin_amdgcn_s_sleep(1);
-#endif
 
   for (; t < tend; ++t) {
     const int rbase = t * 16 + 4 * fg;                       // C layout: rows rbase + q, column slot fr
@@ -732,16 +675,10 @@ __device__ __forceinline__ void update_b3_part(const UpdB3Args& a, unsigned char
     for (int q = 0; q < 4; ++q) {
       int row = min(rbase + q, a.M - 1);
       if (FL && ((fl >> (8 * q)) & 0xffu) == 0u) row = a.M;      // not a frontier row: the zero row behind the buffer
-      const float* arow = a.add + (size_t)row * D + col0;
-#if GNNRAG_UPD_ABL & 4
-      addg[q] = zero4;
+      const unsigned ro = (unsigned)row * rowB;
+      addg[q] = *reinterpret_cast<const f32x4*>(addb + (ro + cgB));
 #pragma unroll
-      for (int nt = 4; nt < CTN; ++nt) addt[nt - 4][q] = 0.f;
-#else
-      addg[q] = *reinterpret_cast<const f32x4*>(arow + min(4 * fr, ncol - 4));
-#pragma unroll
-      for (int nt = 4; nt < CTN; ++nt) addt[nt - 4][q] = arow[min(nt * 16 + fr, ncol - 1)];
-#endif
+      for (int nt = 4; nt < CTN; ++nt) addt[nt - 4][q] = *reinterpret_cast<const float*>(addb + (ro + ctB[nt - 4]));
     }
     float mrow = 0.f;
     {
@@ -752,60 +689,47 @@ __device__ __forceinline__ void update_b3_part(const UpdB3Args& a, unsigned char
     f32x4 acc[CTN];
 #pragma unroll
     for (int nt = 0; nt < CTN; ++nt) acc[nt] = zero4;
-    const int tload = t + 1 < tend ? t + 1 : t;
-    const int fg_t = opaque_i(fg);                           // keeps the (loop invariant) plane reads inside the tile loop
+    const unsigned ro_next = a_rowoff(t + 1 < tend ? t + 1 : t);
+    // one base register per LDS plane (made opaque once per tile: keeps the loop-invariant plane reads inside the loop)
+    const unsigned char* wbp[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      unsigned o = (unsigned)(fr * RB + fg * 16 + pl * PL);
+      asm volatile("" : "+v"(o));
+      wbp[pl] = lds + o;
+    }
     constexpr int PA[6] = {1, 2, 0, 1, 0, 0};
     constexpr int PB[6] = {1, 0, 2, 0, 1, 0};
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      const bool kok = 32 * kb + 8 * fg_t <= kmax;
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       bf16x8 ap[3];
-#if GNNRAG_UPD_ABL & 16
-      ap[0] = __builtin_bit_cast(bf16x8, ra[kb][0]);
-      ap[1] = __builtin_bit_cast(bf16x8, ra[kb][1]);
-      ap[2] = __builtin_bit_cast(bf16x8, ra[kb][0] + ra[kb][1]);
-#else
       // only the LAST k block can reach past D (the launcher admits 192 < D <= 208): no select in the others
-      const Split3 s0 = split3(kb < NKB - 1 || kok ? ra[kb][0] : zero4);
-      const Split3 s1 = split3(kb < NKB - 1 || kok ? ra[kb][1] : zero4);
+      const bool kok = kb < NKB - 1 || 32 * kb + 8 * fg <= kmax;
+      const Split3 s0 = split3(kok ? ra[kb][0] : zero4);
+      const Split3 s1 = split3(kok ? ra[kb][1] : zero4);
       ap[0] = __builtin_bit_cast(bf16x8, (u32x4){s0.hi.x, s0.hi.y, s1.hi.x, s1.hi.y});
       ap[1] = __builtin_bit_cast(bf16x8, (u32x4){s0.mid.x, s0.mid.y, s1.mid.x, s1.mid.y});
       ap[2] = __builtin_bit_cast(bf16x8, (u32x4){s0.lo.x, s0.lo.y, s1.lo.x, s1.lo.y});
-#endif
-#if !(GNNRAG_UPD_ABL & 2)
-      ra[kb][0] = a_piece(tload, kb, 0);                     // refill: the next tile's k block kb
-      ra[kb][1] = a_piece(tload, kb, 1);
-#endif
-      const unsigned char* wb = lds + fr * RB + kb * 64 + fg_t * 16;
-#if GNNRAG_UPD_PRIO
-      __builtin_amdgcn_s_setprio(GNNRAG_UPD_PRIO);          // experiment: the wave in its MFMA block wins the issue arbitration
-#endif
+      ra[kb][0] = a_piece(ro_next, kb, 0);                   // refill: the next tile's k block kb
+      ra[kb][1] = a_piece(ro_next, kb, 1);
 #pragma unroll
       for (int nt = 0; nt < CTN; nt += 2) {
         bf16x8 b0[3], b1[3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
-#if GNNRAG_UPD_ABL & 1
-          b0[pl] = ap[pl];
-          b1[pl] = ap[(pl + 1) % 3];
-#else
-          b0[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + nt * 16 * RB));
+          b0[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wbp[pl] + (nt * 16 * RB + kb * 64)));
           b1[pl] = b0[pl];
           if (nt + 1 < CTN)
-            b1[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + (nt + 1) * 16 * RB));
-#endif
+            b1[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wbp[pl] + ((nt + 1) * 16 * RB + kb * 64)));
         }
 #pragma unroll
-        for (int p = (GNNRAG_UPD_ABL & 32 ? 3 : 0); p < 6; ++p) {
+        for (int p = 0; p < 6; ++p) {
           acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[PA[p]], b0[PB[p]], acc[nt], 0, 0, 0);
           if (nt + 1 < CTN)
             acc[nt + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[PA[p]], b1[PB[p]], acc[nt + 1], 0, 0, 0);
         }
       }
-#if GNNRAG_UPD_PRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
     }
     // epilogue from the registers
     float part[4] = {0.f, 0.f, 0.f, 0.f};
@@ -814,13 +738,14 @@ __device__ __forceinline__ void update_b3_part(const UpdB3Args& a, unsigned char
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = rbase + q;
+      const unsigned ro = (unsigned)min(row, a.M - 1) * rowB;
       f32x4 v = {acc[0][q], acc[1][q], acc[2][q], acc[3][q]};
       v = __builtin_elementwise_max((v + bias_g) + addg[q], zero4);
       const int c = 4 * fr;
       if (c + 4 > ncol) {                                    // (ncol % 4 == 0: a lane's group is all in or all out)
         v = zero4;
-      } else if (row < a.M && (!(GNNRAG_UPD_ABL & 8) || v[0] == 1234.5f)) {
-        *reinterpret_cast<f32x4*>(a.C + (size_t)row * D + col0 + c) = v;
+      } else if (row < a.M) {
+        *reinterpret_cast<f32x4*>(Cb + (ro + cgB)) = v;
       }
       part[q] += v[0] * ws_g[0] + v[1] * ws_g[1] + v[2] * ws_g[2] + v[3] * ws_g[3];
 #pragma unroll
@@ -828,7 +753,7 @@ __device__ __forceinline__ void update_b3_part(const UpdB3Args& a, unsigned char
         const int cc = nt * 16 + fr;
         float x = fmaxf((acc[nt][q] + Bl[cc]) + addt[nt - 4][q], 0.f);
         if (cc >= ncol) x = 0.f;
-        else if (row < a.M && (!(GNNRAG_UPD_ABL & 8) || x == 1234.5f)) a.C[(size_t)row * D + col0 + cc] = x;
+        else if (row < a.M) *reinterpret_cast<float*>(Cb + (ro + ctB[nt - 4])) = x;
         part[q] += x * Sl[cc];
       }
     }
@@ -846,256 +771,17 @@ __device__ __forceinline__ void update_b3_part(const UpdB3Args& a, unsigned char
 }
 
 template <bool FL>
-__global__ __launch_bounds__(512, 2) void k_update_b3(UpdB3Args a, int nchunks, int nchunks1) {
+__global__ __launch_bounds__(512, 2) void k_update_b3(UpdB3Args a, int nchunks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int blk = blockIdx.x;
   const int NT = (a.D + 15) >> 4;
-  if (nchunks1 > 0) {
-    // Round 4: the 7-tile column part costs 7/6 of the 6-tile part per row, so the parts get DIFFERENT row chunkings -
-    // nchunks workgroups for part 0, nchunks1 for part 1, in the ratio 7 : 6 (136 + 120 on 256 CUs: 412 / 400 tile-units
-    // per CU where equal chunks gave 437 / 375).  XCD x (= blk % 8) runs slots blk / 8: its first nchunks / 8 slots are the
-    // x-th eighth of part 0's chunks, the rest the x-th eighth of part 1's - both reads of a row of h stay in one XCD.
-    const int x = blk & 7, slot = blk >> 3;
-    const int p0 = nchunks >> 3, p1 = nchunks1 >> 3;
-    if (slot < p0) update_b3_part<kTabNTH, FL>(a, lds, 0, true, x * p0 + slot, nchunks);
-    else if (slot < p0 + p1 && NT - a.ct0 == 6) update_b3_part<6, FL>(a, lds, a.ct0 * 16, false, x * p1 + (slot - p0), nchunks1);
-    return;
-  }
-  // equal chunks: the two parts of a row chunk are neighbours in the grid AND on one XCD (blocks b and b + 8):
+  // the two parts of a row chunk are neighbours in the grid AND on one XCD (blocks b and b + 8):
   // block = 16*(c/8) + 8*h + c%8
   const int h = (blk >> 3) & 1;
   const int chunk = (blk >> 4) * 8 + (blk & 7);
   if (chunk >= nchunks) return;
   if (h == 0) update_b3_part<kTabNTH, FL>(a, lds, 0, true, chunk, nchunks);
   else if (NT - a.ct0 == 6) update_b3_part<6, FL>(a, lds, a.ct0 * 16, false, chunk, nchunks);
-}
-
-// ---- the same update with MORE WAVES per CU (round 4) ---------------------------------------------------------------
-// PMC of k_update_b3 at C2 (profiles/r04a_pmc_dense_layer_C2.txt): the matrix pipe is busy 47 % of the waves' lifetime;
-// a wave issues in 27 % of its cycles, is parked at s_waitcnt in 25 % and stalled at issue in 49 % - two 256-register
-// waves per SIMD are not enough to fill the pipe while one of them splits A, waits for LDS fragments or runs its
-// epilogue (tools/probe/mfma_probe: one wave alone sustains 1.0 PFLOP/s on a "2.5 VALU + 0.5 ds_read per MFMA" mix, two
-// 1.6).  k_update_b3w keeps the LDS weight planes, the six plane products and the register epilogue, but a workgroup is
-// 12 or 16 waves (3 / 4 per SIMD, 168 / 128 registers): the A pieces are requested through a 4-slot ring 3-4 k blocks
-// ahead (32 registers instead of a whole tile's 56) with a static refill schedule that runs on into the next tile.
-#ifndef GNNRAG_UPD_WAVES
-#define GNNRAG_UPD_WAVES 8      // 8: k_update_b3 (default until measured); 12 / 16: k_update_b3w
-#endif
-
-template <int CTN, bool FL, int NW>
-__device__ __forceinline__ void update_b3w_part(const UpdB3Args& a, unsigned char* lds, int col0, bool first_part,
-                                                int chunk, int nchunks) {
-  constexpr int RB = kTabSlots * 16;
-  constexpr int PL = kTabNTH * 16 * RB;
-  constexpr int NKB = kTabNKB;
-  constexpr int NTH = 64 * NW;
-  static_assert(NKB == 7, "the ring's refill schedule is written for 7 k blocks");
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fr = lane & 15, fg = lane >> 4;
-  const int D = a.D;
-  const int ncol = min(CTN * 16, D - col0);
-  const int KC = D >> 2;
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  float* Bl = reinterpret_cast<float*>(lds + 3 * PL + 64);      // bias / score weights of this part's columns
-  float* Sl = Bl + kTabNTH * 16;
-
-  if (tid < 16) reinterpret_cast<unsigned*>(lds + 3 * PL)[tid] = 0u;
-  for (int j = tid; j < kTabNTH * 16; j += NTH) {
-    Bl[j] = (j < ncol && a.bias) ? a.bias[col0 + j] : 0.f;
-    Sl[j] = j < ncol ? a.w_s[col0 + j] : 0.f;
-  }
-  {   // weight planes of this column part (self block: columns 0..D-1 of e2e_linear.weight)
-    const int total = tab_stage_rows(CTN) * kTabSlots * 2;
-    constexpr int UN = NW >= 12 ? 3 : 6;
-    for (int base = 0; base < total; base += NTH * UN) {
-      f32x4 v[UN];
-      int off[UN];
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int idx = base + u * NTH + tid;
-        const int j = idx / (kTabSlots * 2), kc = idx - j * (kTabSlots * 2);
-        v[u] = zero4;
-        off[u] = idx < total ? tab_lds_row(j) * RB + kc * 8 : -1;
-        if (idx < total && j < ncol && kc < KC)
-          v[u] = *reinterpret_cast<const f32x4*>(a.W + (size_t)(col0 + j) * a.ldw + 4 * kc);
-      }
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        if (off[u] >= 0) {
-          const Split3 sp = split3(v[u]);
-          unsigned char* dst = lds + off[u];
-          *reinterpret_cast<uint2*>(dst) = sp.hi;
-          *reinterpret_cast<uint2*>(dst + PL) = sp.mid;
-          *reinterpret_cast<uint2*>(dst + 2 * PL) = sp.lo;
-        }
-      }
-    }
-  }
-  // this wave's 16-row tiles
-  const long long U = ((long long)a.M + 15) >> 4;
-  const int c0 = (int)(U * chunk / nchunks), c1 = (int)(U * (chunk + 1) / nchunks);
-  const int nch = c1 - c0;
-  int t = c0 + (int)((long long)nch * wave / NW);
-  const int tend = c0 + (int)((long long)nch * (wave + 1) / NW);
-  const int kmax = D - 8;
-  // 32-bit BYTE offsets from the kernel's uniform base pointers (the launcher admits (M + 1) * D * 4 < 2^32 for this
-  // kernel): scalar base + vector offset addressing, no 64-bit address registers per stream
-  const unsigned char* Ab = reinterpret_cast<const unsigned char*>(a.A);
-  const unsigned char* addb = reinterpret_cast<const unsigned char*>(a.add);
-  unsigned char* Cb = reinterpret_cast<unsigned char*>(a.C);
-  const unsigned rowB = (unsigned)D * 4u;
-  auto a_piece = [&](int tile, int kb, int half) -> f32x4 {
-    const unsigned row = (unsigned)min(tile * 16 + fr, a.M - 1);
-    const unsigned k = (unsigned)(min(32 * kb + 8 * fg, kmax) + 4 * half);
-    return *reinterpret_cast<const f32x4*>(Ab + (size_t)(row * rowB + k * 4u));
-  };
-  // ring of 4 slots: k block kb of a tile lives in slot kb % 4; after slot s has been consumed at step kb it is refilled
-  // with (same tile, kb + 4) for kb = 0..2, with the NEXT tile's k block 3 at kb = 3 and its k blocks 0..2 at kb = 4..6
-  f32x4 ra[4][2];
-  if (t < tend) {
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      ra[kb][0] = a_piece(t, kb, 0);
-      ra[kb][1] = a_piece(t, kb, 1);
-    }
-  }
-  const float bs = a.b_s[0];
-  unsigned fl_next = 0x01010101u;
-  if (FL && t < tend) fl_next = *reinterpret_cast<const unsigned*>(a.add_flag + (size_t)t * 16 + 4 * fg);
-  __syncthreads();
-
-  for (; t < tend; ++t) {
-    const int rbase = t * 16 + 4 * fg;                       // C layout: rows rbase + q, column slot fr
-    const unsigned fl = fl_next;
-    if (FL) fl_next = *reinterpret_cast<const unsigned*>(a.add_flag + (size_t)(t + 1 < tend ? t + 1 : t) * 16 + 4 * fg);
-    f32x4 acc[CTN];
-#pragma unroll
-    for (int nt = 0; nt < CTN; ++nt) acc[nt] = zero4;
-    const int tload = t + 1 < tend ? t + 1 : t;
-    const int fg_t = opaque_i(fg);                           // keeps the (loop invariant) plane reads inside the tile loop
-    constexpr int PA[6] = {1, 2, 0, 1, 0, 0};
-    constexpr int PB[6] = {1, 0, 2, 0, 1, 0};
-    // the epilogue's operands (nbr rows, mask) are requested half way through the k blocks
-    f32x4 addg[4];
-    float addt[CTN > 4 ? CTN - 4 : 1][4];
-    float mrow = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      const bool kok = 32 * kb + 8 * fg_t <= kmax;
-      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-      bf16x8 ap[3];
-      const Split3 s0 = split3(kb < NKB - 1 || kok ? ra[kb & 3][0] : zero4);
-      const Split3 s1 = split3(kb < NKB - 1 || kok ? ra[kb & 3][1] : zero4);
-      ap[0] = __builtin_bit_cast(bf16x8, (u32x4){s0.hi.x, s0.hi.y, s1.hi.x, s1.hi.y});
-      ap[1] = __builtin_bit_cast(bf16x8, (u32x4){s0.mid.x, s0.mid.y, s1.mid.x, s1.mid.y});
-      ap[2] = __builtin_bit_cast(bf16x8, (u32x4){s0.lo.x, s0.lo.y, s1.lo.x, s1.lo.y});
-      {   // refill the slot just consumed (static schedule, see above)
-        const int rt = kb < 3 ? t : tload;
-        const int rk = kb < 3 ? kb + 4 : (kb == 3 ? 3 : kb - 4);
-        ra[kb & 3][0] = a_piece(rt, rk, 0);
-        ra[kb & 3][1] = a_piece(rt, rk, 1);
-      }
-      if (kb == (NW >= 16 ? 5 : 3)) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          int row = min(rbase + q, a.M - 1);
-          if (FL && ((fl >> (8 * q)) & 0xffu) == 0u) row = a.M;      // not a frontier row: the zero row behind the buffer
-          const unsigned ao = (unsigned)row * rowB + (unsigned)col0 * 4u;
-          addg[q] = *reinterpret_cast<const f32x4*>(addb + (size_t)(ao + 4u * (unsigned)min(4 * fr, ncol - 4)));
-#pragma unroll
-          for (int nt = 4; nt < CTN; ++nt)
-            addt[nt - 4][q] = *reinterpret_cast<const float*>(addb + (size_t)(ao + 4u * (unsigned)min(nt * 16 + fr, ncol - 1)));
-        }
-        const int srow = min(rbase + (2 * (fr & 1) + ((fr >> 1) & 1)), a.M - 1);
-        mrow = a.mask[srow];
-      }
-      const unsigned char* wb = lds + fr * RB + kb * 64 + fg_t * 16;
-      if constexpr (NW >= 16) {
-        // 128 registers: one column tile's fragments at a time (a chain of six dependent MFMAs issues at the pipe's
-        // rate - tools/probe/mfma_probe "1acc"), the next tile's fragments requested before the chain
-        bf16x8 bn[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bn[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL));
-#pragma unroll
-        for (int nt = 0; nt < CTN; ++nt) {
-          bf16x8 b0[3];
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) b0[pl] = bn[pl];
-          if (nt + 1 < CTN) {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-              bn[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + (nt + 1) * 16 * RB));
-          }
-#pragma unroll
-          for (int p = 0; p < 6; ++p) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[PA[p]], b0[PB[p]], acc[nt], 0, 0, 0);
-        }
-      } else {
-#pragma unroll
-        for (int nt = 0; nt < CTN; nt += 2) {
-          bf16x8 b0[3], b1[3];
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) {
-            b0[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + nt * 16 * RB));
-            b1[pl] = b0[pl];
-            if (nt + 1 < CTN)
-              b1[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + (nt + 1) * 16 * RB));
-          }
-#pragma unroll
-          for (int p = 0; p < 6; ++p) {
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[PA[p]], b0[PB[p]], acc[nt], 0, 0, 0);
-            if (nt + 1 < CTN)
-              acc[nt + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[PA[p]], b1[PB[p]], acc[nt + 1], 0, 0, 0);
-          }
-        }
-      }
-    }
-    // epilogue from the registers (as k_update_b3)
-    float part[4] = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 bias_g = *reinterpret_cast<const f32x4*>(Bl + min(4 * fr, kTabNTH * 16 - 4));
-    const f32x4 ws_g = *reinterpret_cast<const f32x4*>(Sl + min(4 * fr, kTabNTH * 16 - 4));
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = rbase + q;
-      f32x4 v = {acc[0][q], acc[1][q], acc[2][q], acc[3][q]};
-      v = __builtin_elementwise_max((v + bias_g) + addg[q], zero4);
-      const int c = 4 * fr;
-      if (c + 4 > ncol) {
-        v = zero4;
-      } else if (row < a.M) {
-        *reinterpret_cast<f32x4*>(Cb + (size_t)((unsigned)row * rowB + 4u * (unsigned)(col0 + c))) = v;
-      }
-      part[q] += v[0] * ws_g[0] + v[1] * ws_g[1] + v[2] * ws_g[2] + v[3] * ws_g[3];
-#pragma unroll
-      for (int nt = 4; nt < CTN; ++nt) {
-        const int cc = nt * 16 + fr;
-        float x = fmaxf((acc[nt][q] + Bl[cc]) + addt[nt - 4][q], 0.f);
-        if (cc >= ncol) x = 0.f;
-        else if (row < a.M) *reinterpret_cast<float*>(Cb + (size_t)((unsigned)row * rowB + 4u * (unsigned)(col0 + cc))) = x;
-        part[q] += x * Sl[cc];
-      }
-    }
-    {
-      const float tot = row16_sum4_b3(part, lane);
-      const int srow = rbase + (2 * (fr & 1) + ((fr >> 1) & 1));
-      if (fr < 4 && srow < a.M) {
-        const float share = first_part ? (tot + bs) + (1.0f - mrow) * kVeryNeg : tot;
-        atomicAdd(a.score + srow, share);
-      }
-    }
-  }
-}
-
-template <bool FL, int NW>
-__global__ __launch_bounds__(64 * NW, 1) void k_update_b3w(UpdB3Args a, int nchunks) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int blk = blockIdx.x;
-  const int h = (blk >> 3) & 1;
-  const int chunk = (blk >> 4) * 8 + (blk & 7);
-  if (chunk >= nchunks) return;
-  const int NT = (a.D + 15) >> 4;
-  if (h == 0) update_b3w_part<kTabNTH, FL, NW>(a, lds, 0, true, chunk, nchunks);
-  else if (NT - a.ct0 == 6) update_b3w_part<6, FL, NW>(a, lds, a.ct0 * 16, false, chunk, nchunks);
 }
 
 int update_b3_launch(const float* h, const float* nbr, const float* W, const float* b, const float* w_s, const float* b_s,
@@ -1111,7 +797,8 @@ int update_b3_launch_z(const float* h, const float* nbr, const float* W, const f
 }
 
 bool update_b3_shape_ok(int64_t BN, int32_t D, int32_t ldw) {
-  return !(D % 8 || (D + 31) / 32 != kTabNKB || (D + 15) / 16 != 13 || BN < 8192 || BN * D >= ((int64_t)1 << 31) || ldw % 4);
+  // (32-bit byte offsets from the kernel's base pointers: the zero row behind nbr included)
+  return !(D % 8 || (D + 31) / 32 != kTabNKB || (D + 15) / 16 != 13 || BN < 8192 || (BN + 1) * D * 4 >= ((int64_t)1 << 32) || ldw % 4);
 }
 
 int update_b3_launch_f(const float* h, const float* nbr, const uint8_t* add_flag, const float* W, const float* b,
@@ -1119,14 +806,6 @@ int update_b3_launch_f(const float* h, const float* nbr, const uint8_t* add_flag
                        int32_t D, int32_t ldw, hipStream_t stream, bool score_zeroed) {
   if (!update_b3_shape_ok(BN, D, ldw)) return GNNRAG_E_UNSUPPORTED;
   if ((((uintptr_t)h | (uintptr_t)nbr | (uintptr_t)W | (uintptr_t)h_out) & 15) != 0) return GNNRAG_E_UNSUPPORTED;
-  {   // hidden size 200: the 32x32x16 form (update_x32.hip)
-    const int rc = update_x32_launch_f(h, nbr, add_flag, W, b, w_s, b_s, mask, h_out, score, BN, D, ldw, stream, score_zeroed);
-    if (rc != GNNRAG_E_UNSUPPORTED) return rc;
-  }
-  {   // hidden size 200: the register-resident form (update_wr.hip); it needs no zeroed score
-    const int rc = update_wr_launch_f(h, nbr, add_flag, W, b, w_s, b_s, mask, h_out, score, BN, D, ldw, stream);
-    if (rc != GNNRAG_E_UNSUPPORTED) return rc;
-  }
   UpdB3Args a;
   memset(&a, 0, sizeof(a));
   a.A = h; a.W = W; a.bias = b; a.add = nbr; a.w_s = w_s; a.b_s = b_s; a.mask = mask; a.C = h_out; a.score = score;
@@ -1149,43 +828,8 @@ int update_b3_launch_f(const float* h, const float* nbr, const uint8_t* add_flag
     if (rc) return rc;
   }
   const int nblk = ((chunks + 7) / 8) * 16;
-#if GNNRAG_UPD_WAVES > 8
-  {
-    static DeviceMask capw, capw_f;
-    const int rc = add_flag ? raise_lds_cap(k_update_b3w<true, GNNRAG_UPD_WAVES>, capw_f)
-                            : raise_lds_cap(k_update_b3w<false, GNNRAG_UPD_WAVES>, capw);
-    if (rc) return rc;
-  }
-  if (add_flag) hipLaunchKernelGGL((k_update_b3w<true, GNNRAG_UPD_WAVES>), dim3(nblk), dim3(64 * GNNRAG_UPD_WAVES), 160 * 1024, stream, a, chunks);
-  else hipLaunchKernelGGL((k_update_b3w<false, GNNRAG_UPD_WAVES>), dim3(nblk), dim3(64 * GNNRAG_UPD_WAVES), 160 * 1024, stream, a, chunks);
-#else
-  // 7 : 6 chunk counts for the two column parts (one workgroup per CU, both counts whole XCD eighths, >= 4 tiles per wave)
-  int n0 = chunks, n1 = 0, grid = nblk;
-#if GNNRAG_UPD_BALANCE
-  if (cus >= 64 && cus % 8 == 0 && U >= (long long)cus * 16) {
-    // waves own whole tiles, so what counts is the LARGEST tile count of a wave in each part: pick the split (in whole XCD
-    // eighths) with the smallest max(ceil(ceil(U / c0) / 8) * 7, ceil(ceil(U / c1) / 8) * 6), nearest to 7 : 6 among equals
-    // (C2, 8000 tiles on 256 CUs: 144 + 112 -> 7 tiles x 7 and 9 tiles x 6 = 54 units where equal chunks need 8 x 7 = 56)
-    long long best_cost = -1, best_skew = 0;
-    for (int c0 = 8; c0 + 8 <= cus; c0 += 8) {
-      const int c1 = cus - c0;
-      const long long t0 = ((U + c0 - 1) / c0 + 7) / 8 * 7, t1 = ((U + c1 - 1) / c1 + 7) / 8 * 6;
-      const long long cost = t0 > t1 ? t0 : t1;
-      long long skew = (long long)c0 * 6 - (long long)c1 * 7;
-      if (skew < 0) skew = -skew;
-      if (best_cost < 0 || cost < best_cost || (cost == best_cost && skew < best_skew)) {
-        best_cost = cost;
-        best_skew = skew;
-        n0 = c0;
-        n1 = c1;
-      }
-    }
-    if (n1 > 0) grid = cus;
-  }
-#endif
-  if (add_flag) hipLaunchKernelGGL(k_update_b3<true>, dim3(grid), dim3(512), 160 * 1024, stream, a, n0, n1);
-  else hipLaunchKernelGGL(k_update_b3<false>, dim3(grid), dim3(512), 160 * 1024, stream, a, n0, n1);
-#endif
+  if (add_flag) hipLaunchKernelGGL(k_update_b3<true>, dim3(nblk), dim3(512), 160 * 1024, stream, a, chunks);
+  else hipLaunchKernelGGL(k_update_b3<false>, dim3(nblk), dim3(512), 160 * 1024, stream, a, chunks);
   GNNRAG_LAUNCH_CHECK();
   return 0;
 }

@@ -70,7 +70,7 @@ def test_self_block_update_large_m_every_hidden_size_vs_fp64(dev, M, D, math):
 @pytest.mark.parametrize("M", [70001, 131072 + 17])
 def test_self_block_update_very_large_ragged_rows_vs_fp64(dev, M):
     """k_update_b3 at row counts beyond 65 536 that are not a multiple of 16 or of the chunk count (round 4; also the shape
-    class of the 7 : 6 chunking experiment, GNNRAG_UPD_BALANCE): every row and every score against float64, masked scores
+    size at which the kernel's 32-bit byte offsets are exercised near their upper rows): every row and every score against float64, masked scores
     exactly -1e11, two runs bit-identical."""
     from gnnrag_amd import ops
     D, I = 200, 2
@@ -183,18 +183,3 @@ def test_module_path_graph_replay_is_bit_identical_to_eager(dev):
         for key in ("score", "dist", "h"):
             for c in range(cfg.T * cfg.L):
                 assert np.array_equal(recs[("eager", rep)][key][c], recs[("graph", rep)][key][c]), (key, c, rep)
-
-
-def test_register_resident_update_kernel_in_a_fresh_process():
-    """k_update_wr (update_wr.hip: W planes in registers, h split once per workgroup through an LDS ring, scores without
-    atomics) is parity-green but measured slower than k_update_b3, so it is opt-in (GNNRAG_UPDATE_WR=1, read when the
-    library is first used): the full-size C2 gates through it, dense and gated (frontier) form, in a process of its own."""
-    import os
-    import subprocess
-    import sys
-    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GNNRAG_UPDATE_WR="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu",
-                        "tests/test_gpu_baseline_shapes.py::test_c2_full_batch_against_oracle_slices", "-k", "fused and mixed"],
-                       cwd=repo, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

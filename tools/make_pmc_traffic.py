@@ -51,11 +51,11 @@ def totals(fetch, write):
     res.update(aggregate_fetch_bytes_raw=f, aggregate_write_bytes=w, aggregate_hbm_bytes_per_launch=2 * f + w)
     # the self-block update with a dense nbr (k_update_b3<false>); its row-gated form of layer 0 (k_update_b3<true>, rows off
     # the frontier read a zero row) is a different launch and is kept apart
-    f, w = group(lambda k: ("k_update_b3ILb0E" in k) or ("k_update_wrILb0E" in k) or ("k_update_x32ILb0E" in k))
+    f, w = group(lambda k: ("k_update_b3ILb0E" in k))
     if f or w:
         res.update(update_score_fused_fetch_bytes_raw=f, update_score_fused_write_bytes=w,
                    update_score_fused_hbm_bytes_per_launch=2 * f + w)
-    f, w = group(lambda k: ("k_update_b3ILb1E" in k) or ("k_update_wrILb1E" in k) or ("k_update_x32ILb1E" in k))
+    f, w = group(lambda k: ("k_update_b3ILb1E" in k))
     if f or w:
         res.update(update_score_gated_fetch_bytes_raw=f, update_score_gated_write_bytes=w,
                    update_score_gated_hbm_bytes_per_launch=2 * f + w)
@@ -105,11 +105,11 @@ def totals(fetch, write):
     res.update(aggregate_fetch_bytes_raw=f, aggregate_write_bytes=w, aggregate_hbm_bytes_per_launch=2 * f + w)
     # the self-block update with a dense nbr (k_update_b3<false>); its row-gated form of layer 0 (k_update_b3<true>, rows off
     # the frontier read a zero row) is a different launch and is kept apart
-    f, w = group(lambda k: ("k_update_b3ILb0E" in k) or ("k_update_wrILb0E" in k) or ("k_update_x32ILb0E" in k))
+    f, w = group(lambda k: ("k_update_b3ILb0E" in k))
     if f or w:
         res.update(update_score_fused_fetch_bytes_raw=f, update_score_fused_write_bytes=w,
                    update_score_fused_hbm_bytes_per_launch=2 * f + w)
-    f, w = group(lambda k: ("k_update_b3ILb1E" in k) or ("k_update_wrILb1E" in k) or ("k_update_x32ILb1E" in k))
+    f, w = group(lambda k: ("k_update_b3ILb1E" in k))
     if f or w:
         res.update(update_score_gated_fetch_bytes_raw=f, update_score_gated_write_bytes=w,
                    update_score_gated_hbm_bytes_per_launch=2 * f + w)
@@ -150,11 +150,11 @@ def main(fetch_db, write_db, out, workload="C2"):
     res.update(aggregate_fetch_bytes_raw=f, aggregate_write_bytes=w, aggregate_hbm_bytes_per_launch=2 * f + w)
     # the self-block update with a dense nbr (k_update_b3<false>); its row-gated form of layer 0 (k_update_b3<true>, rows off
     # the frontier read a zero row) is a different launch and is kept apart
-    f, w = group(lambda k: ("k_update_b3ILb0E" in k) or ("k_update_wrILb0E" in k) or ("k_update_x32ILb0E" in k))
+    f, w = group(lambda k: ("k_update_b3ILb0E" in k))
     if f or w:
         res.update(update_score_fused_fetch_bytes_raw=f, update_score_fused_write_bytes=w,
                    update_score_fused_hbm_bytes_per_launch=2 * f + w)
-    f, w = group(lambda k: ("k_update_b3ILb1E" in k) or ("k_update_wrILb1E" in k) or ("k_update_x32ILb1E" in k))
+    f, w = group(lambda k: ("k_update_b3ILb1E" in k))
     if f or w:
         res.update(update_score_gated_fetch_bytes_raw=f, update_score_gated_write_bytes=w,
                    update_score_gated_hbm_bytes_per_launch=2 * f + w)
