@@ -23,6 +23,10 @@ import torch
 from . import ops
 
 
+# what the compacted batches of this process held (tools/run_reference.py prints it with its stage timers): the Evaluator's
+# tail is the reference's own per-candidate Python, so its cost follows `retrieved`, not the subgraph width
+STATS = {"questions": 0, "retrieved": 0, "retrieved_max": 0}
+
 TOPP_MAX_N = 1 << 24    # the kernel takes any N (questions with > 16384 slots filter first and sort the survivors in a
                         # workspace); beyond 2^24 slots the batch is left as it is and the reference's own loop walks it
 
@@ -63,7 +67,10 @@ def compact_batch(pred_dist: torch.Tensor, local_entity: np.ndarray, query_entit
     the retrieved slots best first, then pad entities with probability 0 (the reference's filter skips them,
     evaluate.py:201-202).  pred_dist' is a CPU tensor (the reference calls ``.tolist()`` on its rows).  No per-question
     Python: one gather on the device, one ``take_along_axis`` on the host."""
-    ents, probs, _, _ = _retrieved_arrays(pred_dist, local_entity, query_entities, pad_ent_id, ignore_prob, eps)
+    ents, probs, k, _ = _retrieved_arrays(pred_dist, local_entity, query_entities, pad_ent_id, ignore_prob, eps)
+    STATS["questions"] += int(len(k))
+    STATS["retrieved"] += int(k.sum())
+    STATS["retrieved_max"] = max(STATS["retrieved_max"], int(k.max()) if len(k) else 0)
     return ents, np.zeros(ents.shape, dtype=np.asarray(query_entities).dtype), probs
 
 

@@ -25,7 +25,9 @@ cd $R
 python tools/rocpd_stats.py $(find $OUT/trace -name 'bench_results.db' | head -1) > $OUT/kernel_stats_bench.txt 2>&1
 for W in C1 C3 C4 C5 C2fb C2u; do
   cp $OUT/pmc_traffic_$W.json $R/profiles/pmc_traffic.json 2>/dev/null || cp $OUT/pmc_traffic_C2.json $R/profiles/pmc_traffic.json
-  python bench.py --workload $W --no-cpu-baseline --steps 30 > $OUT/bench_$W.log 2>&1
+  # BASELINE configs 4 and 5 also get the reference's CPU path beside them (4 questions of the same shape)
+  case $W in C4|C5) CPUFLAGS="--cpu-sample-b 4 --no-e2e";; *) CPUFLAGS="--no-cpu-baseline";; esac
+  python bench.py --workload $W $CPUFLAGS --steps 30 > $OUT/bench_$W.log 2>&1
 done
 cp $OUT/pmc_traffic_C2.json $R/profiles/pmc_traffic.json
 for W in C1 C3; do

@@ -136,6 +136,8 @@ def main():
         print("gnnrag_amd: native library %s" % ("mapped: " + mapped[0] if mapped else "NOT loaded"))
         if times is not None:
             import json
+            if not os.environ.get("GNNRAG_NO_EVAL_PATCH"):
+                times["retrieved"] = dict(eval_tail.STATS)      # candidates the Evaluator's own loop walked
             print("GNNRAG_E2E " + json.dumps(times))
 
 
