@@ -260,7 +260,8 @@ class ReasonGNNLayer(BaseGNNLayer):
         # (a dense, differentiable expression over a few ten thousand rows) and the fused walk with its own backward:
         # agg [BN, 2I D] and the K = 2I D product never exist.  GNNRAG_TRAIN_FUSED=0 keeps the unfused autograd form.
         drop_active = self.training and self.linear_dropout > 0
-        if native and self.train_fused and not drop_active and self.plan.rel_total > 0:
+        # (the fused walk's backward gathers whole rows: D <= 1024; beyond that the unfused form below keeps its LDS-sum backward)
+        if native and self.train_fused and not drop_active and self.plan.rel_total > 0 and D <= 1024:
             W = e2e_linear.weight
             P = relation_tables_dense(self.plan, T_fwd, T_inv, relational_ins.float(), W)
             nbr = FusedAggregateFn.apply(self.plan, current_dist.float(), P)

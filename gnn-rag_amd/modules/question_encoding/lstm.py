@@ -30,6 +30,8 @@ class HipLSTM(nn.LSTM):
     def forward(self, input, hx=None):  # noqa: A002  (torch's own argument name)
         fast = (_eligible(self) and isinstance(input, torch.Tensor) and input.is_cuda and input.dim() == 3 and
                 input.dtype == torch.float32 and input.shape[0] > 0 and input.shape[1] > 0 and
+                all(p.dtype == torch.float32 and p.is_cuda for p in self.parameters()) and
+                (hx is None or all(isinstance(t, torch.Tensor) and t.dtype == torch.float32 and t.is_cuda for t in hx)) and
                 not (torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters()))))
         if not fast:
             return super().forward(input, hx)

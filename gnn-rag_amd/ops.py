@@ -1013,9 +1013,12 @@ def lstm_forward(x, w_ih, w_hh, b_ih=None, b_hh=None, h0=None, c0=None):
     h_n = torch.empty((B, H), dtype=torch.float32, device=dev)
     c_n = torch.empty((B, H), dtype=torch.float32, device=dev)
     need = lib.gnnrag_lstm_workspace_bytes(E, H)
-    ws = _lstm_ws.get(dev)
+    # one workspace per (device, stream): two calls on different streams of one device must not share the transposed-weight
+    # scratch (calls on one stream are ordered)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _lstm_ws.get(key)
     if ws is None or ws.numel() < need:
-        ws = _lstm_ws[dev] = torch.empty(need, dtype=torch.uint8, device=dev)
+        ws = _lstm_ws[key] = torch.empty(need, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         _lib.check(lib.gnnrag_lstm_forward(x.data_ptr(), w_ih.data_ptr(), w_hh.data_ptr(), _ptr(b_ih), _ptr(b_hh), _ptr(h0),
                                            _ptr(c0), out.data_ptr(), h_n.data_ptr(), c_n.data_ptr(), B, T, E, H,
