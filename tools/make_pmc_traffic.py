@@ -120,11 +120,6 @@ def main(fetch_db, write_db, out, workload="C2"):
     fetch, nf = per_kernel(fetch_db, "FETCH_SIZE")
     write, _ = per_kernel(write_db, "WRITE_SIZE")
 
-    def group(pred, launches_per_call=1.0):
-        f = sum(v for k, v in fetch.items() if pred(k)) * 1024.0
-        w = sum(v for k, v in write.items() if pred(k)) * 1024.0
-        return f, w
-
     import os
     import subprocess
     import sys as _sys
@@ -139,25 +134,7 @@ def main(fetch_db, write_db, out, workload="C2"):
            "workload": workload, "commit": commit or os.environ.get("GNNRAG_COMMIT", "unknown (no .git on the GPU box)"),
            "kernel_sources_sha256": bench.kernel_sources_digest(),
            "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests at 64 B)"}
-    f, w = group(lambda k: "k_walk_slice" in k or "k_fact_prior" in k or ("k_walk_light" in k and "ILi2E" in k)
-                 or ("k_heavy" in k and "ILi2E" in k) or "k_hub_" in k)
-    res.update(aggregate_fused_fetch_bytes_raw=f, aggregate_fused_write_bytes=w,
-               aggregate_fused_hbm_bytes_per_launch=2 * f + w)
-    # the seed-prior (frontier) form of layer 0: frontier + table rows + neighbour sums of the frontier
-    f, w = group(lambda k: "k_frontier_build" in k or "k_tables_frontier" in k or "k_walk_frontier" in k)
-    res.update(frontier_fetch_bytes_raw=f, frontier_write_bytes=w, frontier_hbm_bytes_per_launch=2 * f + w)
-    f, w = group(lambda k: ("k_walk_light" in k or "k_heavy" in k) and "ILi0E" in k)
-    res.update(aggregate_fetch_bytes_raw=f, aggregate_write_bytes=w, aggregate_hbm_bytes_per_launch=2 * f + w)
-    # the self-block update with a dense nbr (k_update_b3<false>); its row-gated form of layer 0 (k_update_b3<true>, rows off
-    # the frontier read a zero row) is a different launch and is kept apart
-    f, w = group(lambda k: ("k_update_b3ILb0E" in k))
-    if f or w:
-        res.update(update_score_fused_fetch_bytes_raw=f, update_score_fused_write_bytes=w,
-                   update_score_fused_hbm_bytes_per_launch=2 * f + w)
-    f, w = group(lambda k: ("k_update_b3ILb1E" in k))
-    if f or w:
-        res.update(update_score_gated_fetch_bytes_raw=f, update_score_gated_write_bytes=w,
-                   update_score_gated_hbm_bytes_per_launch=2 * f + w)
+    res.update(totals(fetch, write))          # one grouping for fresh runs and --recompute
     res["per_kernel_fetch_KB"] = {k[:60]: v for k, v in fetch.items() if "gnnrag" in k}
     res["per_kernel_write_KB"] = {k[:60]: v for k, v in write.items() if "gnnrag" in k}
     json.dump(res, open(out, "w"), indent=1)
