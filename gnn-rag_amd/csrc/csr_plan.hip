@@ -8,12 +8,13 @@
 //   value = fact id, stable LSD radix sort over ceil(log2(B*N)) bits  ->  facts of one
 //   destination are contiguous and in ascending fact id (one fixed summation order); hub rows
 //   (> kHeavyDeg facts) of large vocabularies are then put in (relation, fact id) order by a
-//   segmented sort over those rows (see hub_sort_scratch) - also one fixed order.
+//   second stable sort over (segment, relation) keys (see hub_sort_scratch) - also one fixed order.
 //
 // The sorts are rocPRIM's device radix sorts (plain library ops); everything around them
 // (record gather, row pointers, ordered hub lists, relation compaction, merged stream) is hand
 // written.  All of it is HBM-bound integer work: coalesced 4/8-byte streams; the only atomics are
 // the per-question appends of the LDS walk's big-node lists (order irrelevant).
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -90,8 +91,15 @@ static size_t sort_temp_bytes(int64_t F, unsigned bits) {
 // Hub rows (more than kHeavyDeg facts) are put in RELATION order at plan time (stable inside a relation): the walk adds
 // the priors of a run of equal relations and gathers the run's table row once (k_heavy_partial) - a Freebase hub has
 // far more facts than distinct relations (BASELINE config 5: 183 000 hub facts of a question, 56 000 distinct (hub,
-// relation) pairs).  rocPRIM's segmented radix sort over the hub rows' (relation, fact id) pairs; every other row keeps
-// the fact order.  Scratch: two key arrays, a second fact-id array, the segment bounds and rocPRIM's own.
+// relation) pairs).  Every other row keeps the fact order.
+//
+// The hub rows are disjoint, ascending ranges of the destination-sorted positions, so ONE more stable radix sort does
+// it: position i gets the key (segment(i) << relation bits) | relation, where the segments alternate between "the run of
+// ordinary rows in front of hub j" (even ids, relation field 0: the stable sort leaves the run as it is) and "hub j" (odd
+// ids).  ceil(log2(2 heavy_cap + 1)) + ceil(log2(R1)) bits - 25 at BASELINE config 5, four one-sweep passes over F pairs
+// (~0.25 ms) where rocPRIM's segmented sort spent 0.98 ms on the same rows (one workgroup per segment: 37 long segments
+// per question do not fill the chip).  The segmented sort stays as the form for keys wider than 32 bits.
+// Scratch: two key arrays, a second fact-id array, the segment bounds and rocPRIM's own.
 static size_t seg_sort_temp_bytes(int64_t F, int32_t segments, unsigned bits) {
   size_t bytes = 0;
   const uint32_t* kin = nullptr;
@@ -106,6 +114,28 @@ static size_t seg_sort_temp_bytes(int64_t F, int32_t segments, unsigned bits) {
     bytes = (size_t)16 * (size_t)(F > 0 ? F : 1) + (size_t)64 * (size_t)segments + ((size_t)1 << 20);
   }
   return bytes;
+}
+
+static size_t pair_sort_temp_bytes(int64_t F, unsigned bits) {
+  size_t bytes = 0;
+  const uint32_t* kin = nullptr;
+  uint32_t* kout = nullptr;
+  const int32_t* vin = nullptr;
+  int32_t* vout = nullptr;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, (size_t)F, 0u, bits, (hipStream_t)0, false);
+  if (e != hipSuccess || bytes == 0) {
+    (void)hipGetLastError();
+    bytes = (size_t)16 * (size_t)(F > 0 ? F : 1) + ((size_t)1 << 20);
+  }
+  return bytes;
+}
+
+// bits of the (segment, relation) key of the hub sort; > 32: the segmented form (GNNRAG_HUB_SORT=segmented asks for it
+// at any size - the tests run both forms against the same numpy order)
+static unsigned hub_key_bits(int32_t R1, int32_t heavy_cap) {
+  const char* e = getenv("GNNRAG_HUB_SORT");        // read per call: a test switches it between two builds
+  if (e && strcmp(e, "segmented") == 0) return 64;
+  return key_bits((size_t)2 * (size_t)heavy_cap + 2) + key_bits((size_t)R1);
 }
 
 // A vocabulary of at most kHubSortMinR1 table rows always fits the LDS walk (aggregate.hip, slice_walk_fits: 2 (R1 + 1)
@@ -134,7 +164,8 @@ static HubSortScratch hub_sort_scratch(int64_t F, int32_t R1, int32_t heavy_cap)
   H.key_out = take(Fp * sizeof(uint32_t));
   H.perm2 = take(Fp * sizeof(int32_t));
   H.seg = take((size_t)2 * heavy_cap * sizeof(int32_t));
-  H.temp = take(seg_sort_temp_bytes(F, heavy_cap, key_bits((size_t)R1)));
+  const unsigned hb = hub_key_bits(R1, heavy_cap);
+  H.temp = take(hb <= 32 ? pair_sort_temp_bytes(F, hb) : seg_sort_temp_bytes(F, heavy_cap, key_bits((size_t)R1)));
   H.total = off;
   return H;
 }
@@ -144,6 +175,36 @@ __global__ __launch_bounds__(256) void k_csr_relkey(const int32_t* __restrict__ 
                                                     int64_t F, uint32_t* __restrict__ key) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < F) key[i] = (uint32_t)rels[perm[i]];
+}
+
+// key[i] = (segment of sorted position i, relation of the fact there if the segment is a hub row): see
+// seg_sort_temp_bytes' comment.  seg_begin / seg_end are the hub rows in ascending order (k_csr_hub_segments); the
+// position's segment is found by a binary search whose bounds the workgroup's first and last position fix in LDS.
+__global__ __launch_bounds__(256) void k_csr_segkey(const int32_t* __restrict__ perm, const int32_t* __restrict__ rels,
+                                                    int64_t F, const int32_t* __restrict__ seg_begin,
+                                                    const int32_t* __restrict__ seg_end,
+                                                    const int32_t* __restrict__ count, int32_t cap, unsigned rel_bits,
+                                                    uint32_t* __restrict__ key) {
+  __shared__ int s_lo, s_hi;
+  const int nh = min(*count, cap);
+  const int64_t i0 = (int64_t)blockIdx.x * 256;
+  auto upper = [&](int64_t pos, int lo, int hi) {      // number of hub rows that begin at or before pos
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((int64_t)seg_begin[mid] <= pos) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  if (threadIdx.x == 0) s_lo = upper(i0, 0, nh);
+  if (threadIdx.x == 64) s_hi = upper(min(i0 + 255, F - 1), 0, nh);
+  __syncthreads();
+  const int64_t i = i0 + threadIdx.x;
+  if (i >= F) return;
+  const int j = upper(i, s_lo, s_hi);
+  const bool in_hub = j > 0 && i < (int64_t)seg_end[j - 1];
+  // (an out-of-range relation id - the build rejects the tuple afterwards - must not reach the segment bits)
+  key[i] = in_hub ? (((uint32_t)(2 * j - 1) << rel_bits) | ((uint32_t)rels[perm[i]] & ((1u << rel_bits) - 1u)))
+                  : ((uint32_t)(2 * j) << rel_bits);
 }
 
 // the hub rows as sort segments: [row_ptr[n], row_ptr[n + 1]) for the listed nodes, empty for the unused list entries
@@ -901,14 +962,23 @@ extern "C" int gnnrag_csr_build_counts(const int32_t* heads, const int32_t* rels
       hipLaunchKernelGGL(k_csr_hub_segments, dim3((L.heavy_cap + 255) / 256), dim3(256), 0, stream, out->row_ptr[d],
                          out->heavy[d], out->n_heavy + d, L.heavy_cap, seg_begin, seg_end);
       GNNRAG_LAUNCH_CHECK();
-      hipLaunchKernelGGL(k_csr_relkey, dim3(nb), dim3(256), 0, stream, out->perm[d], rels, F, key_in);
-      GNNRAG_LAUNCH_CHECK();
-      GNNRAG_HIP(hipMemcpyAsync(perm2, out->perm[d], (size_t)F * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+      const unsigned rb = key_bits((size_t)R1), hb = hub_key_bits(R1, L.heavy_cap);
       size_t stb = H.total - H.temp;
-      GNNRAG_HIP(rocprim::segmented_radix_sort_pairs(hub_base + H.temp, stb, (const uint32_t*)key_in, key_out,
-                                                     (const int32_t*)out->perm[d], perm2, (unsigned)F,
-                                                     (unsigned)L.heavy_cap, (const int32_t*)seg_begin,
-                                                     (const int32_t*)seg_end, 0u, key_bits((size_t)R1), stream, false));
+      if (hb <= 32) {
+        hipLaunchKernelGGL(k_csr_segkey, dim3(nb), dim3(256), 0, stream, out->perm[d], rels, F, seg_begin, seg_end,
+                           out->n_heavy + d, L.heavy_cap, rb, key_in);
+        GNNRAG_LAUNCH_CHECK();
+        GNNRAG_HIP(rocprim::radix_sort_pairs(hub_base + H.temp, stb, (const uint32_t*)key_in, key_out,
+                                             (const int32_t*)out->perm[d], perm2, (size_t)F, 0u, hb, stream, false));
+      } else {
+        hipLaunchKernelGGL(k_csr_relkey, dim3(nb), dim3(256), 0, stream, out->perm[d], rels, F, key_in);
+        GNNRAG_LAUNCH_CHECK();
+        GNNRAG_HIP(hipMemcpyAsync(perm2, out->perm[d], (size_t)F * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+        GNNRAG_HIP(rocprim::segmented_radix_sort_pairs(hub_base + H.temp, stb, (const uint32_t*)key_in, key_out,
+                                                       (const int32_t*)out->perm[d], perm2, (unsigned)F,
+                                                       (unsigned)L.heavy_cap, (const int32_t*)seg_begin,
+                                                       (const int32_t*)seg_end, 0u, rb, stream, false));
+      }
       GNNRAG_HIP(hipMemcpyAsync(out->perm[d], perm2, (size_t)F * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
     }
     if (F > 0) {

@@ -107,6 +107,48 @@ def test_csr_plan_bit_exact(dev, name):
         assert got["n_heavy"].sum() > 0, "the Zipf hub must exercise the heavy-row path"
 
 
+@pytest.mark.parametrize("form", ["keys", "segmented"])
+def test_csr_hub_rows_in_relation_order(dev, form, monkeypatch):
+    """Hub rows (> 256 facts) of a large vocabulary are stored in (relation, fact id) order (csr_plan.hip: one stable sort
+    over (segment, relation) keys; GNNRAG_HUB_SORT=segmented = rocPRIM's segmented sort, the form for keys wider than 32
+    bits): both forms against numpy's lexsort, on hubs placed where a segment search can go wrong - the first row, two
+    adjacent rows, the last row of a question, the last row of the batch, a question without any, in both directions."""
+    from gnnrag_amd import ops
+    if form == "segmented":
+        monkeypatch.setenv("GNNRAG_HUB_SORT", "segmented")
+    else:
+        monkeypatch.delenv("GNNRAG_HUB_SORT", raising=False)
+    rng = np.random.default_rng(11)
+    B, N, R1 = 4, 300, 3000
+    parts = []
+
+    def star(q, hub, n, inverse):              # n facts between random nodes of question q and its node `hub`
+        other = q * N + rng.integers(0, N, n)
+        centre = np.full(n, q * N + hub)
+        rel = rng.integers(0, R1, n)
+        parts.append((centre, rel, other) if inverse else (other, rel, centre))
+
+    star(0, 0, 700, False); star(0, 1, 300, False); star(0, 1, 280, True)
+    star(1, N - 1, 500, False); star(1, 150, 257, True); star(1, 151, 256, True)      # 256 facts: NOT a hub
+    star(3, N - 1, 900, True); star(3, N - 2, 400, True); star(3, N - 1, 300, False)
+    for q in range(B):                         # ordinary rows around them (question 2 has nothing else)
+        n = 1500
+        parts.append((q * N + rng.integers(0, N, n), rng.integers(0, R1, n), q * N + rng.integers(0, N, n)))
+    h = np.concatenate([p[0] for p in parts]).astype(np.int32)
+    r = np.concatenate([p[1] for p in parts]).astype(np.int32)
+    t = np.concatenate([p[2] for p in parts]).astype(np.int32)
+    mix = rng.permutation(len(h))
+    h, r, t = h[mix], r[mix], t[mix]
+    got = ops.CsrPlan(h, r, t, B, N, R1, dev).to_host()
+    want = _csr_numpy(h, r, t, B, N, R1)
+    for k, v in want.items():
+        np.testing.assert_array_equal(got[k], v, err_msg="%s (%s)" % (k, form))
+    for d in (0, 1):
+        deg = np.diff(want["row_ptr%d" % d])
+        assert (deg > 256).sum() >= 4 and (deg == 0).any()
+        np.testing.assert_array_equal(got["heavy%d" % d], np.flatnonzero(deg > 256).astype(np.int32))
+
+
 def test_csr_plan_empty_and_validation(dev):
     from gnnrag_amd import ops
     z = np.zeros(0, np.int64)
