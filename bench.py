@@ -115,8 +115,11 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import gnnrag_amd  # noqa: F401
-    from gnnrag_amd import _lib, ops, shard, stack, synth
+    from gnnrag_amd import _lib, install, ops, shard, stack, synth
     _lib.load()
+    # the rank drives one GPU: no OpenMP team (install.limit_host_threads - spinning workers exhaust a container's CPU quota
+    # and the kernel then parks the launching thread too); the CPU-baseline legs set their own thread counts later
+    install.limit_host_threads()
     if args.math != "default":
         ops.set_dense_math({"fp32": ops.MATH_FP32, "bf16x3": ops.MATH_BF16X3, "mixed": ops.MATH_MIXED}[args.math])
     math_name = ops.MATH_NAMES[ops.get_dense_math()]
@@ -849,8 +852,11 @@ def e2e_leg():
     import stage_ref
     if not stage_ref.staged():
         return {"skipped": "oracle/_ref not staged (python oracle/stage_ref.py in the build container)"}
+    from gnnrag_amd.install import host_cpu_budget
     ncpu = os.cpu_count() or 1
-    cpu_threads = min(32, ncpu)
+    # the CPU leg gets the cores the container may really use (cgroup CFS quota): more OpenMP threads than that are parked
+    # by the kernel for the rest of every 100 ms period and the baseline would be slower than the reference can be here
+    cpu_threads = min(32, ncpu, host_cpu_budget())
 
     def run(variant, pure, batch, data=None, extra_env=None):
         argv = list(stage_ref.variant_argv(variant))
@@ -889,14 +895,18 @@ def e2e_leg():
                 "stages_ms_per_batch": {"get_batch": 1e3 * test["get_batch_s"] / nb, "structure_build": 1e3 * test["structure_s"] / nb,
                                         "forward_without_structure": 1e3 * fwd / nb, "evaluator_tail": 1e3 * tail / nb},
                 "test_f1_h1": [float(x) for x in h1[-1]] if h1 else None, "process_wall_s": wall,
-                "threads": T.get("threads") if pure else None,
+                "threads": T.get("threads"),
                 # the tail is the reference's own per-candidate Python (metrics, json.dumps of every retrieved candidate):
                 # its cost follows the number of RETRIEVED candidates.  This synthetic model is unsure about a third of its
                 # questions and retrieves hundreds of near-tied candidates for them; WebQSP's released model retrieves 8.1
                 # per question on average - `evaluator_tail_at_8_per_question_ms` rescales by that ratio
                 "retrieved_candidates": _tail_stats(T.get("retrieved"), 1e3 * tail / nb, batch)}
 
-    out = {"entry": "unmodified gnn/main.py --is_eval via tools/run_reference.py; staged synthetic datasets (oracle/stage_ref.py: "
+    out = {"host_cpu_quota_cores": host_cpu_budget(),
+           "host_threads": "GPU legs: install.limit_host_threads() (min(8, quota / 2) intra-op threads: the driving process "
+                           "needs no OpenMP team, and a spinning one exhausts the CPU quota - 68-78 ms pauses of every thread, "
+                           "profiles/r05i_forward_host_time.txt); CPU leg: min(32, quota) threads",
+           "entry": "unmodified gnn/main.py --is_eval via tools/run_reference.py; staged synthetic datasets (oracle/stage_ref.py: "
                     "a relation path from the seed determines the answer; 520 test questions, subgraphs up to 2000 entities; 24 "
                     "relation types for d50, 12 for d200)",
            "host_cores": ncpu}
@@ -965,9 +975,10 @@ def reference_cpu_leg(cfg, sample_b):
                 dist, _ = layer(dist, ins, step=j)
             return t1 - t0, time.perf_counter() - t1
 
+    from gnnrag_amd.install import host_cpu_budget
     ncpu = os.cpu_count() or 1
     best = None
-    for nt in sorted({c for c in (16, 32, 64) if c <= ncpu} or {ncpu}):
+    for nt in sorted({c for c in (host_cpu_budget(), 16, 32, 64) if c <= ncpu} or {ncpu}):
         torch.set_num_threads(nt)
         _, dt = one_pass()
         if best is None or dt < best[0]:
@@ -1038,8 +1049,9 @@ def port_cpu_leg(cfg, sample_b):
 
     # torch-CPU does not scale to every core of a big host (256 threads ran 2x slower than 32 on
     # the GPU box): probe a few thread counts on one pass each and keep the fastest
+    from gnnrag_amd.install import host_cpu_budget
     best = None
-    for nt in sorted({c for c in (16, 32, 64) if c <= ncpu} or {ncpu}):
+    for nt in sorted({c for c in (host_cpu_budget(), 16, 32, 64) if c <= ncpu} or {ncpu}):
         torch.set_num_threads(nt)
         t0 = time.perf_counter()
         one_pass()

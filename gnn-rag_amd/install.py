@@ -37,6 +37,60 @@ def install() -> None:
         sys.modules[ref_name] = importlib.import_module(our_name)
 
 
+def host_cpu_budget() -> int:
+    """CPU cores this process may actually use: ``os.cpu_count()`` capped by the cgroup's CFS quota (``cpu.max`` of
+    cgroup v2, ``cpu.cfs_quota_us / cpu.cfs_period_us`` of v1).  A container on a 256-thread host is typically given a
+    fraction of it, and ``os.cpu_count()`` (hence torch's / OpenMP's default thread count) does not know."""
+    import os
+    n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def limit_host_threads(n: int | None = None) -> int:
+    """Intra-op CPU threads of the process that DRIVES the GPU: ``min(8, host_cpu_budget() // 2)`` unless given.
+    The GPU path leaves the host a few hundred small launches and a handful of [B, N] conversions per forward - nothing to
+    parallelise - but torch starts one OpenMP worker per visible hardware thread, and the workers spin after every
+    parallel region.  On the MI355X box (256 hardware threads visible, a 16-core CFS quota) that exhausts the quota: the
+    kernel parks EVERY thread of the process for the rest of the 100 ms period, the launching thread included.  Measured
+    through the unmodified main.py (profiles/r05i_forward_host_time.txt): a 64-question forward 12-22 ms -> 4.8 ms of
+    host time, one 68-78 ms pause every few batches -> none, ``nr_throttled`` 17 -> 0.  Returns the thread count set."""
+    import torch
+    if n is None:
+        n = max(1, min(8, host_cpu_budget() // 2))
+    torch.set_num_threads(int(n))
+    return int(n)
+
+
+def freeze_loaded_data() -> int:
+    """Call once after the reference has loaded its data and built its model (and before the evaluation / training
+    loop): ``gc.collect(); gc.freeze()``.  The reference's loaders (dataset_load.py:24-160) keep every question of every
+    split as Python lists / dicts / numpy rows - millions of container objects - and CPython's cyclic collector walks
+    all of them at every full collection (1.2 million objects for the 680 staged questions; WebQSP has 4 700).  Frozen
+    objects are never walked again; nothing is leaked that the run would have freed.  On the staged data the collector
+    turned out NOT to be what paused the forward (two collections of 0.04 ms inside 8 forwards - the pauses were CPU-quota
+    throttling, see limit_host_threads); the freeze is kept as the cheap insurance it is for the full-size datasets.
+    Returns the number of frozen objects."""
+    import gc
+    gc.collect()
+    gc.freeze()
+    return gc.get_freeze_count()
+
+
 def uninstall() -> None:
     for ref_name in _TARGETS:
         m = sys.modules.get(ref_name)

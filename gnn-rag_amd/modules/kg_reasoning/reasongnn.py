@@ -150,7 +150,8 @@ class ReasonGNNLayer(BaseGNNLayer):
         if self.use_posemb:
             for j in range(self.num_gnn):
                 src += [getattr(self, "pos_emb" + str(j)).weight, getattr(self, "pos_emb_inv" + str(j)).weight]
-        key = (Dp, id(self.rel_features), id(self.rel_features_inv)) + tuple((t.data_ptr(), t._version) for t in src)
+        wkey = (Dp,) + tuple((t.data_ptr(), t._version) for t in src)
+        key = (id(self.rel_features), id(self.rel_features_inv)) + wkey
         if self._padded is not None and self._padded["key"] == key:
             return self._padded
 
@@ -160,21 +161,28 @@ class ReasonGNNLayer(BaseGNNLayer):
         def pad_sq(t):                       # [D, D] -> [Dp, Dp]
             return t if Dp == D else F.pad(t.detach().float(), (0, Dp - D, 0, Dp - D))
 
-        layers = []
-        for j, (rl, e2e) in enumerate(mods):
-            W_e2e = e2e.weight
-            if Dp != D:                      # every [D, D] column block of e2e_linear.weight moves to its padded place
-                W_e2e = torch.cat([pad_sq(e2e.weight[:, k * D:(k + 1) * D]) for k in range(2 * I + 1)], dim=1).contiguous()
-            pos = pos_inv = None
-            if self.use_posemb:
-                pos = pad_cols(getattr(self, "pos_emb" + str(j)).weight).contiguous()
-                pos_inv = pad_cols(getattr(self, "pos_emb_inv" + str(j)).weight).contiguous()
-            layers.append((pad_sq(rl.weight).contiguous(), pad_cols(rl.bias).contiguous(), W_e2e,
-                           pad_cols(e2e.bias).contiguous(), pos, pos_inv))
-        self._padded = dict(key=key, D=D, Dp=Dp, layers=layers,
+        # the parameters' copies outlive a batch (an evaluation run never changes them: 18 pads per forward at D = 50
+        # otherwise); only the relation features' copies follow the batch
+        W = getattr(self, "_padded_w", None)
+        if W is None or W["wkey"] != wkey:
+            layers = []
+            for j, (rl, e2e) in enumerate(mods):
+                W_e2e = e2e.weight
+                if Dp != D:                  # every [D, D] column block of e2e_linear.weight moves to its padded place
+                    W_e2e = torch.cat([pad_sq(e2e.weight[:, k * D:(k + 1) * D]) for k in range(2 * I + 1)], dim=1).contiguous()
+                pos = pos_inv = None
+                if self.use_posemb:
+                    pos = pad_cols(getattr(self, "pos_emb" + str(j)).weight).contiguous()
+                    pos_inv = pad_cols(getattr(self, "pos_emb_inv" + str(j)).weight).contiguous()
+                layers.append((pad_sq(rl.weight).contiguous(), pad_cols(rl.bias).contiguous(), W_e2e,
+                               pad_cols(e2e.bias).contiguous(), pos, pos_inv))
+            W = self._padded_w = dict(wkey=wkey, layers=layers,
+                                      w_score=pad_cols(self.score_func.weight.reshape(-1)).contiguous(),
+                                      b_score=self.score_func.bias)
+        self._padded = dict(key=key, D=D, Dp=Dp, layers=W["layers"],
                             relfeat=pad_cols(self.rel_features.detach().float()).contiguous(),
                             relfeat_inv=pad_cols(self.rel_features_inv.detach().float()).contiguous(),
-                            w_score=pad_cols(self.score_func.weight.reshape(-1)).contiguous(), b_score=self.score_func.bias)
+                            w_score=W["w_score"], b_score=W["b_score"])
         return self._padded
 
     @staticmethod

@@ -12,6 +12,15 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle's torch ops: no more OpenMP threads than the container's CPU quota allows (the GPU box shows 256
+    # hardware threads and grants 16 cores; the surplus threads only get every thread of the process parked)
+    try:
+        import torch
+        import gnnrag_amd  # noqa: F401
+        from gnnrag_amd.install import host_cpu_budget
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), host_cpu_budget())))
+    except Exception:
+        pass
 
 
 def _has_gpu():

@@ -40,6 +40,11 @@ def main():
     import gnnrag_amd  # noqa: F401
     from gnnrag_amd import install
     install.install()
+    # the process that drives the GPU needs no OpenMP team (install.limit_host_threads: spinning workers exhaust a
+    # container's CPU quota and the kernel parks the launching thread with them); GNNRAG_HOST_THREADS=0 leaves torch's
+    # default, any other number sets that many
+    if os.environ.get("GNNRAG_HOST_THREADS", "") != "0":
+        install.limit_host_threads(int(os.environ["GNNRAG_HOST_THREADS"]) if os.environ.get("GNNRAG_HOST_THREADS") else None)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     is_eval = "--is_eval" in sys.argv
@@ -127,7 +132,11 @@ def main():
 
         evaluate.Evaluator.__init__ = _init_sharded
 
+    freeze_after_setup(evaluate)
     times = install_e2e_timers(pure=False) if os.environ.get("GNNRAG_E2E_TIMES") == "1" else None
+    if os.environ.get("GNNRAG_PROFILE_FORWARD"):
+        install_forward_profile(os.path.abspath(os.path.join(REPO, os.environ["GNNRAG_PROFILE_FORWARD"])),
+                                os.environ.get("GNNRAG_PROFILE_KIND", "torch"))
     sys.argv = [os.path.join(ref, "main.py")] + sys.argv[2:]
     try:
         runpy.run_path(os.path.join(ref, "main.py"), run_name="__main__")
@@ -155,10 +164,29 @@ def shim_startup_bugs():
         base_encoder.BaseInstruction.__init__ = _init
 
 
+def freeze_after_setup(evaluate) -> None:
+    """``gc.freeze()`` once the data is loaded and the model built (``Evaluator.__init__`` is the last step of
+    ``Trainer_KBQA.__init__``, train_model.py:25-72): see ``gnnrag_amd.install.freeze_loaded_data``.  Applied to the pure
+    reference run as well (same interpreter-level setting for both sides of the e2e comparison); GNNRAG_GC_FREEZE=0
+    leaves the collector as it is."""
+    if os.environ.get("GNNRAG_GC_FREEZE", "1") == "0":
+        return
+    init = evaluate.Evaluator.__init__
+
+    def _init(self, *a, **kw):
+        init(self, *a, **kw)
+        import gc
+        gc.collect()
+        gc.freeze()
+    evaluate.Evaluator.__init__ = _init
+
+
 def run_pure(ref):
     """The reference as it is (plus its two start-up shims), timed: bench.py's CPU baseline of the e2e block."""
     import json
     shim_startup_bugs()
+    import evaluate
+    freeze_after_setup(evaluate)
     times = install_e2e_timers(pure=True) if os.environ.get("GNNRAG_E2E_TIMES") == "1" else None
     sys.argv = [os.path.join(ref, "main.py")] + sys.argv[2:]
     try:
@@ -222,6 +250,162 @@ def install_e2e_timers(pure: bool) -> dict:
         return out
     evaluate.Evaluator.evaluate = evaluate_timed
     return T
+
+
+def install_forward_profile(out_path: str, kind: str, warm: int = None, calls: int = None) -> None:
+    """GNNRAG_PROFILE_FORWARD=<file> [GNNRAG_PROFILE_KIND=torch|cprofile]: where the HOST time of a steady-state
+    ``ReaRev.forward`` goes.  Calls ``warm`` .. ``warm + calls - 1`` run under torch.profiler (CPU side of every op and
+    launch) or cProfile (Python functions); first-call costs (kernel loading, hipBLASLt heuristics, allocator growth) stay
+    outside.  The summary is written when the last profiled call returns."""
+    import io
+    import time
+    import torch
+    from models.ReaRev import rearev
+    warm = int(os.environ.get("GNNRAG_PROFILE_WARM", "8")) if warm is None else warm
+    calls = int(os.environ.get("GNNRAG_PROFILE_CALLS", "12")) if calls is None else calls
+    fwd = rearev.ReaRev.forward
+    state = {"n": 0, "prof": None, "wall": 0.0, "wall_sync": 0.0}
+    if kind.startswith("sections"):
+        # perf_counter around the forward's own seams, no profiler: host time per section ("sections"), or with a device
+        # synchronisation at every seam ("sections_sync": the section's device work included)
+        import gc
+        from modules.question_encoding import base_encoder
+        import gnnrag_amd.modules.kg_reasoning.reasongnn as g_rg
+        import gnnrag_amd.modules.query_update as g_qu
+        import gnnrag_amd.modules.layer_init as g_li
+        sec, on, marks = {}, {"v": False}, {}
+        do_sync = kind == "sections_sync"
+
+        def wrap(cls, name, label):
+            f = getattr(cls, name)
+
+            def w(*a, **kw):
+                if not on["v"]:
+                    return f(*a, **kw)
+                if do_sync:
+                    torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                marks.setdefault("first_in", t0)
+                r = f(*a, **kw)
+                if do_sync:
+                    torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                if not label.startswith("  "):
+                    marks["last_out"] = t1
+                d = sec.setdefault(label, [0.0, 0])
+                d[0] += t1 - t0
+                d[1] += 1
+                return r
+            setattr(cls, name, w)
+        wrap(base_encoder.BaseInstruction, "init_reason", "instruction.init_reason (question encoder)")
+        wrap(base_encoder.BaseInstruction, "get_instruction", "instruction.get_instruction")
+        wrap(rearev.ReaRev, "init_reason", "ReaRev.init_reason (relation features, TypeLayer, structure)")
+        wrap(g_rg.ReasonGNNLayer, "forward", "ReasonGNNLayer.forward")
+        wrap(g_qu.QueryReform, "forward", "QueryReform.forward")
+        wrap(g_li.TypeLayer, "forward", "  of which TypeLayer.forward")
+        wrap(rearev.ReaRev, "calc_loss_label", "calc_loss_label")
+        wrap(rearev.ReaRev, "get_rel_feature", "  of which get_rel_feature")
+        wrap(rearev.ReaRev, "get_ent_init", "  of which get_ent_init")
+        if os.environ.get("GNNRAG_PROFILE_GC") == "0":
+            gc.disable()
+        gc_log, gc_t0, per_call, allocs = [], {}, [], []
+
+        def gc_cb(phase, info):          # every collection while a profiled forward runs: generation, duration, objects freed
+            if phase == "start":
+                gc_t0["t"] = time.perf_counter()
+            elif on["v"]:
+                gc_log.append((info["generation"], (time.perf_counter() - gc_t0.get("t", time.perf_counter())) * 1e3,
+                               info["collected"], info["uncollectable"]))
+        gc.callbacks.append(gc_cb)
+
+        def forward(self, *a, **kw):
+            n = state["n"]
+            state["n"] += 1
+            on["v"] = warm <= n < warm + calls
+            if on["v"]:
+                torch.cuda.synchronize()
+            marks.clear()
+            ms0 = torch.cuda.memory_stats() if on["v"] else None
+            t0 = time.perf_counter()
+            out = fwd(self, *a, **kw)
+            if on["v"]:
+                t1 = time.perf_counter()
+                ms1 = torch.cuda.memory_stats()
+                allocs.append((ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0),
+                               ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0),
+                               round(ms1.get("reserved_bytes.all.current", 0) / 2**20)))
+                state["wall"] += t1 - t0
+                torch.cuda.synchronize()
+                state["wall_sync"] += time.perf_counter() - t0
+                for label, dt in (("forward entry -> first module call (input tensors to the device)", marks["first_in"] - t0),
+                                  ("last module call -> return (argmax of the last distribution)", t1 - marks["last_out"])):
+                    d = sec.setdefault(label, [0.0, 0])
+                    d[0] += dt
+                    d[1] += 1
+                per_call.append(round((t1 - t0) * 1e3, 2))
+            on["v"] = False
+            if n == warm + calls - 1:
+                with open(out_path, "w") as f:
+                    f.write("# %d steady-state ReaRev.forward calls (after %d warm ones), %s, gc %s: %.3f ms per call until "
+                            "forward returns, %.3f ms until the device is idle\n" % (
+                                calls, warm, kind, "on" if gc.isenabled() else "off", state["wall"] / calls * 1e3,
+                                state["wall_sync"] / calls * 1e3))
+                    for k, (t, c) in sec.items():
+                        f.write("%-70s %8.3f ms per forward  (%d calls per forward)\n" % (k, t / calls * 1e3, c // calls))
+                    f.write("per call, ms: %s\n" % per_call)
+                    f.write("per call, caching allocator (device allocations, device frees, MiB reserved after): %s\n" % allocs)
+                    f.write("collections inside the %d forwards: %d, %.2f ms in total; frozen objects %d; tracked objects now %d; "
+                            "the long ones (generation, ms, collected, uncollectable): %s\n" % (
+                                calls, len(gc_log), sum(x[1] for x in gc_log), gc.get_freeze_count(), len(gc.get_objects()),
+                                [(g, round(ms, 2), c, u) for g, ms, c, u in gc_log if ms > 0.5]))
+            return out
+        rearev.ReaRev.forward = forward
+        return
+
+    def forward(self, *a, **kw):
+        n = state["n"]
+        state["n"] += 1
+        if n == warm:
+            torch.cuda.synchronize()
+            if kind == "cprofile":
+                import cProfile
+                state["prof"] = cProfile.Profile()
+                state["prof"].enable()
+            else:
+                acts = [torch.profiler.ProfilerActivity.CPU]
+                if kind == "torchcuda":
+                    acts.append(torch.profiler.ProfilerActivity.CUDA)
+                state["prof"] = torch.profiler.profile(activities=acts)
+                state["prof"].__enter__()
+        t0 = time.perf_counter()
+        out = fwd(self, *a, **kw)
+        if warm <= n < warm + calls:
+            state["wall"] += time.perf_counter() - t0
+            torch.cuda.synchronize()
+            state["wall_sync"] += time.perf_counter() - t0
+        if n == warm + calls - 1:
+            prof = state["prof"]
+            buf = io.StringIO()
+            buf.write("# %d steady-state ReaRev.forward calls (after %d warm ones), host wall %.3f ms per call until forward "
+                      "returns, %.3f ms until the device is idle\n" % (calls, warm, state["wall"] / calls * 1e3,
+                                                                        state["wall_sync"] / calls * 1e3))
+            if kind == "cprofile":
+                import pstats
+                prof.disable()
+                for key in ("cumulative", "tottime"):
+                    st = pstats.Stats(prof, stream=buf)
+                    st.sort_stats(key).print_stats(45)
+            else:
+                prof.__exit__(None, None, None)
+                buf.write(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=50, max_name_column_width=70))
+                if kind == "torchcuda":
+                    buf.write("\n\n==== by device time ====\n")
+                    buf.write(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=40, max_name_column_width=90))
+            torch.cuda.synchronize()
+            with open(out_path, "w") as f:
+                f.write(buf.getvalue())
+        return out
+    rearev.ReaRev.forward = forward
 
 
 if __name__ == "__main__":
