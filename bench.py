@@ -394,7 +394,10 @@ def self_launch(n):
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    import gnnrag_amd  # noqa: F401
+    from gnnrag_amd.install import host_cpu_budget
+    # a rank drives one GPU and needs no OpenMP team: a few threads each, inside the container's CPU quota
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, host_cpu_budget() // n))))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     rc = subprocess.call(cmd, env=env)

@@ -92,8 +92,8 @@ typedef struct gnnrag_csr {
    * facts in ascending fact id, then direction 1's). */
   int32_t* edge_m;      /* [2F][2]                                                              */
   int32_t* m_from;      /* [2F]                                                                 */
-  int32_t* m_dst;       /* [2F]  destination node of every merged record (the streaming walk cuts the stream into
-                                 equal fact ranges and finds the row boundaries in it)                  */
+  int32_t* m_dst;       /* [2F]  destination node of every merged record: for callers that cut the merged stream into
+                                 equal fact ranges (no kernel of this library reads it any more)         */
   /* Dense hub form of the gather walk (tables larger than LDS): the hubs of question b are the list entries
    * hub_q_off[d][b] .. hub_q_off[d][b+1]; hub_wbase[d][b] = sum over earlier questions of hubs x relations in use
    * (rounded up to 4) = offset of the question's hub-by-relation weight block (saturates at INT32_MAX). */
