@@ -87,6 +87,7 @@ SIGNATURES = {
     "gnnrag_lstm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "gnnrag_lstm_forward": (C.c_int, [_VP] * 10 + [C.c_int32] * 4 + [_VP, C.c_size_t, _VP]),
     "gnnrag_seed_retrieve": (C.c_int, [_VP, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, _VP]),
+    "gnnrag_query_reform": (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, _VP]),
     "gnnrag_topp_candidates": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_double, C.c_double, _VP, _VP, _VP]),
     "gnnrag_topp_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "gnnrag_topp_candidates_ws": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_double, C.c_double, _VP, _VP, _VP,
@@ -128,7 +129,7 @@ SIGNATURES = {
     "gnnrag_error_string": (C.c_char_p, [C.c_int]),
 }
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 PATH_AUTO, PATH_UNFUSED, PATH_FUSED = 0, 1, 2
 PATH_ONLY_FWD, PATH_ONLY_INV = 0x10, 0x20        # OR-ed into the path: one-direction layers (NSM)
 PATH_SEED_PRIOR = 0x40                           # OR-ed into the path: the (first layer's) prior is a seed distribution

@@ -5,7 +5,8 @@ update between two ReaRev iterations (``rearev.py:217-221``).
 all N node states (``:36-38``: a [B,N,D] product, a softmax over N and a second [B,N,D] product - three
 passes over the node state plus two [B,N,D] temporaries) and then does not use it: the value it returns
 is ``fusion(q_node, seed_retrieve)`` (``:40,44``).  Here only that is computed, and ``seed_retrieve`` reads
-just the seed rows (``gnnrag_seed_retrieve``) instead of streaming the node state through a bmm.  Same
+just the seed rows instead of streaming the node state through a bmm - retrieval and Fusion in ONE launch
+(``gnnrag_query_reform``; ``gnnrag_seed_retrieve`` + the torch Fusion for shapes it does not take).  Same
 classes, constructors, parameter names (``q_ent_attn`` is kept: released checkpoints hold it) and
 return values.  With autograd enabled the seed retrieval is the reference's ``torch.bmm``."""
 from __future__ import annotations
@@ -44,6 +45,13 @@ class QueryReform(nn.Module):
             seed_retrieve = torch.bmm(seed_info.unsqueeze(1), ent_emb).squeeze(1)       # :40 (autograd form)
         else:
             base = getattr(ent_emb, "_gnnrag_padded", None)        # node state kept zero-padded by ReasonGNNLayer
+            D = ent_emb.shape[-1]
+            r, g = self.fusion.r, self.fusion.g
+            if (q_node.dim() == 2 and q_node.shape[-1] == D and D <= 4096 and r.bias is None and g.bias is None
+                    and r.weight.dtype == torch.float32 and g.weight.dtype == torch.float32):
+                # retrieval + Fusion (:40,44 with :6-16) in one launch: ~11 small torch launches per call otherwise
+                return ops.query_reform(q_node.detach().float(), seed_info.float(), base if base is not None else ent_emb.float(),
+                                        r.weight.detach(), g.weight.detach())
             if base is not None:
                 seed_retrieve = ops.seed_retrieve(seed_info.float(), base)[:, : ent_emb.shape[-1]]
             else:

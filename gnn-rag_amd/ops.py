@@ -1042,6 +1042,32 @@ def seed_retrieve(seed_info: torch.Tensor, ent_emb: torch.Tensor) -> torch.Tenso
     return out
 
 
+def query_reform(q_node: torch.Tensor, seed_info: torch.Tensor, ent_emb: torch.Tensor, W_r: torch.Tensor,
+                 W_g: torch.Tensor) -> torch.Tensor:
+    """``QueryReform.forward`` in one launch (query_update.py:26-44 with Fusion :6-16):
+    ``fusion(q_node, seed_retrieve(seed_info, ent_emb))`` -> [B, D].  ``ent_emb`` [B, N, D'] with D' >= D = q_node's
+    width: a zero-padded node state is read in place."""
+    lib = _lib.load()
+    q_node = _chk(q_node, "q_node")
+    seed_info = _chk(seed_info, "seed_info")
+    ent_emb = _chk(ent_emb, "ent_emb")
+    W_r = _chk(W_r, "W_r")
+    W_g = _chk(W_g, "W_g")
+    B, D = q_node.shape
+    N = seed_info.shape[1]
+    if (seed_info.shape[0] != B or ent_emb.dim() != 3 or ent_emb.shape[0] != B or ent_emb.shape[1] != N
+            or ent_emb.shape[2] < D):
+        raise ValueError("query_reform: q_node [B,D], seed_info [B,N], ent_emb [B,N,>=D]")
+    if tuple(W_r.shape) != (D, 3 * D) or tuple(W_g.shape) != (D, 3 * D):
+        raise ValueError("query_reform: fusion weights must be [D, 3D]")
+    out = torch.empty((B, D), dtype=torch.float32, device=q_node.device)
+    with torch.cuda.device(q_node.device):
+        _lib.check(lib.gnnrag_query_reform(q_node.data_ptr(), seed_info.data_ptr(), ent_emb.data_ptr(), ent_emb.shape[2],
+                                           W_r.data_ptr(), W_g.data_ptr(), out.data_ptr(), B, N, D, _stream()),
+                   "gnnrag_query_reform")
+    return out
+
+
 def topp_candidates(pred_dist: torch.Tensor, eligible: torch.Tensor, ignore_prob: float, eps: float):
     """Per question: slots kept by the Evaluator's filter, sorted by probability (descending, stable), and
     how many of them the top-p cut retrieves.  Returns (slots int32 [B,N] (-1 padded), counts int32 [B,2])."""

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GNNRAG_ABI_VERSION 15
+#define GNNRAG_ABI_VERSION 16
 
 #define GNNRAG_E_BADARG      (-1)  /* null pointer / negative size / inconsistent sizes   */
 #define GNNRAG_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set (see DESIGN)  */
@@ -482,6 +482,17 @@ int gnnrag_topp_candidates_ws(const float* pred_dist, const uint8_t* eligible, i
  * read, in ascending n.  seed_info [B,N], ent_emb [B,N,D], out [B,D]. */
 int gnnrag_seed_retrieve(const float* seed_info, const float* ent_emb, float* out, int32_t B, int32_t N,
                          int32_t D, gnnrag_stream_t stream);
+
+/* QueryReform.forward as ONE launch (gnn/modules/query_update.py:26-44; Fusion :6-16; called once per instruction between
+ * two ReaRev iterations, gnn/models/ReaRev/rearev.py:217-221):
+ *   y = seed retrieval as above;  feats = [x, y, x - y];  out = sigmoid(W_g feats) * (W_r feats) + (1 - sigmoid(..)) * x
+ * with x = q_node [B, D], W_r / W_g = fusion.r.weight / fusion.g.weight [D, 3 D] (no bias), ent_emb [B, N, ld_ent]
+ * (row stride ld_ent >= D: a zero-padded node state is read in place), out [B, D].  The reference's attention over all
+ * N node states (:36-38) does not enter its return value and is not computed.  D <= 4096 (GNNRAG_E_UNSUPPORTED beyond).
+ * (ABI 16) */
+int gnnrag_query_reform(const float* q_node, const float* seed_info, const float* ent_emb, int64_t ld_ent,
+                        const float* W_r, const float* W_g, float* out, int32_t B, int32_t N, int32_t D,
+                        gnnrag_stream_t stream);
 
 /* The question encoder's LSTM (the instruction path): one layer, one direction, batch_first,
  * torch.nn.LSTM semantics and parameter layout (gate order i, f, g, o) - what

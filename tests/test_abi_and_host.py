@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, n), "missing export: " + n
         assert n in _lib.SIGNATURES, "binding lacks a signature for " + n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.gnnrag_abi_version() == _lib.ABI_VERSION == 15
+    assert lib.gnnrag_abi_version() == _lib.ABI_VERSION == 16
     assert b"bad argument" in lib.gnnrag_error_string(-1)
 
 

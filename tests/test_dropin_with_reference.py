@@ -141,6 +141,13 @@ def _patch_backend(monkeypatch):
     monkeypatch.setattr(base_gnn, "_device_from_args", lambda args, like=None: torch.device("cpu"))
     monkeypatch.setattr(ops, "seed_retrieve",
                         lambda seed_info, ent_emb: torch.bmm(seed_info.unsqueeze(1), ent_emb).squeeze(1))
+
+    def query_reform(q_node, seed_info, ent_emb, W_r, W_g):      # query_update.py:40,44 with Fusion :6-16, op for op
+        y = torch.bmm(seed_info.unsqueeze(1), ent_emb[..., : q_node.shape[-1]]).squeeze(1)
+        feats = torch.cat([q_node, y, q_node - y], dim=-1)
+        gate = torch.sigmoid(feats @ W_g.t())
+        return gate * (feats @ W_r.t()) + (1 - gate) * q_node
+    monkeypatch.setattr(ops, "query_reform", query_reform)
     monkeypatch.setattr(base_gnn, "_check_gpu_tensor", lambda t, what: None)
     base_gnn._last_plan.update(key=None, plan=None, tuple=None)
 

@@ -627,7 +627,7 @@ def test_no_cpu_fallback_and_autograd_form_agrees(dev):
         ops.linear(torch.zeros(4, 4), torch.zeros(4, 4))
 
 
-@pytest.mark.parametrize("B,N,D", [(3, 70, 50), (64, 2000, 200), (2, 130, 300)])
+@pytest.mark.parametrize("B,N,D", [(3, 70, 50), (64, 2000, 200), (2, 130, 300), (20, 500, 200), (1, 2000, 50)])
 def test_query_reform_seed_retrieve(dev, B, N, D):
     """QueryReform drop-in (query_update.py:26-44): the seed retrieval kernel against torch.bmm, and the
     module's output against fusion(q, bmm) with the same parameters (the reference's attention over all
@@ -651,9 +651,18 @@ def test_query_reform_seed_retrieve(dev, B, N, D):
     qr = QueryReform(D).to(dev).eval()
     q = torch.randn(B, D, generator=g).to(dev)
     with torch.no_grad():
-        out = qr(q, ent, seed, (seed == 0).float())
-        ref = qr.fusion(q, want)
-    assert (out - ref).abs().max().item() <= 1e-6
+        out = qr(q, ent, seed, (seed == 0).float())         # one launch: gnnrag_query_reform
+        ref = qr.fusion(q, want)                            # the reference's Fusion on torch (query_update.py:6-16)
+        assert (out - ref).abs().max().item() <= 4e-6       # two fp32 summation orders of 3 D terms (1.2e-6 seen at D = 200)
+        # a node state kept zero-padded by ReasonGNNLayer (hidden size 50 -> 56): the view the caller holds carries its
+        # padded base, which the kernel reads in place with the padded row stride
+        Dp = (D + 7) // 8 * 8 + 8
+        base = torch.zeros(B, N, Dp, device=dev)
+        base[..., :D] = ent
+        view = base[..., :D]
+        view._gnnrag_padded = base
+        assert torch.equal(qr(q, view, seed, (seed == 0).float()), out)
+        assert torch.equal(ops.query_reform(q, seed, ent, qr.fusion.r.weight, qr.fusion.g.weight), out)
 
 
 def test_query_reform_equals_reference_op_sequence_at_c2(dev, capsys):
@@ -680,7 +689,9 @@ def test_query_reform_equals_reference_op_sequence_at_c2(dev, capsys):
         return qr(q, ent, seed, local_entity)
 
     with torch.no_grad():
-        assert (mine() - ref()).abs().max().item() <= 1e-6
+        # the drop-in is ONE launch (gnnrag_query_reform): its 600-term sums run in another fp32 order than hipBLASLt's
+        # (1.6e-6 seen on values up to ~4, i.e. 3 ulp; the stated bar is 1e-4)
+        assert (mine() - ref()).abs().max().item() <= 4e-6
         times = []
         for fn in (ref, mine):
             fn()
