@@ -37,22 +37,22 @@ def install() -> None:
         sys.modules[ref_name] = importlib.import_module(our_name)
 
 
-def host_cpu_budget() -> int:
+def host_cpu_budget(cgroup_root: str = "/sys/fs/cgroup") -> int:
     """CPU cores this process may actually use: ``os.cpu_count()`` capped by the cgroup's CFS quota (``cpu.max`` of
     cgroup v2, ``cpu.cfs_quota_us / cpu.cfs_period_us`` of v1).  A container on a 256-thread host is typically given a
     fraction of it, and ``os.cpu_count()`` (hence torch's / OpenMP's default thread count) does not know."""
     import os
     n = os.cpu_count() or 1
     try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
+        with open(cgroup_root + "/cpu.max") as f:
             quota, period = f.read().split()[:2]
         if quota != "max":
             n = min(n, max(1, int(quota) // int(period)))
     except (OSError, ValueError):
         try:
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            with open(cgroup_root + "/cpu/cpu.cfs_quota_us") as f:
                 quota = int(f.read())
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            with open(cgroup_root + "/cpu/cpu.cfs_period_us") as f:
                 period = int(f.read())
             if quota > 0 and period > 0:
                 n = min(n, max(1, quota // period))

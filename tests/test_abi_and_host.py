@@ -227,3 +227,41 @@ def test_pmc_source_digest_ignores_comments_and_whitespace(tmp_path, monkeypatch
     assert bench.kernel_sources_digest() == base
     p.write_text(text.replace("kFrAltSeeds = 32", "kFrAltSeeds = 16"))
     assert bench.kernel_sources_digest() != base
+
+
+def test_host_cpu_budget_follows_the_cgroup_quota(tmp_path):
+    """install.host_cpu_budget: the CFS quota of cgroup v2 (cpu.max) or v1 (cfs_quota_us / cfs_period_us) caps
+    os.cpu_count(); "max" / -1 / no cgroup files leave it alone.  (The MI355X box: 256 visible hardware threads, 16 granted -
+    torch's default thread count follows the former and gets the whole process parked, profiles/r05i_forward_host_time.txt.)"""
+    import gnnrag_amd  # noqa: F401
+    from gnnrag_amd.install import host_cpu_budget
+    ncpu = os.cpu_count() or 1
+    v2 = tmp_path / "v2"
+    v2.mkdir()
+    (v2 / "cpu.max").write_text("200000 100000\n")
+    assert host_cpu_budget(str(v2)) == min(ncpu, 2)
+    (v2 / "cpu.max").write_text("50000 100000\n")            # half a core: at least one thread
+    assert host_cpu_budget(str(v2)) == 1
+    (v2 / "cpu.max").write_text("max 100000\n")
+    assert host_cpu_budget(str(v2)) == ncpu
+    v1 = tmp_path / "v1"
+    (v1 / "cpu").mkdir(parents=True)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("300000\n")
+    (v1 / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert host_cpu_budget(str(v1)) == min(ncpu, 3)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
+    assert host_cpu_budget(str(v1)) == ncpu
+    assert host_cpu_budget(str(tmp_path / "nothing_here")) == ncpu
+
+
+def test_limit_host_threads_sets_a_small_team():
+    import torch
+    import gnnrag_amd  # noqa: F401
+    from gnnrag_amd.install import host_cpu_budget, limit_host_threads
+    before = torch.get_num_threads()
+    try:
+        n = limit_host_threads()
+        assert n == torch.get_num_threads() == max(1, min(8, host_cpu_budget() // 2))
+        assert limit_host_threads(3) == torch.get_num_threads() == 3
+    finally:
+        torch.set_num_threads(before)
