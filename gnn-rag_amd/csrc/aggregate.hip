@@ -1740,12 +1740,12 @@ static int fill_common(WalkArgs& a, const gnnrag_csr* csr, int D, void* ws, size
 // instructions of it).  na = accumulators whose partial-sum scratch precedes the prior pairs.
 template <int MODE, int NI>
 static int launch_slice(const WalkArgs& a, const gnnrag_csr* csr, void* workspace, size_t workspace_bytes,
-                        int na_ws, hipStream_t stream) {
+                        int na_ws, hipStream_t stream, bool pairs_ready = false) {
   const int D = a.D;
   if (workspace_bytes < partial_bytes(csr, D, na_ws) + prior_bytes(csr)) return GNNRAG_E_WORKSPACE;
   int2* pr = (int2*)((char*)workspace + partial_bytes(csr, D, na_ws));
   const int64_t F = csr->F;
-  if (F > 0 && a.i0 == 0) {     // the (p, rel) pairs do not depend on the instruction pass
+  if (F > 0 && a.i0 == 0 && !(pairs_ready && a.merged)) {     // the (p, rel) pairs do not depend on the instruction pass
     if (a.merged)
       hipLaunchKernelGGL(k_fact_prior_merged, dim3((unsigned)((2 * F + 255) / 256)), dim3(256), 0, stream, a.edge_m,
                          a.m_from, a.w[0], a.w[1], a.dist, F, pr);
@@ -1896,8 +1896,31 @@ static int prepare_fused(WalkArgs& a, const gnnrag_csr* csr, const float* dist, 
   return 0;
 }
 
+int gnnrag::prior_pairs_target(const gnnrag_csr* csr, int32_t D, void* workspace, size_t workspace_bytes,
+                               PriorPairsTarget* out) {
+  if (!csr || !out || !workspace || D <= 0 || csr->rel_total < 0) return GNNRAG_E_BADARG;
+  memset(out, 0, sizeof(*out));
+  WalkArgs a;
+  int variant = 0;
+  // dist / P / out are not dereferenced here; any non-null value passes prepare_fused
+  const int rc = prepare_fused(a, csr, (const float*)workspace, (const float*)workspace, (float*)workspace, D, 0, workspace,
+                               workspace_bytes, &variant);
+  if (rc) return rc;
+  if (variant == GNNRAG_WALK_L2_GATHER || !a.merged || csr->F <= 0) return 0;
+  if (workspace_bytes < partial_bytes(csr, D, 1) + prior_bytes(csr)) return GNNRAG_E_WORKSPACE;
+  out->edge_m = a.edge_m;
+  out->m_from = a.m_from;
+  out->w0 = a.w[0];
+  out->w1 = a.w[1];
+  out->pairs = (int2*)((char*)workspace + partial_bytes(csr, D, 1));
+  out->F = csr->F;
+  out->ok = true;
+  return 0;
+}
+
 int gnnrag::aggregate_fused_dirs(const gnnrag_csr* csr, const float* dist, const float* P, float* out, int32_t D,
-                                 int32_t skip_dir, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                                 int32_t skip_dir, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                                 bool pairs_ready) {
   if (!csr || !dist || !P || !out || D <= 0 || csr->rel_total < 0 || skip_dir < 0 || skip_dir > 2) return GNNRAG_E_BADARG;
   WalkArgs a;
   int variant = 0;
@@ -1907,8 +1930,8 @@ int gnnrag::aggregate_fused_dirs(const gnnrag_csr* csr, const float* dist, const
     case GNNRAG_WALK_L2_GATHER: return launch_walk<MODE_FUSED>(a, 1, stream);   // tables too big for LDS
     // 32-column slices when two of them still fit a CU's LDS (questions that use up to ~300 relations): half
     // as many workgroups re-walk the question's facts
-    case GNNRAG_WALK_LDS_32: return launch_slice<MODE_FUSED, 2>(a, csr, workspace, workspace_bytes, 1, stream);
-    default: return launch_slice<MODE_FUSED, 1>(a, csr, workspace, workspace_bytes, 1, stream);
+    case GNNRAG_WALK_LDS_32: return launch_slice<MODE_FUSED, 2>(a, csr, workspace, workspace_bytes, 1, stream, pairs_ready);
+    default: return launch_slice<MODE_FUSED, 1>(a, csr, workspace, workspace_bytes, 1, stream, pairs_ready);
   }
 }
 

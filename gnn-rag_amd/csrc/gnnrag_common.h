@@ -131,9 +131,26 @@ bool tables_vq_shape_ok(int32_t D, int32_t I);
 int tables_vq_launch(const gnnrag_csr* csr, const void* planes, const float* ins, const float* W, float* P, int32_t D,
                      int32_t I, int32_t only_dir, hipStream_t stream);
 
-// gnnrag_aggregate_fused with one direction left out (skip_dir = 1 + d; 0 = both): aggregate.hip
+// gnnrag_aggregate_fused with one direction left out (skip_dir = 1 + d; 0 = both): aggregate.hip.  pairs_ready: the
+// (prior, relation) pairs of `dist` are already in the workspace (written by the previous layer's softmax launch,
+// see prior_pairs_target) - the walk's own pass over the facts is skipped.
 int aggregate_fused_dirs(const gnnrag_csr* csr, const float* dist, const float* P, float* out, int32_t D,
-                         int32_t skip_dir, void* workspace, size_t workspace_bytes, hipStream_t stream);
+                         int32_t skip_dir, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                         bool pairs_ready = false);
+
+// Where the LDS walk of gnnrag_aggregate_fused(csr, ., ., D, workspace) expects its (prior, relation) pairs and what they
+// are made of: the merged record stream, the facts' positions (per-fact weights) and the weights.  ok = false when that
+// call would not read pairs at all (gather walk, unmerged rows, no facts).
+struct PriorPairsTarget {
+  const int2* edge_m;
+  const int32_t* m_from;
+  const float* w0;
+  const float* w1;
+  int2* pairs;
+  int64_t F;
+  bool ok;
+};
+int prior_pairs_target(const gnnrag_csr* csr, int32_t D, void* workspace, size_t workspace_bytes, PriorPairsTarget* out);
 
 // the self-block update in bf16x3 on the W-resident kernel of tables_b3.hip (score must be writable scratch: it is
 // zeroed and accumulated by two atomic adds per row); GNNRAG_E_UNSUPPORTED outside its shapes

@@ -75,6 +75,89 @@ __global__ __launch_bounds__(1024) void k_masked_softmax(const float* __restrict
   }
 }
 
+// The softmax above AND the next layer's fact priors in one launch: layer l + 1's dense-prior walk starts by turning
+// dist_l into one (prior, relation) pair per fact and direction (k_fact_prior_merged: a pass over 2F records that gathers
+// dist[src], 7.8 us at C2) - here the workgroups that just normalised a question's scores keep its distribution in LDS
+// and write the pairs of the question's own facts (a contiguous range of the merged stream), so the walk finds them
+// ready.  Workgroup (g, part): every part repeats the question's softmax (8 KB of scores; same arithmetic, same
+// reduction order as k_masked_softmax<ITEMS>, so the distribution is bit-identical), part 0 writes it, and the parts
+// share the question's facts.  GNNRAG_SOFTMAX_PAIRS=0 keeps the two launches apart (diagnostic).
+template <int ITEMS>
+__global__ __launch_bounds__(1024) void k_softmax_pairs(const float* __restrict__ score, float* __restrict__ dist, int N,
+                                                        const int32_t* __restrict__ rp0, const int32_t* __restrict__ rp1,
+                                                        const int2* __restrict__ em, const int32_t* __restrict__ from,
+                                                        const float* __restrict__ w0, const float* __restrict__ w1,
+                                                        int64_t F, int2* __restrict__ pr) {
+  extern __shared__ float s_dist[];        // [N]
+  __shared__ float red[16];
+  __shared__ float bcast;
+  const int g = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
+  const float* s = score + (size_t)g * N;
+  float* o = dist + (size_t)g * N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float v[ITEMS];
+  float m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int i = threadIdx.x + k * 1024;
+    v[k] = i < N ? s[i] : -INFINITY;
+    m = fmaxf(m, v[k]);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float mm = red[0];
+    for (int w = 1; w < 16; ++w) mm = fmaxf(mm, red[w]);
+    bcast = mm;
+  }
+  __syncthreads();
+  m = bcast;
+  __syncthreads();
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    v[k] = expf(v[k] - m);
+    sum += v[k];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    bcast = t;
+  }
+  __syncthreads();
+  const float total = bcast;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int i = threadIdx.x + k * 1024;
+    if (i < N) {
+      const float d = v[k] / total;
+      s_dist[i] = d;
+      if (part == 0) o[i] = d;
+    }
+  }
+  __syncthreads();
+  // the question's facts: merged positions [rp0[gN] + rp1[gN], rp0[(g+1)N] + rp1[(g+1)N])
+  const int64_t n0 = (int64_t)g * N;
+  const int64_t beg = (int64_t)rp0[n0] + rp1[n0], end = (int64_t)rp0[n0 + N] + rp1[n0 + N];
+  const int64_t lo = beg + (end - beg) * part / nparts, hi = beg + (end - beg) * (part + 1) / nparts;
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  for (int64_t j = lo + threadIdx.x; j < hi; j += 1024) {
+    const i32x2 e = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(em) + j);
+    float p = s_dist[e.x - (int)n0];       // a fact stays inside its question (validated by the structure build)
+    if (w0) {
+      const int f = from[j];
+      p *= f < F ? w0[f] : w1[f - F];
+    }
+    pr[j] = make_int2(__float_as_int(p), e.y);
+  }
+}
+
 // float4 copy that measures the streaming ceiling of the box (bench.py's `measured_copy_ceiling_GBps`): four 16-byte loads
 // per thread in flight before the first store, every block iteration moves 16 KB of contiguous data (round 3's one
 // load -> one store loop reached 4.95 TB/s where the guide's float4 copy reaches 6.29)
@@ -166,12 +249,47 @@ extern "C" size_t gnnrag_layer_workspace_bytes(const gnnrag_csr* csr, int32_t D,
   return layer_ws(csr, D, I).total;
 }
 
+// the layer's last launch: softmax of the scores - and, when the caller says the NEXT layer's dense-prior LDS walk will
+// read this distribution (want_pairs), that walk's (prior, relation) pairs with it (k_softmax_pairs).  *pairs_done tells
+// whether they were written.
+static int finish_softmax(const gnnrag_csr* csr, const LayerWs& w, char* base, const float* score, float* dist_out, int32_t D,
+                          bool want_pairs, bool* pairs_done, gnnrag_stream_t stream) {
+  if (pairs_done) *pairs_done = false;
+  const char* env = getenv("GNNRAG_SOFTMAX_PAIRS");      // read per call: the test compares both forms in one process
+  const bool enabled = !(env && env[0] == '0');
+  if (want_pairs && pairs_done && enabled && csr->N <= 8192 && csr->edge_m) {
+    PriorPairsTarget t;
+    const int rc = prior_pairs_target(csr, D, base + w.partial, w.partial_bytes, &t);
+    if (rc) return rc;
+    if (t.ok) {
+      // about two workgroups per CU over the batch; a question's facts are shared by at most 8
+      int parts = (512 + csr->B - 1) / csr->B;
+      parts = parts < 1 ? 1 : parts > 8 ? 8 : parts;
+      const size_t lds = (size_t)csr->N * sizeof(float);
+      if (csr->N <= 2048)
+        hipLaunchKernelGGL(k_softmax_pairs<2>, dim3(csr->B, parts), dim3(1024), lds, (hipStream_t)stream, score, dist_out,
+                           csr->N, csr->row_ptr[0], csr->row_ptr[1], t.edge_m, t.m_from, t.w0, t.w1, t.F, t.pairs);
+      else
+        hipLaunchKernelGGL(k_softmax_pairs<8>, dim3(csr->B, parts), dim3(1024), lds, (hipStream_t)stream, score, dist_out,
+                           csr->N, csr->row_ptr[0], csr->row_ptr[1], t.edge_m, t.m_from, t.w0, t.w1, t.F, t.pairs);
+      GNNRAG_LAUNCH_CHECK();
+      *pairs_done = true;
+      return 0;
+    }
+  }
+  return gnnrag_masked_softmax(score, dist_out, csr->B, csr->N, stream);
+}
+
 // one layer behind its relation projections T_fwd / T_inv (already computed)
 static int layer_body(const gnnrag_csr* csr, const LayerWs& w, char* base, const float* h, const float* dist,
                       const float* ins, const float* T_fwd, const float* T_inv, const void* planes, const float* W_e2e,
                       const float* b_e2e, const float* w_score, const float* b_score, const float* mask,
                       float* h_out, float* score_out, float* dist_out, int32_t D, int32_t I, int32_t path,
-                      int32_t math, gnnrag_stream_t stream) {
+                      int32_t math, gnnrag_stream_t stream, bool pairs_ready = false, bool* pairs_for_next = nullptr) {
+  // pairs_ready: the previous layer's softmax launch left this layer's (prior, relation) pairs in the workspace;
+  // pairs_for_next != nullptr: the caller will run another layer on dist_out - *pairs_for_next reports whether this
+  // layer's last launch wrote that layer's pairs
+  if (pairs_for_next) *pairs_for_next = false;
   const int64_t BN = (int64_t)csr->B * csr->N;
   int rc;
   // one-direction layers (NSM): only that direction's tables are built and walked where the kernels at hand can
@@ -207,7 +325,7 @@ static int layer_body(const gnnrag_csr* csr, const LayerWs& w, char* base, const
       rc = update_score_fused_rows(h, nbr, gated ? frontier_row_flags(csr, fws) : nullptr, W_e2e, b_e2e, w_score, b_score,
                                    mask, h_out, score_out, BN, D, I, math, (hipStream_t)stream, true);
       if (rc) return rc;
-      return gnnrag_masked_softmax(score_out, dist_out, csr->B, csr->N, stream);
+      return finish_softmax(csr, w, base, score_out, dist_out, D, only < 0, pairs_for_next, stream);
     }
     rc = GNNRAG_E_UNSUPPORTED;
     bool score_zeroed = false;    // the V-form table kernel also zeroes the score the update accumulates onto
@@ -219,11 +337,12 @@ static int layer_body(const gnnrag_csr* csr, const LayerWs& w, char* base, const
     if (rc == GNNRAG_E_UNSUPPORTED) rc = gnnrag_relation_tables(csr, T_fwd, T_inv, ins, W_e2e, P, D, I, math, stream);
     if (rc) return rc;
     rc = aggregate_fused_dirs(csr, dist, P, nbr, D, one_dir ? 2 - only : 0, base + w.partial, w.partial_bytes,
-                              (hipStream_t)stream);
+                              (hipStream_t)stream, pairs_ready && !one_dir);
     if (rc) return rc;
     rc = update_score_fused_z(h, nbr, W_e2e, b_e2e, w_score, b_score, mask, h_out, score_out, BN, D, I, math,
                               (hipStream_t)stream, score_zeroed);
     if (rc) return rc;
+    return finish_softmax(csr, w, base, score_out, dist_out, D, only < 0, pairs_for_next, stream);
   } else {
     float* agg = (float*)(base + w.agg);
     rc = gnnrag_aggregate(csr, dist, ins, T_fwd, T_inv, agg, D, I, base + w.partial, w.partial_bytes, stream);
@@ -341,6 +460,7 @@ extern "C" int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnra
   }
   const float* h = h0;
   const float* dist = dist0;
+  bool pairs_ready = false;      // layer j - 1's softmax launch wrote layer j's (prior, relation) pairs
   for (int j = 0; j < L; ++j) {
     const gnnrag_layer_params& p = layers[j];
     float* hj = h_out + (size_t)j * BN * D;
@@ -355,9 +475,12 @@ extern "C" int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnra
     }
     if (!planes_written) planes = nullptr;
     // GNNRAG_PATH_SEED_PRIOR describes dist0, i.e. layer 0 only (every later layer starts from a softmax output)
+    bool pairs_next = false;
     const int rc = layer_body(csr, w, base, h, dist, ins, T, T + RD, planes, p.W_e2e, p.b_e2e, w_score, b_score, mask, hj, sj,
-                              dj, D, I, j == 0 ? path : (path & ~GNNRAG_PATH_SEED_PRIOR), math, stream);
+                              dj, D, I, j == 0 ? path : (path & ~GNNRAG_PATH_SEED_PRIOR), math, stream, pairs_ready,
+                              j + 1 < L ? &pairs_next : nullptr);
     if (rc) return rc;
+    pairs_ready = pairs_next;
     h = hj;
     dist = dj;
   }

@@ -291,6 +291,31 @@ def test_layer_stack_matches_reference_fixture(dev, name, path):
         np.testing.assert_array_equal(out["dist"][-1][~some], ref["dist"][-1][~some])
 
 
+@pytest.mark.parametrize("case", ["c2_like", "weights_d50", "wide_rows"])
+def test_softmax_with_next_layers_pairs_is_bit_identical(dev, case, monkeypatch):
+    """Inside the whole-iteration call a layer's last launch writes the distribution AND the next layer's (prior,
+    relation) pairs (k_softmax_pairs; softmax_layer.hip) instead of leaving the pairs to a pass of the walk
+    (k_fact_prior_merged): same arithmetic, so every tensor of the stack is bit-identical to the two-launch form
+    (GNNRAG_SOFTMAX_PAIRS=0) - without and with per-fact weights (reasongnn.py:106-111 under normalized_gnn), and with more
+    than 2048 node slots per question (the 8-scores-per-thread softmax)."""
+    from gnnrag_amd import stack, synth
+    cfg = {"c2_like": synth.GraphConfig(name="c2_like", B=5, N=2000, E=10000, R=600, D=200, I=2, L=3, T=2, seed=3),
+           "weights_d50": synth.GraphConfig(name="w50", B=4, N=700, E=3000, R=40, D=50, I=3, L=3, T=2, normalized_gnn=True,
+                                            pos_emb=True, seed=4),
+           "wide_rows": synth.GraphConfig(name="wide", B=2, N=3000, E=9000, R=300, D=200, I=2, L=2, T=1, seed=5)}[case]
+    batch = synth.make_batch(cfg)
+    feats = synth.make_features(cfg)
+    params = synth.make_layer_params(cfg)
+    monkeypatch.setenv("GNNRAG_SOFTMAX_PAIRS", "0")
+    two = stack.run_stack(batch, feats, params, dev, path=2)
+    monkeypatch.delenv("GNNRAG_SOFTMAX_PAIRS")
+    one = stack.run_stack(batch, feats, params, dev, path=2)
+    for key in ("h", "score", "dist"):
+        for c in range(cfg.T * cfg.L):
+            np.testing.assert_array_equal(one[key][c], two[key][c], err_msg="%s[%d]" % (key, c))
+    assert np.isfinite(one["dist"][-1]).all() and abs(one["dist"][-1].sum(1) - 1).max() < 1e-4
+
+
 @pytest.mark.parametrize("norm_rel", [False, True])
 def test_type_layer_matches_reference_fixture(dev, norm_rel):
     from gnnrag_amd import stack, synth
