@@ -31,8 +31,33 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+
+def _limit_thread_pools_early():
+    """Before numpy / torch are imported: the default size of every CPU thread pool of this process (OpenMP, OpenBLAS,
+    MKL) follows the visible hardware threads (256 on the MI355X box), not the container's CPU quota (16 cores there).
+    Pools that size spin the quota away and the kernel then parks every thread of the process for the rest of a 100 ms
+    period - including the one that enqueues the timed steps (seen as 24-36 ms of silence inside a 30 ms timed region,
+    profiles/r05n_host_stall_in_timed_region.txt).  min(8, quota / 2) threads per pool unless the variable is already
+    set; GNNRAG_HOST_THREADS=0 leaves everything as it is.  The CPU-baseline legs size their own teams later."""
+    if os.environ.get("GNNRAG_HOST_THREADS") == "0":
+        return
+    budget = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            budget = min(budget, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    n = str(max(1, min(8, budget // 2)))
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        os.environ.setdefault(k, n)
+
+
+_limit_thread_pools_early()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
@@ -397,7 +422,9 @@ def self_launch(n):
     import gnnrag_amd  # noqa: F401
     from gnnrag_amd.install import host_cpu_budget
     # a rank drives one GPU and needs no OpenMP team: a few threads each, inside the container's CPU quota
-    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, host_cpu_budget() // n))))
+    per_rank = max(1, min(8, host_cpu_budget() // (2 * n)))
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        env[k] = str(min(per_rank, int(env[k])) if env.get(k, "").isdigit() else per_rank)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     rc = subprocess.call(cmd, env=env)

@@ -1,8 +1,13 @@
 import os
 import sys
 
-import numpy as np
-import pytest
+# thread pools sized after the visible hardware threads (256 on the GPU box) spin a container's CPU quota (16 cores there)
+# away and get the whole process parked: a sane default before numpy / torch start theirs (see gnnrag_amd.install)
+for _k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_k, str(max(1, min(16, os.cpu_count() or 1))))
+
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:

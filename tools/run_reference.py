@@ -27,6 +27,30 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _limit_thread_pools_early():
+    """Before numpy / torch are imported (same rule as bench.py): OpenMP / OpenBLAS / MKL pools of min(8, CPU quota / 2)
+    threads unless the variables are already set - pools sized after the visible hardware threads spin a container's CPU
+    quota away and get every thread of the process parked (gnnrag_amd.install.limit_host_threads).  Not for the pure
+    reference run (its thread count is the caller's: bench.py sets OMP_NUM_THREADS for that leg) and not with
+    GNNRAG_HOST_THREADS=0."""
+    if os.environ.get("GNNRAG_HOST_THREADS") == "0" or os.environ.get("GNNRAG_PURE_REFERENCE") == "1":
+        return
+    budget = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            budget = min(budget, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    n = os.environ.get("GNNRAG_HOST_THREADS") or str(max(1, min(8, budget // 2)))
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        os.environ.setdefault(k, n)
+
+
+_limit_thread_pools_early()
+
+
 def main():
     if len(sys.argv) < 2 or not os.path.isfile(os.path.join(sys.argv[1], "main.py")):
         raise SystemExit(__doc__)
