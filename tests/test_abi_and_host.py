@@ -265,3 +265,25 @@ def test_limit_host_threads_sets_a_small_team():
         assert limit_host_threads(3) == torch.get_num_threads() == 3
     finally:
         torch.set_num_threads(before)
+
+
+def test_bench_limits_the_thread_pools_before_importing_numpy_and_torch():
+    """bench.py sets OMP / OpenBLAS / MKL pool sizes before numpy and torch are imported (pools sized after the visible
+    hardware threads spin a container's CPU quota away: profiles/r05n_host_stall_in_timed_region.txt); an explicit setting
+    wins, GNNRAG_HOST_THREADS=0 switches the rule off."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; "
+            "print(os.environ.get('OMP_NUM_THREADS'), os.environ.get('OPENBLAS_NUM_THREADS'), os.environ.get('MKL_NUM_THREADS'))" % REPO)
+    base = {k: v for k, v in os.environ.items()
+            if k not in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "GNNRAG_HOST_THREADS")}
+
+    def run(extra):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(base, **extra), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stdout.strip().splitlines()[-1].split()
+
+    got = run({})
+    assert all(v.isdigit() and 1 <= int(v) <= 8 for v in got), got
+    assert run({"OMP_NUM_THREADS": "3"})[0] == "3"
+    assert run({"GNNRAG_HOST_THREADS": "0"}) == ["None", "None", "None"]
