@@ -32,6 +32,19 @@ import sys
 import time
 
 
+def _cpu_budget():
+    """os.cpu_count() capped by the cgroup-v2 CFS quota (no package import: the parent of a self-launch only sizes pools)."""
+    budget = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            budget = min(budget, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return budget
+
+
 def _limit_thread_pools_early():
     """Before numpy / torch are imported: the default size of every CPU thread pool of this process (OpenMP, OpenBLAS,
     MKL) follows the visible hardware threads (256 on the MI355X box), not the container's CPU quota (16 cores there).
@@ -41,15 +54,12 @@ def _limit_thread_pools_early():
     set; GNNRAG_HOST_THREADS=0 leaves everything as it is.  The CPU-baseline legs size their own teams later."""
     if os.environ.get("GNNRAG_HOST_THREADS") == "0":
         return
-    budget = os.cpu_count() or 1
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            quota, period = f.read().split()[:2]
-        if quota != "max":
-            budget = min(budget, max(1, int(quota) // int(period)))
-    except (OSError, ValueError):
-        pass
-    n = str(max(1, min(8, budget // 2)))
+    budget = _cpu_budget()
+    # the ranks of one node share the quota (same rule as gnnrag_amd.install.host_thread_limit, restated here because
+    # nothing of the package may be imported before the pools are sized)
+    lw = os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or "1"
+    local = int(lw) if lw.isdigit() and int(lw) > 0 else 1
+    n = str(max(1, min(8, budget // (2 * local))))
     for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
         os.environ.setdefault(k, n)
 
@@ -411,22 +421,17 @@ def main():
 
 def self_launch(n):
     """``python bench.py --gpus N`` without a launcher: run the same command line under ``torch.distributed.run``
-    (one rank per GPU, rendezvous on 127.0.0.1 at a free port).  stdout / stderr are the children's, the return code too."""
-    import socket
+    (one rank per GPU, ``--standalone``: the launcher's own c10d rendezvous on 127.0.0.1 picks a free port itself - no
+    bind / close / reuse race).  stdout / stderr are the children's, the return code too."""
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    import gnnrag_amd  # noqa: F401
-    from gnnrag_amd.install import host_cpu_budget
     # a rank drives one GPU and needs no OpenMP team: a few threads each, inside the container's CPU quota
-    per_rank = max(1, min(8, host_cpu_budget() // (2 * n)))
+    per_rank = max(1, min(8, _cpu_budget() // (2 * n)))
     for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         env[k] = str(min(per_rank, int(env[k])) if env.get(k, "").isdigit() else per_rank)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(n), os.path.abspath(__file__)] + sys.argv[1:]
     rc = subprocess.call(cmd, env=env)
     if rc != 0:
         raise SystemExit(rc)

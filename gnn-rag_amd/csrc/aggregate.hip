@@ -1083,9 +1083,6 @@ __global__ __launch_bounds__(1024) void k_hub_finish(const WalkArgs a) {
 // shares them with width-4 shuffles.  Node sets are handed out by an LDS ticket so a set with a
 // hub does not hold up its wave's other sets.  All slice workgroups of a question run on one
 // XCD (workgroup b -> XCD b % 8), so their partial-line writes to out[] merge in that L2.
-#ifndef GNNRAG_SLICE_BRANCHLESS
-#define GNNRAG_SLICE_BRANCHLESS 1   // LDS walk: the 4 facts of a step are multiplied without per-fact branches
-#endif
 #ifndef GNNRAG_SLICE_MERGED
 #define GNNRAG_SLICE_MERGED 1      // fused LDS walk over merged rows (both directions of a node in one loop)
 #endif
@@ -1233,7 +1230,6 @@ template <int MODE, int NI> struct SliceAcc {
 template <int MODE, int NI>
 __device__ __forceinline__ void slice_fma4(SliceAcc<MODE, NI>& acc, int2 pairs, const float* __restrict__ Td,
                                            const f32x4 (&q)[SliceAcc<MODE, NI>::n]) {
-#if GNNRAG_SLICE_BRANCHLESS
   if (__ballot(pairs.x != 0) == 0) return;               // (p >= 0: bits == 0 <=> p == 0)
   constexpr int NT = (MODE == MODE_REASON) ? 1 : NI;     // table float4s per fact
   // G facts' rows are in flight together (two 1024-thread workgroups per CU leave 64 VGPRs: the broadcasts are made
@@ -1268,25 +1264,6 @@ __device__ __forceinline__ void slice_fma4(SliceAcc<MODE, NI>& acc, int2 pairs, 
     group(std::integral_constant<int, 2>{});
     group(std::integral_constant<int, 3>{});
   }
-#else
-#define GNNRAG_SLICE_STEP(K)                                                                        \
-  {                                                                                                 \
-    const float pk = __int_as_float(quad_bcast<K>(pairs.x));                                        \
-    const int rk = quad_bcast<K>(pairs.y);                                                          \
-    if (pk != 0.f) {                                                                                \
-      const float* trow = Td + (size_t)rk * SliceAcc<MODE, NI>::width;                             \
-      if constexpr (MODE == MODE_REASON) {                                                          \
-        const f32x4 t = *reinterpret_cast<const f32x4*>(trow);                                      \
-        _Pragma("unroll") for (int i = 0; i < NI; ++i) acc.v[i] += pk * vrelu(t * q[i]);            \
-      } else {                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < NI; ++i)                                              \
-          acc.v[i] += pk * *reinterpret_cast<const f32x4*>(trow + kSliceW * i);                     \
-      }                                                                                             \
-    }                                                                                               \
-  }
-  GNNRAG_SLICE_STEP(0) GNNRAG_SLICE_STEP(1) GNNRAG_SLICE_STEP(2) GNNRAG_SLICE_STEP(3)
-#undef GNNRAG_SLICE_STEP
-#endif
 }
 
 // one direction of one row, walked by a whole wave: 64 facts per step (lane group k owns facts

@@ -149,7 +149,10 @@ __global__ __launch_bounds__(1024) void k_softmax_pairs(const float* __restrict_
   typedef int i32x2 __attribute__((ext_vector_type(2)));
   for (int64_t j = lo + threadIdx.x; j < hi; j += 1024) {
     const i32x2 e = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(em) + j);
-    float p = s_dist[e.x - (int)n0];       // a fact stays inside its question (validated by the structure build)
+    // a fact stays inside its question; a tuple that was never validated (gnnrag_csr_build_counts defers the check to
+    // gnnrag_csr_status) must still read a DEFINED value: a source outside the question contributes prior 0
+    const unsigned s = (unsigned)(e.x - (int)n0);
+    float p = s < (unsigned)N ? s_dist[s] : 0.f;
     if (w0) {
       const int f = from[j];
       p *= f < F ? w0[f] : w1[f - F];

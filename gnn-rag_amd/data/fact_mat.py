@@ -161,9 +161,13 @@ class BatchFacts:
     ``norm_rel``).  The reference's own modules cannot consume it (they build ``torch.LongTensor`` from numpy arrays):
     it is handed out only by ``patch_loader(..., device=...)``, i.e. next to ``install.swap``-ed modules."""
 
-    def __init__(self, hrt_device, sizes, parts, N, plans=None, make_hrt=None, checked=False):
+    def __init__(self, hrt_device, sizes, parts, N, plans=None, make_hrt=None, checked=False, checked_r1=None, owner=None):
         self._hrt, self._make_hrt = hrt_device, make_hrt
         self._sizes, self._parts, self._N = sizes, parts, N
+        # what the host range check of the cache covered: node ids < N, relation ids < checked_r1.  plan_for passes the
+        # relation counts on (no-wait build) only for a structure of exactly this N and at least this many table rows;
+        # `owner` (the cache) gets ONE deferred device-side validation (CsrPlan.status) on its first no-wait build
+        self.checked_n, self.checked_r1, self.owner = (N if checked else None), checked_r1, owner
         # (rel_total, rel_max) of the batch for ops.CsrPlan(rel_counts=): only when every question's ids were range-checked
         # on the host as it was cached (the build then skips its wait AND its read-back of the device-side validation)
         self.rel_counts = ((sum(p.nrel for p in parts), max([p.nrel for p in parts] or [0])) if checked and parts else None)
@@ -219,7 +223,8 @@ class BatchFacts:
         if lo:
             hrt[0] -= lo * self._N
             hrt[2] -= lo * self._N
-        return BatchFacts(hrt, self._sizes[lo:hi], self._parts[lo:hi], self._N, checked=self.rel_counts is not None)
+        return BatchFacts(hrt, self._sizes[lo:hi], self._parts[lo:hi], self._N, checked=self.rel_counts is not None,
+                          checked_r1=self.checked_r1, owner=self.owner)
 
 
 class ShardedFacts:
@@ -302,7 +307,7 @@ class DeviceFactCache(FactCache):
             hrt = _cat_blocks(blocks, sizes, N)
         else:
             hrt = torch.zeros((3, 0), dtype=torch.int32, device=self.device)
-        return BatchFacts(hrt, sizes, parts, N, checked=True)
+        return BatchFacts(hrt, sizes, parts, N, checked=True, checked_r1=int(self.loader.num_kb_relation) + 1, owner=self)
 
 
 class DeviceStructureCache(DeviceFactCache):

@@ -61,8 +61,29 @@ def host_cpu_budget(cgroup_root: str = "/sys/fs/cgroup") -> int:
     return n
 
 
+def host_thread_limit(budget: int | None = None, environ=None) -> int:
+    """Threads one GPU-driving process may use: ``min(8, budget // (2 * local ranks))``, at least 1, and never more than an
+    ``OMP_NUM_THREADS`` the launcher already set (``torch.distributed.run`` sets 1 when it starts more than one rank).
+    ``local ranks`` = ``LOCAL_WORLD_SIZE`` (else ``WORLD_SIZE``) of the environment: the ranks of one node share ONE CPU
+    quota, so eight ranks with eight spinning workers each would bring the throttling back on exactly the multi-GPU path."""
+    import os
+    env = os.environ if environ is None else environ
+    if budget is None:
+        budget = host_cpu_budget()
+
+    def _int(name):
+        v = str(env.get(name, "")).strip()
+        return int(v) if v.isdigit() and int(v) > 0 else None
+
+    local = _int("LOCAL_WORLD_SIZE") or _int("WORLD_SIZE") or 1
+    n = max(1, min(8, int(budget) // (2 * local)))
+    omp = _int("OMP_NUM_THREADS")
+    return min(n, omp) if omp else n
+
+
 def limit_host_threads(n: int | None = None) -> int:
-    """Intra-op CPU threads of the process that DRIVES the GPU: ``min(8, host_cpu_budget() // 2)`` unless given.
+    """Intra-op CPU threads of the process that DRIVES the GPU: ``host_thread_limit()`` unless given -
+    ``min(8, host_cpu_budget() // (2 * local ranks))``, capped by an explicit ``OMP_NUM_THREADS``.
     The GPU path leaves the host a few hundred small launches and a handful of [B, N] conversions per forward - nothing to
     parallelise - but torch starts one OpenMP worker per visible hardware thread, and the workers spin after every
     parallel region.  On the MI355X box (256 hardware threads visible, a 16-core CFS quota) that exhausts the quota: the
@@ -71,7 +92,7 @@ def limit_host_threads(n: int | None = None) -> int:
     host time, one 68-78 ms pause every few batches -> none, ``nr_throttled`` 17 -> 0.  Returns the thread count set."""
     import torch
     if n is None:
-        n = max(1, min(8, host_cpu_budget() // 2))
+        n = host_thread_limit()
     torch.set_num_threads(int(n))
     return int(n)
 

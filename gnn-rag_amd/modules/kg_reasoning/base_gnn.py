@@ -7,6 +7,8 @@ and builds a destination-sorted structure on the GPU (``ops.CsrPlan`` ->
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ... import ops
@@ -33,7 +35,21 @@ def plan_for(edge_list, B: int, N: int, R1: int, device) -> "ops.CsrPlan":
     elif hrt is not None:
         # a device fact cache knows every question's relation count: the build is told them and does not wait
         rc = getattr(edge_list, "rel_counts", None) if R1 > 0 else None
+        # ... but only for the shape the cache's host-side range check covered (a caller with another N, or fewer table
+        # rows than the largest relation id admits, gets the waiting build and its device-side validation instead of
+        # undersized relation tables)
+        cn, cr = getattr(edge_list, "checked_n", None), getattr(edge_list, "checked_r1", None)
+        if rc is not None and (cn != N or cr is None or R1 < cr):
+            rc = None
         plan = ops.CsrPlan(None, None, None, B, N, R1, hrt.device, hrt_device=hrt, rel_counts=rc)
+        owner = getattr(edge_list, "owner", None)
+        if rc is not None and (owner is None or not getattr(owner, "_status_checked", False)
+                               or os.environ.get("GNNRAG_CHECK_STRUCTURES") == "1"):
+            # the deferred device-side validation, ONCE per cache (= per loader split), or on every batch under
+            # GNNRAG_CHECK_STRUCTURES=1: the counts told to the build are compared with what the device counted
+            plan.status()
+            if owner is not None:
+                owner._status_checked = True
     else:
         plan = ops.CsrPlan(edge_list[0], edge_list[1], edge_list[2], B, N, R1, device)
     _last_plan.update(key=key, plan=plan, tuple=edge_list)

@@ -43,8 +43,10 @@ class HipLSTM(nn.LSTM):
                 return super().forward(input, hx)       # torch raises its own shape error
             h0, c0 = h0[0], c0[0]
         bias = self.bias
+        ws = self.__dict__.setdefault("_gnnrag_ws", {})       # the module's own scratch (not a parameter / buffer)
         out, h_n, c_n = ops.lstm_forward(input, self.weight_ih_l0, self.weight_hh_l0,
-                                         self.bias_ih_l0 if bias else None, self.bias_hh_l0 if bias else None, h0, c0)
+                                         self.bias_ih_l0 if bias else None, self.bias_hh_l0 if bias else None, h0, c0,
+                                         workspaces=ws)
         return out, (h_n.unsqueeze(0), c_n.unsqueeze(0))
 
     @classmethod

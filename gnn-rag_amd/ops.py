@@ -989,12 +989,11 @@ class LayerStack:
             pass
 
 
-_lstm_ws = {}
-
-
-def lstm_forward(x, w_ih, w_hh, b_ih=None, b_hh=None, h0=None, c0=None):
+def lstm_forward(x, w_ih, w_hh, b_ih=None, b_hh=None, h0=None, c0=None, workspaces=None):
     """One-layer batch_first LSTM, torch.nn.LSTM semantics (lstm_encoder.py:27-36): x [B,T,E], w_ih [4H,E], w_hh [4H,H],
-    biases [4H] or None, h0 / c0 [B,H] or None (zeros).  Returns (out [B,T,H], h_n [B,H], c_n [B,H])."""
+    biases [4H] or None, h0 / c0 [B,H] or None (zeros).  Returns (out [B,T,H], h_n [B,H], c_n [B,H]).
+    ``workspaces``: a dict OWNED BY THE CALLER (``HipLSTM`` keeps one per module) in which the transposed-weight scratch
+    is kept between calls, keyed by (device, stream); None = a fresh scratch for this call."""
     lib = _lib.load()
     x = _chk(x, "x")
     if x.dim() != 3:
@@ -1016,9 +1015,11 @@ def lstm_forward(x, w_ih, w_hh, b_ih=None, b_hh=None, h0=None, c0=None):
     # one workspace per (device, stream): two calls on different streams of one device must not share the transposed-weight
     # scratch (calls on one stream are ordered)
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
-    ws = _lstm_ws.get(key)
+    ws = workspaces.get(key) if workspaces is not None else None
     if ws is None or ws.numel() < need:
-        ws = _lstm_ws[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        if workspaces is not None:
+            workspaces[key] = ws
     with torch.cuda.device(dev):
         _lib.check(lib.gnnrag_lstm_forward(x.data_ptr(), w_ih.data_ptr(), w_hh.data_ptr(), _ptr(b_ih), _ptr(b_hh), _ptr(h0),
                                            _ptr(c0), out.data_ptr(), h_n.data_ptr(), c_n.data_ptr(), B, T, E, H,

@@ -257,14 +257,29 @@ def test_host_cpu_budget_follows_the_cgroup_quota(tmp_path):
 def test_limit_host_threads_sets_a_small_team():
     import torch
     import gnnrag_amd  # noqa: F401
-    from gnnrag_amd.install import host_cpu_budget, limit_host_threads
+    from gnnrag_amd.install import host_cpu_budget, host_thread_limit, limit_host_threads
     before = torch.get_num_threads()
     try:
         n = limit_host_threads()
-        assert n == torch.get_num_threads() == max(1, min(8, host_cpu_budget() // 2))
+        assert n == torch.get_num_threads() == host_thread_limit() <= max(1, min(8, host_cpu_budget() // 2))
         assert limit_host_threads(3) == torch.get_num_threads() == 3
     finally:
         torch.set_num_threads(before)
+
+
+def test_host_thread_limit_divides_the_quota_by_the_local_ranks():
+    """ADVICE round 5: the ranks of one node share ONE CPU quota - 8 ranks on a 16-core quota get 1 thread each, not 8;
+    an OMP_NUM_THREADS the launcher set (torch.distributed.run: 1) is never exceeded."""
+    import gnnrag_amd  # noqa: F401
+    from gnnrag_amd.install import host_thread_limit
+    assert host_thread_limit(16, {}) == 8
+    assert host_thread_limit(16, {"WORLD_SIZE": "8"}) == 1
+    assert host_thread_limit(16, {"WORLD_SIZE": "8", "LOCAL_WORLD_SIZE": "2"}) == 4
+    assert host_thread_limit(64, {"LOCAL_WORLD_SIZE": "8"}) == 4
+    assert host_thread_limit(64, {"LOCAL_WORLD_SIZE": "8", "OMP_NUM_THREADS": "1"}) == 1
+    assert host_thread_limit(64, {"OMP_NUM_THREADS": "12"}) == 8
+    assert host_thread_limit(1, {"WORLD_SIZE": "8"}) == 1
+    assert host_thread_limit(16, {"WORLD_SIZE": "junk", "OMP_NUM_THREADS": ""}) == 8
 
 
 def test_bench_limits_the_thread_pools_before_importing_numpy_and_torch():
@@ -286,4 +301,6 @@ def test_bench_limits_the_thread_pools_before_importing_numpy_and_torch():
     got = run({})
     assert all(v.isdigit() and 1 <= int(v) <= 8 for v in got), got
     assert run({"OMP_NUM_THREADS": "3"})[0] == "3"
+    # eight local ranks share the quota: this container's 8 cores // (2 * 8) -> 1 thread per pool
+    assert run({"WORLD_SIZE": "8", "LOCAL_WORLD_SIZE": "8"}) == ["1", "1", "1"] or (os.cpu_count() or 1) >= 32
     assert run({"GNNRAG_HOST_THREADS": "0"}) == ["None", "None", "None"]

@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC picture of the self-block update alone, per kernel form (GNNRAG_UPDATE_X32 = 0: k_update_b3, 1 / 2: the 32x32x16 forms)
-# usage (GPU box): bash tools/r5/pmc_update.sh <tag> "<forms>"
+# usage (GPU box): bash tools/pmc_update.sh <tag> "<forms>"
 TAG=${1:-r5c}
 FORMS=${2:-"0 2"}
 R=$PWD

@@ -24,7 +24,7 @@ VARIANTS = {
     "no_halfstep": {"GNNRAG_SLICE_HALFSTEP": 0},
     "wide_always": {"GNNRAG_SLICE_WIDE_LDS_KB": 159},
     "sl_unmerged": {"GNNRAG_SLICE_MERGED": 0},
-    "sl_branchy": {"GNNRAG_SLICE_BRANCHLESS": 0}, "sl_g2": {"GNNRAG_SLICE_BL_GROUP": 2}, "sl_g4": {"GNNRAG_SLICE_BL_GROUP": 4},
+    "sl_g2": {"GNNRAG_SLICE_BL_GROUP": 2}, "sl_g4": {"GNNRAG_SLICE_BL_GROUP": 4},
     # LDS walk workgroup sizes (two workgroups per CU either way): 512 / 640 / 768 threads = 4 / 5 / 6 waves per SIMD
     "sl_t512_g1": {"GNNRAG_SLICE_THREADS": 512, "GNNRAG_SLICE_WPE": 4, "GNNRAG_SLICE_BL_GROUP": 1},
     "sl_t768": {"GNNRAG_SLICE_THREADS": 768, "GNNRAG_SLICE_WPE": 6},
