@@ -78,6 +78,48 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 (MI355X_MICROARCH.md); a bf16x3 ke
                                  # product, so its ceiling in fp32-equivalent flops is 2500 / 6 = 417 TFLOP/s
 
 
+PARITY_BAR = 1e-4           # north_star: answer-node scores within 1e-4 (fp32) of the reference CPU path
+
+
+def parity_in_run(gpu_results, ref, cfg):
+    """GPU results of the timed configuration against the reference's own ReasonGNNLayer (host cores, the cpu_baseline
+    leg's last pass) on the IDENTICAL batch: per math mode the largest |dist_gpu - dist_ref| over all L layers' answer
+    distributions and all B x N node slots, the final node state relative to its largest entry, and whether every
+    question's argmax (= its Hits@1 decision) is the same.  ``ok`` is False - and bench.py exits non-zero - above 1e-4
+    or when an argmax differs for a question whose two best reference scores are further apart than the bar."""
+    out = {"questions": int(cfg.B), "layers": int(cfg.L), "bar": PARITY_BAR, "ok": True,
+           "against": "the reference's own ReasonGNNLayer (oracle/_ref/gnn, torch CPU), same seeded batch, features and "
+                      "parameters as the timed steps"}
+    ref_dist = [np.asarray(d, dtype=np.float64) for d in ref["dist"]]
+    ref_h = np.asarray(ref["h"], dtype=np.float64)
+    hmax = float(np.abs(ref_h).max())
+    top2 = np.sort(ref_dist[-1], axis=1)[:, -2:]
+    gap = top2[:, 1] - top2[:, 0]
+    for name, g in gpu_results.items():
+        dd = [float(np.abs(np.asarray(a, dtype=np.float64) - b).max()) for a, b in zip(g["dist"], ref_dist)]
+        dh = float(np.abs(np.asarray(g["h"], dtype=np.float64) - ref_h).max()) / max(hmax, 1e-30)
+        am_g, am_r = np.asarray(g["dist"][-1]).argmax(1), ref_dist[-1].argmax(1)
+        diff = np.nonzero(am_g != am_r)[0]
+        # (a distribution over ~N candidates has entries of ~1/N: the error relative to the largest probability beside it)
+        dr = max(float(np.abs(np.asarray(a, dtype=np.float64) - b).max() / max(b.max(), 1e-30)) for a, b in zip(g["dist"], ref_dist))
+        o = {"max_abs_dist": max(dd), "max_abs_dist_per_layer": dd, "max_dist_err_rel_to_largest_prob": dr, "max_rel_h": dh,
+             "argmax_equal": bool(len(diff) == 0), "argmax_equal_questions": int(cfg.B - len(diff))}
+        if "timed_loop_last_step_bit_identical" in g:
+            o["timed_loop_last_step_bit_identical"] = g["timed_loop_last_step_bit_identical"]
+        if len(diff):
+            o["argmax_differs_only_at_reference_ties"] = bool((gap[diff] <= PARITY_BAR).all())
+        o["ok"] = bool(max(dd) <= PARITY_BAR and dh <= PARITY_BAR and (len(diff) == 0 or o["argmax_differs_only_at_reference_ties"])
+                       and g.get("timed_loop_last_step_bit_identical", True))
+        out[name] = o
+        out["ok"] = out["ok"] and o["ok"]
+    first = next(iter(gpu_results), None)
+    if first is not None:        # the headline figures: the timed configuration's
+        for k in ("max_abs_dist", "max_rel_h", "argmax_equal"):
+            out[k] = out[first][k]
+        out["math_of_headline"] = first
+    return out
+
+
 def bytes_agg(cfg, F_g: int) -> float:
     """Algorithmic HBM bytes of ONE aggregation layer call (pinned):
     two CSRs (row_ptr + src + rel, int32), dist read, agg write, T tables once, instructions."""
@@ -117,6 +159,9 @@ def main():
                          "workload's whole per-GPU batch up to 64 questions of C2 size (C2: all 64), 4 for the larger shapes")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the end-to-end block (unmodified main.py --is_eval on the staged dataset, GPU and CPU)")
+    ap.add_argument("--other-workloads", default="C3,C4,C5",
+                    help="comma-separated workloads timed in short legs of their own after the main run (default bench at "
+                         "--workload C2 on one GPU only; '' = none): the other BASELINE shapes in the driver-run line")
     ap.add_argument("--clock-ramp-ms", type=float, default=600.0,
                     help="keep the chip busy with HBM copy kernels for this long before the warm-up steps (clock ramp of an "
                          "idle chip); 0 = off")
@@ -309,6 +354,25 @@ def main():
                                       "at_the_slowest_device_step": float(hs[worst])},
                   "slowest_step_index": worst}
 
+    # parity in the run itself ("same inputs both sides ... in the same run"): the results of the
+    # TIMED configuration - every layer's distribution and the final node state of one more step on the same batch, which
+    # must reproduce the timed loop's last result bit for bit - are kept and compared further down with the reference's
+    # own ReasonGNNLayer run on the identical batch by the cpu_baseline leg
+    gpu_results = {}
+    want_parity = rank == 0 and world == 1 and graph is None and not args.no_cpu_baseline
+
+    def record_results(lay):
+        with torch.no_grad():
+            lay.local_entity_emb = devin.h0
+            if lay._stack is not None:
+                lay._stack.new_forward()
+            d, rec = stack.run_layers(lay, cfg, devin, record=True)
+        return {"dist": rec["dist"], "h": rec["h"][-1], "last": d}
+
+    if want_parity:
+        gpu_results[math_name] = record_results(layer)
+        gpu_results[math_name]["timed_loop_last_step_bit_identical"] = bool(torch.equal(gpu_results[math_name].pop("last"), last))
+
     # the same step in EXACT fp32 (v_mfma_f32_16x16x4_f32 everywhere; the default 'mixed' mode runs the two large
     # products as bf16x3): a second, shorter timed loop on a layer object bound to that math mode
     ms_per_step_fp32 = None
@@ -328,6 +392,9 @@ def main():
                     stack.run_layers(layer32, cfg, devin)
                 torch.cuda.synchronize()
                 ms_per_step_fp32 = (time.perf_counter() - t32) * 1e3 / args.fp32_steps
+            if want_parity:
+                gpu_results["fp32"] = record_results(layer32)
+                gpu_results["fp32"].pop("last")
             del layer32
         finally:
             ops.set_dense_math(old_math)
@@ -402,12 +469,26 @@ def main():
             sample_b = args.cpu_sample_b
             if sample_b is None:     # ~0.8 M facts per pass is ~10 s on the host cores: C2's whole batch, 4 questions of C5
                 sample_b = max(1, min(cfg.B, int(64 * 12000 // max(F_g, 1)), 64))
-            out["cpu_baseline"] = cpu_baseline_leg(cfg, min(sample_b, cfg.B))
+            keep = {} if (want_parity and min(sample_b, cfg.B) == cfg.B and cfg.T == 1) else None
+            out["cpu_baseline"] = cpu_baseline_leg(cfg, min(sample_b, cfg.B), keep)
+            if keep:
+                out["parity_in_run"] = parity_in_run(gpu_results, keep, cfg)
+            elif want_parity:
+                out["parity_in_run"] = {"skipped": "the CPU leg ran a %d-question sample, not the whole %d-question batch "
+                                                   "(--cpu-sample-b %d compares all of them)" % (min(sample_b, cfg.B), cfg.B, cfg.B)}
+        if args.workload == "C2" and world == 1 and not distributed and args.other_workloads and graph is None:
+            torch.cuda.empty_cache()                      # the legs run in processes of their own
+            out["other_workloads"] = other_workloads_leg([w for w in args.other_workloads.split(",") if w], args.math)
         if not args.no_e2e and not args.no_cpu_baseline and world == 1:
             try:
                 out["e2e"] = e2e_leg()
             except Exception as e:               # the staged reference is test infrastructure: never fail the bench on it
                 out["e2e"] = {"error": repr(e)[:400]}
+        if not args.no_e2e and not args.no_cpu_baseline and world == 1 and args.workload == "C2":
+            try:
+                out["train_step"] = train_step_leg()
+            except Exception as e:
+                out["train_step"] = {"error": repr(e)[:400]}
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
@@ -417,6 +498,13 @@ def main():
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
         print(json.dumps(out))
+        sys.stdout.flush()
+        par = out.get("parity_in_run") or {}
+        if par.get("ok") is False:
+            # a fast step whose results differ from the reference's is not a measurement: the line above says where
+            sys.stderr.write("bench.py: parity_in_run FAILED (bar %g): %s\n" % (PARITY_BAR, json.dumps(
+                {k: v for k, v in par.items() if k != "note"})))
+            raise SystemExit(3)
 
 
 def self_launch(n):
@@ -435,6 +523,47 @@ def self_launch(n):
     rc = subprocess.call(cmd, env=env)
     if rc != 0:
         raise SystemExit(rc)
+
+
+def other_workloads_leg(names, math):
+    """The other BASELINE shapes (C3: WebQSP-dev-shaped batch of 32, D = 50, 3 x 3 layer calls; C4: CWQ-shaped, 4 layers;
+    C5: the per-GPU share of the Freebase-scale config) in the driver-run line: each in a process of its own (a fresh HIP
+    runtime and allocator; C5 alone holds ~10 GB) running THIS file with --workload W - 20 timed steps after a 200 ms
+    clock ramp (the chip is warm from the main run) and 10 warm-up steps, the same roofline leg as the main run, no CPU
+    baseline, no spread loop, no structure timings.  What is kept of each line: ms_per_step, value, and the walk's
+    roofline (kernel, frac, avg launch, PMC traffic when profiles/pmc_traffic_<W>.json matches the kernel sources)."""
+    import subprocess
+    out = {}
+    for w in names:
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", "20", "--warmup", "10",
+               "--no-cpu-baseline", "--no-e2e", "--spread-steps", "0", "--fp32-steps", "0", "--clock-ramp-ms", "200",
+               "--other-workloads", "", "--math", math]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, env=dict(os.environ, BENCH_SKIP_STRUCTURE_TIMING="1"), capture_output=True, text=True,
+                               timeout=600)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[w] = {"error": (r.stdout + r.stderr)[-400:]}
+                continue
+            d = json.loads(line[-1])
+        except Exception as e:                       # a side leg never fails the main line
+            out[w] = {"error": repr(e)[:300]}
+            continue
+        rf = d.get("roofline") or {}
+        out[w] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "steps": d["steps"],
+                  "layer_calls_per_step": d["config"]["L"] * synth_T(w), "config": d["config"]["workload"],
+                  "path": d.get("path"), "dense_math": d.get("dense_math"),
+                  "roofline": {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                      "avg_launch_ms", "algorithmic_bytes_per_launch", "real_traffic_frac",
+                                                      "frac_incl_tables", "traffic_source")},
+                  "kernel_ms": d.get("kernel_ms"), "process_wall_s": time.perf_counter() - t0}
+    return out
+
+
+def synth_T(name):
+    from gnnrag_amd import synth
+    return synth.CONFIGS[name].T
 
 
 def cached_structure_ms(batch, dev, ops):
@@ -673,9 +802,18 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
     relf, relf_inv = P["relfeat"], P["relfeat_inv"]
     box = {}
 
-    def t(fn):
+    stalls = {}
+
+    def t(fn, name=None):
         fn()                                                          # warm
-        return float(np.mean(_events_ms(fn, reps)))
+        ts = np.asarray(_events_ms(fn, reps))
+        # the event pair brackets the host's enqueue as well: a one-off host pause inside it (the HIP runtime's ~45 ms
+        # stall every few thousand launches, tools/c3_probe.sh) would pass for a 20 x slower kernel - repetitions above
+        # 3 x the median are left out of the average and counted
+        keep = ts[ts <= 3.0 * np.median(ts)]
+        if len(keep) < len(ts):
+            stalls[name or "launch_%d" % len(stalls)] = {"dropped": int(len(ts) - len(keep)), "largest_ms": float(ts.max())}
+        return float(keep.mean())
 
     ms = {}
     # relation projections of ALL L layers and both directions: one launch per step (rel_transform.hip)
@@ -705,7 +843,7 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
     else:
         ms["relation_tables"] = t(lambda: box.__setitem__("P", ops.relation_tables(plan, Tf, Ti, ins, e2e.weight)))
     P = box["P"]
-    ms["aggregate_fused_dense"] = t(lambda: box.__setitem__("nbr", ops.aggregate_fused(plan, dense, P)))
+    ms["aggregate_fused_dense"] = t(lambda: box.__setitem__("nbr", ops.aggregate_fused(plan, dense, P)), "aggregate_fused_dense")
     ms["aggregate_fused_seed"] = t(lambda: ops.aggregate_fused(plan, seed, P))
     # the seed-prior launch as the timed steps run it (layer 0 of every iteration): frontier of the prior, the table
     # rows and neighbour sums of the frontier only (csrc/frontier.hip)
@@ -778,7 +916,9 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
     # from inside the process); tools/refresh_profiles.sh stores them in profiles/pmc_traffic.json together with the
     # digest of the kernel sources they were measured on.  A figure measured on OTHER sources is not reported.
     pmc, pmc_note = {}, "profiles/pmc_traffic.json absent"
-    ppath = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    ppath = os.path.join(REPO, "profiles", "pmc_traffic_%s.json" % cfg.name)      # one file per workload, else the default
+    if not os.path.exists(ppath):
+        ppath = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(ppath):
         try:
             pmc = json.load(open(ppath))
@@ -852,6 +992,7 @@ def roofline_leg(cfg, layer, devin, ops, F_g, steps):
                                        b3=b3_mode and 193 <= Dk <= 208 and B * N >= 8192),
         },
         "kernel_ms": ms,
+        "kernel_ms_host_stalls_left_out": stalls or None,
     }
     # the self-block update streams h, nbr and h' (3 x BN x D x 4 B): it sits nearer its HBM roof than its MFMA roof -
     # both fractions are reported
@@ -946,19 +1087,63 @@ def e2e_leg():
                     "relation types for d50, 12 for d200)",
            "host_cores": ncpu}
     out["d200_batch16"] = {"gpu": run("d200", False, 16),
-                           # the same with the question encoder's nn.LSTM left to torch / MIOpen (GNNRAG_HIP_LSTM=0: MIOpen's
-                           # RNN call is ~12 ms at these shapes, twice per batch; default: gnnrag_lstm_forward)
-                           "gpu_miopen_lstm": run("d200", False, 16, extra_env={"GNNRAG_HIP_LSTM": "0"}),
                            "cpu_reference_sample32": run("d200", True, 16, True)}
     # BASELINE config 2's batch (64 questions per forward): the host's per-batch costs spread over four times the questions
     out["d200_batch64"] = {"gpu": run("d200", False, 64)}
     out["c1_d50_batch1"] = {"gpu": run("d50", False, 1),
-                            "gpu_miopen_lstm": run("d50", False, 1, extra_env={"GNNRAG_HIP_LSTM": "0"}),
                             "cpu_reference_sample32": run("d50", True, 1, True)}
     for k in ("d200_batch16", "c1_d50_batch1"):
         g, c = out[k]["gpu"], out[k]["cpu_reference_sample32"]
         if "questions_per_s" in g and "questions_per_s" in c:
             out[k]["gpu_over_cpu_questions_per_s"] = g["questions_per_s"] / c["questions_per_s"]
+    return out
+
+
+def train_step_leg():
+    """One training step as the reference's trainer runs it (Trainer_KBQA.train_epoch, train_model.py:209-233: get_batch,
+    zero_grad, model(batch, training=True), loss.backward(), clip_grad_norm_, Adam.step, loss.item()) on the staged
+    dataset at hidden size 200, batch 16 - the reference's own trainer, model code and optimiser in both legs
+    (tools/time_train_step.py): on the MI355X with this package's modules underneath (autograd form, HIP backward of the
+    typed-edge aggregation), and the pure reference on the host cores.  Two flag sets: the reference's defaults
+    (linear_dropout 0.2: the unfused autograd form, as dropout acts between aggregation and e2e_linear) and all dropouts
+    off (the fused training form; there both legs see the same numbers, so the first step's losses are comparable)."""
+    import subprocess
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import stage_ref
+    if not stage_ref.staged():
+        return {"skipped": "oracle/_ref not staged"}
+    cpu_threads = min(32, os.cpu_count() or 1, _cpu_budget())
+
+    def run(pure, extra, steps, warm):
+        cmd = [sys.executable, os.path.join(REPO, "tools", "time_train_step.py"), stage_ref.GNN, "--variant", "d200",
+               "--steps", str(steps), "--warm", str(warm)] + (["--pure"] if pure else []) + list(extra)
+        env = dict(os.environ)
+        if pure:
+            env.update(CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(cpu_threads), MKL_NUM_THREADS=str(cpu_threads))
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        line = [l for l in (r.stdout + r.stderr).splitlines() if l.startswith("GNNRAG_TRAIN ")]
+        if r.returncode != 0 or not line:
+            return {"error": (r.stdout + r.stderr)[-500:]}
+        return json.loads(line[-1][len("GNNRAG_TRAIN "):])
+
+    out = {"config": "staged synthetic dataset (oracle/stage_ref.py, 12 relation types, 1200 train questions, subgraphs padded to "
+                     "the split's largest), ReaRev --entity_dim 200 --num_iter 3 --num_ins 2 --num_gnn 3 --batch_size 16, Adam, "
+                     "gradient clip 1.0, from the staged checkpoint; median wall per step, seams synchronised",
+           "cpu_threads": cpu_threads}
+    for tag, extra in (("default_flags", []), ("dropout_off", ["--linear_dropout", "0", "--lm_dropout", "0"])):
+        g = run(False, extra, 20, 5)
+        c = run(True, extra, 5, 1)
+        o = {"gpu": g, "reference_cpu": c}
+        if "ms_per_step" in g and "ms_per_step" in c:
+            o["gpu_ms"], o["reference_cpu_ms"] = g["ms_per_step"], c["ms_per_step"]
+            o["reference_cpu_over_gpu"] = c["ms_per_step"] / g["ms_per_step"]
+            if tag == "dropout_off":
+                o["loss_first_step"] = {"gpu": g["losses"][0], "reference_cpu": c["losses"][0],
+                                        "abs_diff": abs(g["losses"][0] - c["losses"][0])}
+        out[tag] = o
+    d = out["default_flags"]
+    if "gpu_ms" in d:
+        out["gpu_ms"], out["reference_cpu_ms"] = d["gpu_ms"], d["reference_cpu_ms"]
     return out
 
 
@@ -971,7 +1156,7 @@ def _tail_stats(st, tail_ms_per_batch, batch):
             "evaluator_tail_at_8_per_question_ms": tail_ms_per_batch * min(1.0, 8.1 / max(per_q, 1e-9))}
 
 
-def reference_cpu_leg(cfg, sample_b):
+def reference_cpu_leg(cfg, sample_b, keep=None):
     """The REAL reference layer (`ReasonGNNLayer` from the sources staged into the git-ignored oracle/_ref/gnn by
     oracle/stage_ref.py - /root/reference itself does not exist on the GPU box) on the host cores, on a bounded sample:
     sample_b questions of the same shape, same parameters, eval mode, no_grad; `build_matrix` timed separately.
@@ -1006,9 +1191,15 @@ def reference_cpu_leg(cfg, sample_b):
             layer.init_reason(kb_adj_mat=batch.edge_tuple, **tens)       # build_matrix (base_gnn.py:19-51)
             t1 = time.perf_counter()
             dist = seed
+            dists = []
             for j in range(sub.L):
                 dist, _ = layer(dist, ins, step=j)
-            return t1 - t0, time.perf_counter() - t1
+                dists.append(dist)
+            t2 = time.perf_counter()
+            if keep is not None:                      # (after the clock is read) the pass's results, for parity_in_run
+                keep["dist"] = [d.numpy().copy() for d in dists]
+                keep["h"] = layer.local_entity_emb.numpy().copy()
+            return t1 - t0, t2 - t1
 
     from gnnrag_amd.install import host_cpu_budget
     ncpu = os.cpu_count() or 1
@@ -1035,13 +1226,13 @@ def reference_cpu_leg(cfg, sample_b):
             "seconds_per_pass": t, "build_matrix_seconds": float(np.median([r[0] for r in runs]))}
 
 
-def cpu_baseline_leg(cfg, sample_b):
+def cpu_baseline_leg(cfg, sample_b, keep=None):
     """The reference's CPU path on a bounded sample of the same workload: the REAL reference layer when its sources were
     staged (kind "reference"), with the torch-CPU restatement (oracle/rearev_torch_cpu.py, kind "port") timed beside it;
     only the port when they were not."""
     out = port_cpu_leg(cfg, sample_b)
     try:
-        ref = reference_cpu_leg(cfg, sample_b)
+        ref = reference_cpu_leg(cfg, sample_b, keep)
     except Exception as e:                       # the staged reference is test infrastructure: never fail the bench on it
         ref = None
         out["reference_error"] = repr(e)[:300]
