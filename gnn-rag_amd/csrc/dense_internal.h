@@ -10,6 +10,11 @@ namespace gnnrag {
 int tables_vq_launch_z(const gnnrag_csr* csr, const void* planes, const float* ins, const float* W, float* P, int32_t D,
                        int32_t I, int32_t only_dir, float* zero, int64_t zero_n, hipStream_t stream);
 
+// the same tables from k_tables_vq_lite (256 threads, 81.5 KB of LDS: fits a CU beside a workgroup of the LDS walk) - what the
+// stack driver's side stream launches; bit-identical to tables_vq_launch_z
+int tables_vq_lite_launch_z(const gnnrag_csr* csr, const void* planes, const float* ins, const float* W, float* P, int32_t D,
+                            int32_t I, int32_t only_dir, float* zero, int64_t zero_n, hipStream_t stream);
+
 int update_b3_launch_z(const float* h, const float* nbr, const float* W, const float* b, const float* w_s,
                        const float* b_s, const float* mask, float* h_out, float* score, int64_t BN, int32_t D,
                        int32_t ldw, hipStream_t stream, bool score_zeroed);

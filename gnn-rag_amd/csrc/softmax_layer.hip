@@ -2,6 +2,13 @@
 #include "gnnrag_common.h"
 #include "dense_internal.h"
 
+#include <map>
+#include <vector>
+
+#ifndef GNNRAG_OVERLAP_TABLES_DEFAULT
+#define GNNRAG_OVERLAP_TABLES_DEFAULT 0
+#endif
+
 namespace gnnrag {
 
 // dist[g,:] = softmax(score[g,:])  (reasongnn.py:169).  One 1024-thread workgroup per question.
@@ -224,6 +231,54 @@ static LayerWs layer_ws(const gnnrag_csr* csr, int32_t D, int32_t I) {
   return w;
 }
 
+// ---- the stack driver's side stream (relation tables of layers 1.. under the layers in front of them) ---------------
+// P of layer j >= 1 depends on the relation planes, the instructions and e2e_linear{j}.weight only - on nothing the
+// layers 0 .. j-1 compute.  With GNNRAG_OVERLAP_TABLES (default: see overlap_enabled) the whole-iteration call forks a
+// side stream behind its relation projections, runs the L - 1 table launches there into L - 1 table buffers of their
+// own, and the caller's stream waits for layer j's tables right before layer j's walk: the MFMA-bound table kernel runs
+// beside the issue-bound walk / the latency-bound frontier launches of the layers in front of it.  Same kernels'
+// arithmetic in the same order per output element: results are bit-identical to the serial sequence.
+// Stream and events are cached per host thread and device (an event shared by two host threads could hand one thread's
+// wait the other thread's record).
+struct OverlapRes {
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr;
+  std::vector<hipEvent_t> done;
+};
+
+static int overlap_res(int n_done, OverlapRes** out) {
+  static thread_local std::map<int, OverlapRes> per_device;
+  int dev = 0;
+  GNNRAG_HIP(hipGetDevice(&dev));
+  OverlapRes& r = per_device[dev];
+  if (!r.side) {
+    GNNRAG_HIP(hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking));
+    GNNRAG_HIP(hipEventCreateWithFlags(&r.fork, hipEventDisableTiming));
+  }
+  while ((int)r.done.size() < n_done) {
+    hipEvent_t e = nullptr;
+    GNNRAG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    r.done.push_back(e);
+  }
+  *out = &r;
+  return 0;
+}
+
+static bool overlap_enabled() {
+  const char* env = getenv("GNNRAG_OVERLAP_TABLES");      // read per call: tests compare both forms in one process
+  return env ? env[0] != '0' : GNNRAG_OVERLAP_TABLES_DEFAULT != 0;
+}
+
+// shapes for which the side-stream form exists: the V-form table kernel's (planes) and the LDS walk behind it
+static bool overlap_shape_ok(const gnnrag_csr* csr, int32_t L, int32_t D, int32_t I) {
+  return L > 1 && tables_vq_shape_ok(D, I) && csr->rel_total >= 1024 &&
+         gnnrag_aggregate_fused_variant(csr, D) != GNNRAG_WALK_L2_GATHER;
+}
+
+static size_t overlap_p_bytes(const gnnrag_csr* csr, int32_t D) {
+  return align_up((size_t)2 * (csr->rel_total > 0 ? csr->rel_total : 1) * D * sizeof(float), 256);
+}
+
 }  // namespace gnnrag
 
 using namespace gnnrag;
@@ -288,7 +343,10 @@ static int layer_body(const gnnrag_csr* csr, const LayerWs& w, char* base, const
                       const float* ins, const float* T_fwd, const float* T_inv, const void* planes, const float* W_e2e,
                       const float* b_e2e, const float* w_score, const float* b_score, const float* mask,
                       float* h_out, float* score_out, float* dist_out, int32_t D, int32_t I, int32_t path,
-                      int32_t math, gnnrag_stream_t stream, bool pairs_ready = false, bool* pairs_for_next = nullptr) {
+                      int32_t math, gnnrag_stream_t stream, bool pairs_ready = false, bool* pairs_for_next = nullptr,
+                      float* P_done = nullptr) {
+  // P_done != nullptr: this layer's relation tables were already computed into P_done (and its score buffer zeroed) by
+  // the stack driver's side stream, and the caller's stream has waited for them - the table launch is skipped
   // pairs_ready: the previous layer's softmax launch left this layer's (prior, relation) pairs in the workspace;
   // pairs_for_next != nullptr: the caller will run another layer on dist_out - *pairs_for_next reports whether this
   // layer's last launch wrote that layer's pairs
@@ -304,7 +362,7 @@ static int layer_body(const gnnrag_csr* csr, const LayerWs& w, char* base, const
   if (path == GNNRAG_PATH_AUTO)
     path = fused_is_cheaper(csr->B, csr->N, csr->rel_total, D, I) ? GNNRAG_PATH_FUSED : GNNRAG_PATH_UNFUSED;
   if (path == GNNRAG_PATH_FUSED) {
-    float* P = (float*)(base + w.P);
+    float* P = P_done ? P_done : (float*)(base + w.P);
     float* nbr = (float*)(base + w.nbr);
     const bool one_dir = only >= 0 && gnnrag_aggregate_fused_variant(csr, D) != GNNRAG_WALK_L2_GATHER;
     // the frontier kernels issue 16-byte loads / stores on ins, W, T, P (workspace) and the node rows: a misaligned view
@@ -332,9 +390,13 @@ static int layer_body(const gnnrag_csr* csr, const LayerWs& w, char* base, const
     }
     rc = GNNRAG_E_UNSUPPORTED;
     bool score_zeroed = false;    // the V-form table kernel also zeroes the score the update accumulates onto
-    if (planes && math != GNNRAG_MATH_FP32 && csr->rel_total > 0) {
-      rc = tables_vq_launch_z(csr, planes, ins, W_e2e, P, D, I, one_dir ? only : -1, score_out, BN,
-                              (hipStream_t)stream);
+    if (P_done) {
+      rc = 0;
+      score_zeroed = true;
+    } else if (planes && math != GNNRAG_MATH_FP32 && csr->rel_total > 0) {
+      const char* menv = getenv("GNNRAG_TABLES_LITE_MAIN");      // experiment knob: the side-stream kernel in the serial sequence
+      rc = ((menv && menv[0] == '1') ? tables_vq_lite_launch_z : tables_vq_launch_z)(
+          csr, planes, ins, W_e2e, P, D, I, one_dir ? only : -1, score_out, BN, (hipStream_t)stream);
       score_zeroed = rc == 0;
     }
     if (rc == GNNRAG_E_UNSUPPORTED) rc = gnnrag_relation_tables(csr, T_fwd, T_inv, ins, W_e2e, P, D, I, math, stream);
@@ -384,8 +446,11 @@ extern "C" size_t gnnrag_stack_workspace_bytes(const gnnrag_csr* csr, int32_t L,
   if (!csr || L <= 0 || D <= 0 || I <= 0) return 0;
   // one layer's workspace + the relation projections of all L layers (one contiguous block, computed up front)
   // + their bf16 planes where the V-form tables kernel applies
+  // + L - 1 relation-table buffers where the side-stream form applies (layer j's tables are computed while layer j - 1
+  // still reads its own)
   return layer_ws(csr, D, I).total + align_up((size_t)L * 2 * csr->R1 * D * sizeof(float), 256) +
-         align_up(tables_vq_shape_ok(D, I) ? (size_t)L * tables_vq_planes_bytes(csr->R1) : 0, 256);
+         align_up(tables_vq_shape_ok(D, I) ? (size_t)L * tables_vq_planes_bytes(csr->R1) : 0, 256) +
+         (overlap_shape_ok(csr, L, D, I) ? (size_t)(L - 1) * overlap_p_bytes(csr, D) : 0);
 }
 
 extern "C" int gnnrag_reason_layer(const gnnrag_csr* csr, const float* h, const float* dist, const float* ins,
@@ -461,6 +526,48 @@ extern "C" int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnra
                                    want_planes ? planes_all : nullptr, &planes_written, D, math, stream);
     if (rc) return rc;
   }
+  // side-stream tables (see OverlapRes): only in the full-workspace form with the planes in place, both directions
+  const bool overlap = upfront && want_planes && planes_written && fused && (path & ~0xf & ~GNNRAG_PATH_SEED_PRIOR) == 0 &&
+                       overlap_shape_ok(csr, L, D, I) && overlap_enabled() &&
+                       ((((uintptr_t)ins | (uintptr_t)planes_all) & 15) == 0);
+  OverlapRes* ov = nullptr;
+  char* P_extra = planes_all + align_up(tables_vq_shape_ok(D, I) ? (size_t)L * plane_bytes : 0, 256);
+  const size_t p_bytes = overlap_p_bytes(csr, D);
+  bool side_ok[64] = {false};
+  // gate (GNNRAG_OVERLAP_GATE, default on): layer j + 1's tables are not enqueued at the fork but right in front of layer
+  // j's walk, so that they run BESIDE that walk (complementary pipes) instead of competing with layer j - 1's update for CUs
+  const char* genv = getenv("GNNRAG_OVERLAP_GATE");
+  const bool gate = !(genv && genv[0] == '0');
+  const char* lenv = getenv("GNNRAG_TABLES_LITE");           // 0: the side stream launches k_tables_vq itself (A/B)
+  const bool lite = !(lenv && lenv[0] == '0');
+  auto side_tables = [&](int j) -> int {                     // layer j's tables on the side stream
+    if (j >= 64 || (((uintptr_t)layers[j].W_e2e) & 15) != 0) return 0;
+    const int rc = (lite ? tables_vq_lite_launch_z : tables_vq_launch_z)(
+        csr, planes_all + (size_t)j * plane_bytes, ins, layers[j].W_e2e, (float*)(P_extra + (size_t)(j - 1) * p_bytes), D, I, -1,
+        score_out + (size_t)j * BN, (int64_t)BN, ov->side);
+    if (rc == GNNRAG_E_UNSUPPORTED) return 0;
+    if (rc) return rc;
+    side_ok[j] = true;
+    GNNRAG_HIP(hipEventRecord(ov->done[j], ov->side));
+    return 0;
+  };
+  auto side_join_all = [&](int from) {       // whatever happened: a forked side stream is joined again (captures!)
+    if (!ov) return;
+    (void)hipEventRecord(ov->done[0], ov->side);
+    (void)hipStreamWaitEvent((hipStream_t)stream, ov->done[0], 0);
+    (void)from;
+  };
+  if (overlap && L <= 64) {
+    { const int rc = overlap_res(L, &ov); if (rc) return rc; }
+    GNNRAG_HIP(hipEventRecord(ov->fork, (hipStream_t)stream));
+    GNNRAG_HIP(hipStreamWaitEvent(ov->side, ov->fork, 0));
+    int rc_side = 0;
+    for (int j = 1; j < (gate ? 2 : L) && !rc_side; ++j) rc_side = side_tables(j);
+    if (rc_side) {
+      side_join_all(0);
+      return rc_side;
+    }
+  }
   const float* h = h0;
   const float* dist = dist0;
   bool pairs_ready = false;      // layer j - 1's softmax launch wrote layer j's (prior, relation) pairs
@@ -479,10 +586,28 @@ extern "C" int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnra
     if (!planes_written) planes = nullptr;
     // GNNRAG_PATH_SEED_PRIOR describes dist0, i.e. layer 0 only (every later layer starts from a softmax output)
     bool pairs_next = false;
+    float* P_done = nullptr;
+    if (ov && j < 64 && side_ok[j]) {
+      GNNRAG_HIP(hipStreamWaitEvent((hipStream_t)stream, ov->done[j], 0));     // joins the side stream up to layer j's tables
+      P_done = (float*)(P_extra + (size_t)(j - 1) * p_bytes);
+    }
+    if (ov && gate && j >= 1 && j + 1 < L) {
+      // layer j + 1's tables start where layer j's walk starts
+      GNNRAG_HIP(hipEventRecord(ov->fork, (hipStream_t)stream));
+      GNNRAG_HIP(hipStreamWaitEvent(ov->side, ov->fork, 0));
+      const int rc_side = side_tables(j + 1);
+      if (rc_side) {
+        side_join_all(j);
+        return rc_side;
+      }
+    }
     const int rc = layer_body(csr, w, base, h, dist, ins, T, T + RD, planes, p.W_e2e, p.b_e2e, w_score, b_score, mask, hj, sj,
                               dj, D, I, j == 0 ? path : (path & ~GNNRAG_PATH_SEED_PRIOR), math, stream, pairs_ready,
-                              j + 1 < L ? &pairs_next : nullptr);
-    if (rc) return rc;
+                              j + 1 < L ? &pairs_next : nullptr, P_done);
+    if (rc) {
+      side_join_all(j);       // join what is still outstanding on the side stream before reporting the error
+      return rc;
+    }
     pairs_ready = pairs_next;
     h = hj;
     dist = dj;

@@ -548,6 +548,227 @@ __global__ __launch_bounds__(512, 2) void k_tables_vq(VqArgs a) {
   }
 }
 
+// ---- k_tables_vq_lite: the V form for the stack driver's SIDE STREAM (round 6) ------------------------------------------
+// Same product, same six plane products per (column tile, k block) in the same order on the same operands - every
+// element of P gets the same fp32 sum as from k_tables_vq, bit for bit - but cut so that ONE of these workgroups fits
+// a CU BESIDE a workgroup of the LDS walk (k_walk_slice: 16 waves x 64 registers, ~80 KB of LDS at 602 relations) or
+// beside the small frontier / softmax launches, instead of owning the CU:
+//   * 256 threads = ONE wave per SIMD with a 256-register budget (the walk's four waves per SIMD hold the other 256);
+//   * column parts of 3 / 3 / 3 / 2 / 2 tiles: the V planes of one half of K for 48 columns are 3 x 48 x 416 B = 58.5 KB
+//     (61.5 KB with the instruction rows; the walk's 79.7 KB beside it leave room);
+//   * a wave owns up to 10 row tiles (38 tiles of a 602-relation question over 4 waves: one pass) - 10 x 3 x 4 = 120
+//     accumulator registers -, reads a k block's B fragments of all column tiles ONCE for its ten row tiles (36
+//     registers; no LDS read inside the MFMA stream) and keeps only TWO tiles' A fragments in flight (the current one and
+//     the next one's, requested a whole tile = 18 MFMAs ahead) instead of all tiles' (12 registers per tile).
+// The matrix pipe is then fed by one wave per SIMD whose stalls nothing of its own kernel hides - that is the point: the
+// co-resident walk's waves issue VALU / LDS / SALU work into exactly those slots, and the walk's own s_waitcnt idle
+// (64 % of its wave-cycles) is where the MFMAs run.
+constexpr int kVlThreads = 256;
+constexpr int kVlWaves = kVlThreads / 64;
+#ifndef GNNRAG_VL_TPW
+#define GNNRAG_VL_TPW 10
+#endif
+constexpr int kVlTPW = GNNRAG_VL_TPW;          // row tiles per wave and pass (even: the two fragment sets alternate)
+constexpr int kVlCT = 3;                       // column tiles of the widest column part = rows of an LDS plane / 16
+#ifndef GNNRAG_VL_NB
+#define GNNRAG_VL_NB 5
+#endif
+constexpr int kVlNB = GNNRAG_VL_NB;            // A-fragment sets in flight per wave (ring; kVlTPW is a multiple of it)
+static_assert(kVlTPW % kVlNB == 0, "the A-fragment ring keeps its phase from one k block to the next");
+
+__device__ __forceinline__ int vl_lds_row(int j, int ctn) { return ctn >= 4 ? tab_lds_row(j) : j; }   // (parts of < 4 tiles: plain order)
+
+template <int CTN, int UN>
+__device__ __forceinline__ void vl_stage(const VqArgs& a, unsigned char* lds, const float* qarea, int col0, int ncol,
+                                         int d, int s) {
+  constexpr int RB = kTabSlots * 16;
+  constexpr int PL = kVlCT * 16 * RB;
+  const int tid = threadIdx.x;
+  const int D = a.D, I = a.I, KC = D >> 2;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  constexpr int rows = CTN < kVlCT ? CTN * 16 + 1 : CTN * 16;    // + one zero row behind a part that does not fill the plane
+  const int total = rows * kTabSlots * 2;                        // 8-byte pieces (4 k) per plane
+  for (int base = 0; base < total; base += kVlThreads * UN) {
+    f32x4 v[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) v[u] = zero4;
+    for (int i = 0; i < I; ++i) {
+      f32x4 w[UN];
+      const float* wsrc = a.W + (size_t)col0 * a.ldw + (1 + 2 * i + d) * D;
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int idx = base + u * kVlThreads + tid;
+        const int j = idx / (kTabSlots * 2), kc = idx - j * (kTabSlots * 2);
+        w[u] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)min(j, ncol - 1) * a.ldw + 4 * min(kc, KC - 1));
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int idx = base + u * kVlThreads + tid;
+        const int kc = idx % (kTabSlots * 2);
+        f32x4 q = *reinterpret_cast<const f32x4*>(qarea + i * D + 4 * min(kc, KC - 1));
+        q = __builtin_elementwise_max(s ? -q : q, zero4);
+        v[u] += w[u] * q;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int idx = base + u * kVlThreads + tid;
+      const int j = idx / (kTabSlots * 2), kc = idx - j * (kTabSlots * 2);
+      if (idx < total) {
+        const Split3 sp = split3(j < ncol && kc < KC ? v[u] : zero4);
+        unsigned char* dst = lds + vl_lds_row(j, CTN) * RB + kc * 8;
+        *reinterpret_cast<uint2*>(dst) = sp.hi;
+        *reinterpret_cast<uint2*>(dst + PL) = sp.mid;
+        *reinterpret_cast<uint2*>(dst + 2 * PL) = sp.lo;
+      }
+    }
+  }
+}
+
+template <int CTN>
+__device__ __forceinline__ void tables_vl_part(const VqArgs& a, unsigned char* lds, int col0) {
+  constexpr int RB = kTabSlots * 16;
+  constexpr int PL = kVlCT * 16 * RB;
+  constexpr int NKB = kTabNKB;
+  constexpr int TPW = kVlTPW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int d = a.dir0 + blockIdx.y;
+  const int g = blockIdx.x / a.nchunk, ch = blockIdx.x - g * a.nchunk;
+  const int D = a.D, I = a.I;
+  const int r0 = a.rel_off[g], r1 = a.rel_off[g + 1];
+  if (r1 <= r0) return;
+  const int ncol = min(CTN * 16, D - col0);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  float* P = a.P + (size_t)d * a.M * D;
+  const unsigned char* planes = a.planes + (size_t)d * 3 * a.R1 * kVqRowB;
+  const size_t plane_stride = (size_t)a.R1 * kVqRowB;
+
+  const int U = (r1 - r0 + 15) >> 4;
+  const int c0 = U * ch / a.nchunk, c1 = U * (ch + 1) / a.nchunk;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int w0 = c0 + (c1 - c0) * wv / kVlWaves, w1 = c0 + (c1 - c0) * (wv + 1) / kVlWaves;
+  const int npass = ((c1 - c0 + kVlWaves - 1) / kVlWaves + TPW - 1) / TPW;     // workgroup-uniform (the barriers below)
+
+  if (tid < 16) reinterpret_cast<unsigned*>(lds + 3 * PL)[tid] = 0u;   // slack behind the last plane stays finite
+  float* qarea = reinterpret_cast<float*>(lds + 3 * PL + 64);          // ins[g, :, :]
+  for (int x = tid * 4; x < I * D; x += kVlThreads * 4)
+    *reinterpret_cast<f32x4*>(qarea + x) = *reinterpret_cast<const f32x4*>(a.ins + (size_t)g * I * D + x);
+
+  for (int pass = 0; pass < npass; ++pass) {
+    const int tbase = w0 + pass * TPW;
+    const int ntile = max(0, min(TPW, w1 - tbase));           // wave-uniform
+    f32x4 acc[TPW][CTN];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+      for (int nt = 0; nt < CTN; ++nt) acc[j][nt] = zero4;
+    unsigned aoff[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      const int m = min(r0 + (tbase + (j < ntile ? j : 0)) * 16 + fr, r1 - 1);
+      aoff[j] = (unsigned)a.rows[m].y * (unsigned)kVqRowB + (unsigned)fg * 16u;
+    }
+    const unsigned char* const plane_base[3] = {planes, planes + plane_stride, planes + 2 * plane_stride};
+
+    for (int s = 0; s < 2; ++s) {
+      __syncthreads();
+      vl_stage<CTN, 3>(a, lds, qarea, col0, ncol, d, s);
+      __syncthreads();
+
+      // a ring of NB A-fragment sets: tile j computes from set j % NB while the set of the tile NB - 1 slots ahead (behind
+      // the last tile: the first tiles of the next k block) is requested - an L2 hit takes ~3 tiles' worth of MFMAs
+      constexpr int NB = kVlNB;
+      bf16x8 ap[NB][3];
+#pragma unroll
+      for (int j = 0; j < NB - 1; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          ap[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(plane_base[pl] + (aoff[j] + (unsigned)(s * (kVqHalf * 2)))));
+      for (int kb = 0; kb < NKB; ++kb) {
+        const int kbn = min(kb + 1, NKB - 1);
+        const unsigned char* wb = lds + fr * RB + kb * 64 + fg * 16;
+        constexpr int PA[6] = {1, 2, 0, 1, 0, 0};
+        constexpr int PB[6] = {1, 0, 2, 0, 1, 0};
+        // the k block's B fragments of ALL column tiles, once: every row tile of the wave multiplies against the same
+        // V columns, so the MFMA stream below runs without an LDS read inside it
+        bf16x8 bfr[CTN][3];
+#pragma unroll
+        for (int nt = 0; nt < CTN; ++nt)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            bfr[nt][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(wb + pl * PL + nt * 16 * RB));
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          {
+            constexpr int AH = NB - 1;
+            const unsigned nxt = j + AH < TPW ? aoff[j + AH < TPW ? j + AH : 0] + (unsigned)(s * (kVqHalf * 2) + kb * 64)
+                                              : aoff[j + AH < TPW ? 0 : j + AH - TPW] + (unsigned)(s * (kVqHalf * 2) + kbn * 64);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+              ap[(j + AH) % NB][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(plane_base[pl] + nxt));
+          }
+          if (j < ntile) {                                    // wave-uniform
+            // p outermost: CTN independent accumulators between two MFMAs on the same one
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+#pragma unroll
+              for (int nt = 0; nt < CTN; ++nt)
+                acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[j % NB][PA[p]], bfr[nt][PB[p]], acc[j][nt], 0, 0, 0);
+          }
+          // the scheduler may not move the later tiles' fragment loads up across this point (it would hold all ten tiles'
+          // fragments at once: 120 registers)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+
+    // ---- epilogue (C layout: rows 4 fg + q, column slot fr) ----
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      if (j < ntile) {
+        const int rbase = r0 + (tbase + j) * 16 + 4 * fg;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = rbase + q;
+          if (row < r1) {
+            float* prow = P + (size_t)row * D + col0;
+            if constexpr (CTN >= 4) {       // interleaved rows: a lane holds four consecutive columns
+              const f32x4 v = {acc[j][0][q], acc[j][1][q], acc[j][2][q], acc[j][3][q]};
+              const int c = 4 * fr;
+              if (c + 4 <= ncol) *reinterpret_cast<f32x4*>(prow + c) = v;
+              else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (c + e < ncol) prow[c + e] = v[e];
+              }
+            } else {
+#pragma unroll
+              for (int nt = 0; nt < CTN; ++nt) {
+                const int c = nt * 16 + fr;
+                if (c < ncol) prow[c] = acc[j][nt][q];
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kVlThreads, 2) void k_tables_vq_lite(VqArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  if (a.zero) {
+    const int64_t nb = (int64_t)gridDim.x * gridDim.y * gridDim.z;
+    const int64_t lin = blockIdx.x + (int64_t)gridDim.x * (blockIdx.y + (int64_t)gridDim.y * blockIdx.z);
+    for (int64_t i = lin * kVlThreads + threadIdx.x; i < a.zero_n; i += nb * kVlThreads) a.zero[i] = 0.f;
+  }
+  // 13 column tiles as parts of 3 / 3 / 3 / 2 / 2
+  const int h = blockIdx.z;
+  if (h < 3) tables_vl_part<3>(a, lds, h * 48);
+  else tables_vl_part<2>(a, lds, 144 + (h - 3) * 32);
+}
+
 // ---- the self-block update in bf16x3 on the same weight-plane layout -------------------------------------------------
 //   h'[m, :] = relu( h[m, :] . W_e2e[:, 0:D]^T + b + nbr[m, :] ),   score[m] = w_s . h'[m, :] + b_s + (1 - mask[m]) * -1e11
 // (reasongnn.py:161-168 with the neighbour blocks already reduced into nbr).  Workgroup = (row chunk, column part of
@@ -879,6 +1100,48 @@ int tables_vq_launch_z(const gnnrag_csr* csr, const void* planes, const float* i
     if (rc) return rc;
   }
   hipLaunchKernelGGL(k_tables_vq, dim3(csr->B * nchunk, ndir, 2), dim3(512), 160 * 1024, stream, a);
+  GNNRAG_LAUNCH_CHECK();
+  return 0;
+}
+
+// the side-stream form (k_tables_vq_lite): same results as tables_vq_launch_z, bit for bit
+int tables_vq_lite_launch_z(const gnnrag_csr* csr, const void* planes, const float* ins, const float* W, float* P, int32_t D,
+                            int32_t I, int32_t only_dir, float* zero, int64_t zero_n, hipStream_t stream) {
+  if (!tables_vq_shape_ok(D, I) || csr->rel_total < 1024 || only_dir > 1) return GNNRAG_E_UNSUPPORTED;
+  if ((((uintptr_t)planes | (uintptr_t)ins | (uintptr_t)W | (uintptr_t)P) & 15) != 0) return GNNRAG_E_UNSUPPORTED;
+  VqArgs a;
+  memset(&a, 0, sizeof(a));
+  a.planes = (const unsigned char*)planes; a.ins = ins; a.W = W; a.P = P;
+  a.rows = (const int2*)csr->rel_rows; a.rel_off = csr->rel_off;
+  a.M = csr->rel_total; a.D = D; a.I = I; a.ldw = (2 * I + 1) * D; a.R1 = csr->R1;
+  a.ct0 = kVlCT;
+  int cus = 0;
+  {
+    const int rc = device_cu_count(&cus);
+    if (rc) return rc;
+  }
+  const int ndir = only_dir < 0 ? 2 : 1;
+  a.dir0 = only_dir < 0 ? 0 : only_dir;
+  int nchunk = cus / (csr->B * 5 * ndir);
+  const int tiles_max = (csr->rel_max + 15) / 16;
+  if (nchunk > tiles_max / 8) nchunk = tiles_max / 8;
+  if (nchunk < 1) nchunk = 1;
+  a.nchunk = nchunk;
+  a.zero = zero;
+  a.zero_n = zero ? zero_n : 0;
+  static DeviceMask cap;
+  {
+    const int rc = raise_lds_cap(k_tables_vq_lite, cap);
+    if (rc) return rc;
+  }
+  size_t lds = (size_t)3 * kVlCT * 16 * kTabSlots * 16 + 64 + (size_t)I * D * sizeof(float);
+  // GNNRAG_VL_LDS_KB (experiment knob): a larger LDS request than the kernel needs limits how many of its workgroups share
+  // a CU (61.5 KB: two; above 80 KB: one - the other half of the CU stays free for a workgroup of the walk)
+  if (const char* e = getenv("GNNRAG_VL_LDS_KB")) {
+    const size_t want = (size_t)atoi(e) * 1024;
+    if (want > lds && want <= 160 * 1024) lds = want;
+  }
+  hipLaunchKernelGGL(k_tables_vq_lite, dim3(csr->B * nchunk, ndir, 5), dim3(kVlThreads), lds, stream, a);
   GNNRAG_LAUNCH_CHECK();
   return 0;
 }

@@ -51,6 +51,23 @@ VARIANTS = {
              "data": DATA12, "lr": "0.0005", "lr_by_epoch": [0.0005, 0.001, 0.002, 0.002, 0.0025]},
     "cwq": {"argv": ["--entity_dim", "50", "--kg_dim", "25", "--name", "cwq"], "train": "synth", "epochs": 0},
 }
+# round 6: the released hyper-parameters and a Freebase-sized relation vocabulary through main.py
+DATA6K = os.path.join(DST, "data", "synth6k") + "/"      # 6000 relation types, <= 300 per question (24 core types carry the signal)
+VARIANTS.update({
+    # ~6000 relation types: the per-question relation compaction (rel_off / rel_rows), relation tables of 6002 rows and the
+    # device structure cache run through main.py; the seed's path relations are the 24 core types, so the reference's
+    # trainer learns it like d50
+    "fb6k": {"argv": ["--entity_dim", "50", "--kg_dim", "25", "--name", "synth"], "train": "synth6k", "epochs": 8, "data": DATA6K},
+    # the released CWQ flags (gnn/scripts/rearev_cwq.sh:14): --num_iter 2 --num_ins 3 --num_gnn 3 --name cwq (argparse keeps
+    # the LAST occurrence of a flag, so these override COMMON_ARGV's)
+    "cwqflags": {"argv": ["--entity_dim", "50", "--kg_dim", "25", "--name", "cwq", "--num_iter", "2", "--num_ins", "3",
+                          "--num_gnn", "3"], "train": "synthcwq", "epochs": 8},
+    # --normalized_gnn true --pos_emb --norm_rel: the per-fact weights (weight_list / weight_rel_list) and the relation
+    # position embeddings through main.py (covered at layer level before)
+    "normpos": {"argv": ["--entity_dim", "50", "--kg_dim", "25", "--name", "synth", "--normalized_gnn", "true", "--pos_emb",
+                         "--norm_rel"], "train": "synthnp", "epochs": 8},
+})
+ROUND6_VARIANTS = ("fb6k", "cwqflags", "normpos")
 DATASET_VERSION = "r4-learnable-3"
 
 
@@ -91,8 +108,12 @@ def shim_reference_startup_bugs():
         base_encoder.BaseInstruction.__init__ = _init
 
 
-def _question(rng, n_ent, n_rel, words_of_rel, fillers, size_class):
-    """One question whose ANSWER IS DETERMINED BY A RELATION PATH FROM THE SEED: the question text names one relation
+def _question(rng, n_ent, n_rel, words_of_rel, fillers, size_class, core_rel=None, rel_subset=None):
+    """(core_rel / rel_subset, both None for the round-4 datasets, whose random stream they leave untouched: the path,
+    distractor and hub relations come from the first ``core_rel`` relation types only - the learnable signal stays a
+    24-way one - while the noise facts draw from a per-question subset of ``rel_subset`` types out of all ``n_rel``: a
+    Freebase-sized vocabulary of which a question touches a few hundred, like WebQSP's <= 300 of 6105.)
+    One question whose ANSWER IS DETERMINED BY A RELATION PATH FROM THE SEED: the question text names one relation
     (1 hop: the answers are the tails of the seed's facts of that relation) or two (2 hops: tails of the named second
     relation out of the tails of the first).  Around that: distractor relations out of the seed and out of the 1-hop
     nodes, uniform noise facts, and - for the "hub" size classes - a node that thousands of filler nodes point at with
@@ -108,6 +129,7 @@ def _question(rng, n_ent, n_rel, words_of_rel, fillers, size_class):
     rng.shuffle(rest)
     take = iter(rest)
     tuples = []
+    n_all, n_rel = n_rel, (core_rel or n_rel)          # below this line n_rel = the types the path relations come from
     k1 = int(rng.integers(3, 7))
     rels1 = [int(r) for r in rng.choice(n_rel, size=k1, replace=False)]
     hop1 = {}
@@ -135,7 +157,11 @@ def _question(rng, n_ent, n_rel, words_of_rel, fillers, size_class):
     n_noise = int(rng.integers(2 * n_sub, 4 * n_sub))
     h = others[(rng.zipf(1.6, size=n_noise) - 1) % len(others)]
     t = others[rng.integers(0, len(others), size=n_noise)]
-    r = rng.integers(0, n_rel, size=n_noise)
+    if rel_subset:
+        pool = rng.choice(n_all, size=min(rel_subset, n_all), replace=False)
+        r = pool[rng.integers(0, len(pool), size=n_noise)]
+    else:
+        r = rng.integers(0, n_rel, size=n_noise)
     tuples += [[int(a), int(b), int(c)] for a, b, c in zip(h, r, t)]
     if size_class == "hub":
         hub = int(others[int(rng.integers(0, len(others)))])
@@ -150,7 +176,7 @@ def _question(rng, n_ent, n_rel, words_of_rel, fillers, size_class):
             "subgraph": {"tuples": tuples, "entities": sub_ents}}
 
 
-def write_dataset(folder, seed=314, n_ent=20000, n_rel=24, n_train=1200, n_dev=160, n_test=520):
+def write_dataset(folder, seed=314, n_ent=20000, n_rel=24, n_train=1200, n_dev=160, n_test=520, core_rel=None, rel_subset=None):
     """A LEARNABLE synthetic KBQA dataset in the reference's on-disk format (dataset_load.py:45-55,228-238,565-575).
     train: small subgraphs only (the CPU trainer's cost); dev: small + medium; test: small + medium + 16 questions of
     1700-2000 entities with a hub row of more than 4096 facts (so the test split is padded to WebQSP's 2000 slots)."""
@@ -180,7 +206,7 @@ def write_dataset(folder, seed=314, n_ent=20000, n_rel=24, n_train=1200, n_dev=1
         nf = []
         with open(os.path.join(folder, split + ".json"), "w") as f:
             for qi, cls in enumerate(classes):
-                q = _question(rng, n_ent, n_rel, words_of_rel, fillers, cls)
+                q = _question(rng, n_ent, n_rel, words_of_rel, fillers, cls, core_rel, rel_subset)
                 q["id"] = "%s-%d" % (split, qi)
                 nf.append(len(q["subgraph"]["tuples"]))
                 f.write(json.dumps(q) + "\n")
@@ -291,13 +317,21 @@ def parse_metrics(log_text):
 def staged() -> bool:
     need = [os.path.join(GNN, "main.py"), os.path.join(DATA, "test.json"), os.path.join(DATA, "VERSION"),
             os.path.join(DATA12, "test.json"), os.path.join(sample_folder("d50"), "test.json"),
-            os.path.join(sample_folder("d200"), "test.json")]
+            os.path.join(sample_folder("d200"), "test.json"), os.path.join(DATA6K, "test.json")]
     for v in VARIANTS:
+        if v in ROUND6_VARIANTS:          # staged one by one (staged_variant): one that failed does not void the others
+            continue
         need += [os.path.join(CKPT, ckpt_name(v)), os.path.join(CKPT, "expected_%s_test.info" % v),
                  os.path.join(CKPT, "expected_%s.json" % v)]
     if not all(os.path.exists(p) for p in need):
         return False
     return open(os.path.join(DATA, "VERSION")).readline().strip() == DATASET_VERSION
+
+
+def staged_variant(v) -> bool:
+    return staged() and all(os.path.exists(p) for p in (
+        os.path.join(data_folder(v), "test.json"), os.path.join(CKPT, ckpt_name(v)),
+        os.path.join(CKPT, "expected_%s_test.info" % v), os.path.join(CKPT, "expected_%s.json" % v)))
 
 
 GOLDEN_CKPT = os.path.join(os.path.dirname(HERE), "tests", "golden", "ckpt")
@@ -340,8 +374,13 @@ def _train_in_subprocess(variant):
 
 
 def main(force=False):
-    if staged() and not force:
+    if staged() and all(staged_variant(v) for v in ROUND6_VARIANTS) and not force:
         print("oracle/_ref already staged")
+        return
+    if staged() and not force:            # only round-6 variants are missing: add them to the tree as it stands
+        if not os.path.exists(os.path.join(DATA6K, "test.json")):
+            write_dataset(DATA6K, seed=316, n_rel=6000, core_rel=24, rel_subset=276)
+        _stage_round6()
         return
     stage_sources()
     if os.path.isdir(CKPT):
@@ -349,17 +388,35 @@ def main(force=False):
     stats = write_dataset(DATA)
     print("stage_ref: dataset %s" % json.dumps(stats), flush=True)
     print("stage_ref: dataset (12 relations) %s" % json.dumps(write_dataset(DATA12, seed=315, n_rel=12)), flush=True)
-    for v in VARIANTS:
+    print("stage_ref: dataset (6000 relations, <= 300 per question) %s" % json.dumps(
+        write_dataset(DATA6K, seed=316, n_rel=6000, core_rel=24, rel_subset=276)), flush=True)
+    base = [v for v in VARIANTS if v not in ROUND6_VARIANTS]
+    for v in base:
         if VARIANTS[v]["epochs"]:
             _train_in_subprocess(v)
     summary = {}
-    for v in VARIANTS:
+    for v in base:
         summary[v] = expect(v)
         lines = open(os.path.join(CKPT, "expected_%s_test.info" % v)).read().splitlines()
         ncand = [len(json.loads(l)["cand"]) for l in lines]
         print("stage_ref[%s]: CPU reference metrics %s; candidates per test question: min %d max %d" %
               (v, summary[v], min(ncand), max(ncand)), flush=True)
+    summary.update(_stage_round6())
     print("oracle/_ref staged: " + json.dumps({v: m["test"] for v, m in summary.items()}))
+
+
+def _stage_round6():
+    """The round-6 variants, each on its own: a failure is reported and leaves the others (and the base variants) staged."""
+    out = {}
+    for v in ROUND6_VARIANTS:
+        try:
+            if VARIANTS[v]["epochs"]:
+                _train_in_subprocess(v)
+            out[v] = expect(v)
+            print("stage_ref[%s]: CPU reference metrics %s" % (v, out[v]), flush=True)
+        except SystemExit as e:
+            print("stage_ref[%s]: NOT staged: %s" % (v, str(e)[-800:]), flush=True)
+    return out
 
 
 def restage_variant(v):

@@ -79,7 +79,13 @@ def _run_main_py(tmp_path, variant, extra_env, tag):
 
 
 CASES = [("d50", "single"), ("d50", "force_dist"), ("d50", "structure_cache"), ("d200", "single"), ("d200", "structure_cache"),
-         ("cwq", "single")]
+         ("cwq", "single"),
+         # round 6: a 6000-type relation vocabulary (<= 300 per question: relation compaction, 6002-row tables), the released
+         # CWQ flags (--num_iter 2 --num_ins 3, gnn/scripts/rearev_cwq.sh:14), and --normalized_gnn true --pos_emb --norm_rel
+         ("fb6k", "single"), ("fb6k", "structure_cache"), ("cwqflags", "single"), ("normpos", "single")]
+# variants whose reference checkpoint need not answer a good part of the questions (a configuration the CPU trainer does
+# not learn within its budget still has to come out candidate for candidate like the reference's)
+NO_H1_GUARD = ()
 
 
 @pytest.mark.skipif(not STAGED, reason="oracle/_ref not staged (python oracle/stage_ref.py in the build container)")
@@ -89,10 +95,13 @@ def test_unmodified_main_py_eval_matches_cpu_reference(tmp_path, variant, mode):
     subgraphs up to 2000 entities, 16 test questions with a hub row of > 4096 facts), checkpoints trained by the
     reference's own trainer on CPU: d50 (released-checkpoint dims), d200 (the benchmark's hidden size), cwq (--name cwq:
     the seed keeps its candidate slot, dataset_load.py:249-257)."""
+    if not stage_ref.staged_variant(variant):
+        pytest.skip("variant %s not staged (python oracle/stage_ref.py)" % variant)
     want_metrics = json.load(open(os.path.join(CKPT, "expected_%s.json" % variant)))
     want = [json.loads(l) for l in open(os.path.join(CKPT, "expected_%s_test.info" % variant)).read().splitlines()]
     # the comparison is only worth something when the reference itself answers a good part of the questions
-    assert 0.3 <= want_metrics["test"][1] <= 0.9 and 0.3 <= want_metrics["eval"][1] <= 0.95, want_metrics
+    if variant not in NO_H1_GUARD:
+        assert 0.3 <= want_metrics["test"][1] <= 0.9 and 0.3 <= want_metrics["eval"][1] <= 0.95, want_metrics
     assert len(want) >= 500
     env = {"force_dist": {"GNNRAG_FORCE_DIST": "1"}, "structure_cache": {"GNNRAG_DEVICE_STRUCTURES": "1"}}.get(mode, {})
     metrics, got, log = _run_main_py(tmp_path, variant, env, "%s_%s" % (variant, mode))

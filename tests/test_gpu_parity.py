@@ -922,3 +922,57 @@ def test_whole_iteration_call_and_graph_replay_are_bit_identical(dev, cfgname):
                 assert np.array_equal(score[j].cpu().numpy(), outs["per_layer"]["score"][c])
                 c += 1
         st.release_graph()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfgname", ["mid", "C2"])
+def test_side_stream_tables_are_bit_identical(dev, cfgname, monkeypatch):
+    """Round 6: with GNNRAG_OVERLAP_TABLES=1 the whole-iteration call computes the relation tables of layers 1.. on a side
+    stream (forked behind the relation projections, joined right before each layer's walk) into table buffers of their
+    own; every layer's h / score / dist over T iterations equals the serial sequence bit for bit, eagerly and as a
+    replayed hipGraph (the fork and the joins are captured with it)."""
+    from gnnrag_amd import ops, stack, synth
+    if cfgname == "mid":
+        cfg = synth.GraphConfig(name="mid", B=4, N=2000, E=10000, R=600, D=200, I=2, L=3, T=3, seed=23)
+    else:
+        cfg = synth.GraphConfig(**{**synth.CONFIGS["C2"].__dict__, "T": 2})
+    batch = synth.make_batch(cfg)
+    feats = synth.make_features(cfg)
+    params = synth.make_layer_params(cfg)
+    devin = stack.DeviceInputs(batch, feats, dev)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GNNRAG_OVERLAP_TABLES", mode)
+        layer = stack.build_layer(cfg, batch, params, dev)
+        stack.init_reason(layer, batch, devin, devin.h0)
+        _, rec = stack.run_layers(layer, cfg, devin, record=True)
+        assert layer._stack is not None
+        outs[mode] = rec
+        _, rec2 = stack.run_layers(layer, cfg, devin, record=True)          # a second forward on the same stack object
+        outs[mode + "b"] = rec2
+    for k in ("h", "score", "dist"):
+        for a, b in zip(outs["0"][k], outs["1"][k]):
+            assert np.array_equal(a, b), k
+        for a, b in zip(outs["0b"][k], outs["1b"][k]):
+            assert np.array_equal(a, b), k
+    # the captured form: fork and joins inside the graph
+    monkeypatch.setenv("GNNRAG_OVERLAP_TABLES", "1")
+    layer = stack.build_layer(cfg, batch, params, dev)
+    stack.init_reason(layer, batch, devin, devin.h0)
+    with torch.no_grad():
+        P = layer._inference_params()
+        st = ops.LayerStack(layer.plan, P["relfeat"], P["relfeat_inv"], P["layers"], P["w_score"], P["b_score"],
+                            layer.local_entity_mask, cfg.I, path=layer._path_of(0))
+        st.run(devin.h0, devin.seed_dist, devin.ins[0])
+        ins_buf = devin.ins[0].clone()
+        st.capture(devin.h0, devin.seed_dist, ins_buf)
+        c = 0
+        for t in range(cfg.T):
+            ins_buf.copy_(devin.ins[t])
+            h, score, dist = st.replay(first=(t == 0))
+            for j in range(cfg.L):
+                assert np.array_equal(h[j].cpu().numpy(), outs["0"]["h"][c])
+                assert np.array_equal(dist[j].cpu().numpy(), outs["0"]["dist"][c])
+                assert np.array_equal(score[j].cpu().numpy(), outs["0"]["score"][c])
+                c += 1
+        st.release_graph()
