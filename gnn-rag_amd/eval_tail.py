@@ -92,10 +92,219 @@ class _CompactingModel:
         return loss, extras, pred_dist, tp_list
 
 
+# ---- the reference's tail in a process of its own ---------------------------------------------------------------------
+# Per batch an evaluation run does two things on the host: the forward side (``get_batch``, a few hundred launches
+# enqueued from Python, the candidate selection) and the reference's per-candidate tail (evaluate.py:188-226: ``tolist``,
+# the filter loop, ``f1_and_hits``, ``json.dumps``).  In ONE interpreter they add up, and a thread does not help: a
+# pure-Python tail gives the interpreter lock back once per switch interval while the launching thread asks for it a few
+# hundred times per forward.  ``start_tail_server`` forks a child that keeps the loaded splits and runs the reference's
+# OWN ``Evaluator.evaluate`` - unchanged - on stand-ins for ``get_batch`` / the model that hand out what the scoring
+# process ships (compacted candidates, probabilities, loss): metrics, ``.info`` records and prints come from there, and
+# a split costs max(forward side, tail side) per batch.
+# The fork must happen BEFORE the process touches the GPU (tools/run_reference.py: right behind ``load_data``): a fork
+# of a process with a live ROCm context leaves the PARENT with copy-on-write pages under every host-to-device copy
+# (measured: ``get_batch`` 2.6 -> 169 ms per batch, profiles/r06h_eval_tail_process.txt) - so a process that already
+# initialised the device is refused and evaluates in line.
+_ORIG_EVALUATE = None       # the reference's own Evaluator.evaluate (set by patch_evaluator_class / patch_evaluator)
+_SERVER = None
+
+
+def _to_cpu(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu()
+    if isinstance(x, (list, tuple)):
+        return type(x)(_to_cpu(v) for v in x)
+    return x
+
+
+def _send(f, obj):
+    import pickle
+    import struct
+    blob = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
+    f.write(struct.pack("<q", len(blob)))
+    f.write(blob)
+    f.flush()
+
+
+def _recv(f):
+    import pickle
+    import struct
+    head = f.read(8)
+    if len(head) < 8:
+        return None
+    return pickle.loads(f.read(struct.unpack("<q", head)[0]))
+
+
+class _ShippedModel(torch.nn.Module):
+    """What the tail's ``self.model`` is: an (empty) module - whatever wraps ``Evaluator.__init__`` may walk it - with the
+    attributes ``evaluate`` reads (``num_iter``) and a forward that hands out the shipped results of the batch
+    ``get_batch`` has just handed out."""
+
+    def __init__(self, num_iter, box):
+        super().__init__()
+        self.num_iter = num_iter
+        self.__dict__["_box"] = box
+
+    def forward(self, batch, *a, **kw):
+        item = self._box["item"]
+        return item["loss"], None, item["pred_dist"], item["tp_list"]
+
+
+def _tail_server_loop(dataset, src, dst):
+    """Child process: one ``evaluate`` command at a time."""
+    import traceback
+    torch.set_num_threads(1)                    # (a forked child must not wake a thread pool of its parent)
+    while True:
+        cmd = _recv(src)
+        if cmd is None:
+            return
+        try:
+            valid_data = dataset[cmd["split"]]
+            box = {}
+
+            def get_batch(iteration, batch_size, fact_dropout=0.0, q_type=None, test=False, _vd=valid_data, _box=box):
+                item = _box["item"] = _recv(src)
+                if item is None:
+                    raise EOFError("the scoring process went away")
+                ids = item["sample_ids"]
+                _vd.sample_ids = ids            # write_info -> get_quest reads it (dataset_load.py:603)
+                # what the tail reads of a batch (evaluate.py:169-186): candidates, seed flags, answer lists; the rest of
+                # the 8-tuple is not looked at behind the forward (answer_dist only becomes an unused tensor)
+                return (item["local_entity"], item["query_entities"], None, None, None, None,
+                        np.zeros((len(ids), 1), dtype=np.float32), _vd.answer_lists[ids])
+
+            from evaluate import Evaluator      # the reference's module (on sys.path of the process that forked)
+            args = dict(cmd["args"])
+            ev = Evaluator(args=args, model=_ShippedModel(cmd["num_iter"], box), entity2id=dataset["entity2id"],
+                           relation2id=dataset["relation2id"], device=torch.device("cpu"))
+            valid_data.get_batch = get_batch
+            try:
+                orig = _ORIG_EVALUATE or Evaluator.evaluate
+                out = orig(ev, valid_data, cmd["test_batch_size"], cmd["write_info"])
+            finally:
+                del valid_data.get_batch
+            import sys
+            sys.stdout.flush()
+            sys.stderr.flush()
+            _send(dst, ("ok", tuple(float(x) for x in out)))
+        except BaseException:
+            _send(dst, ("error", traceback.format_exc()))
+
+
+class _TailServer:
+    def __init__(self, pid, to_child, from_child, splits):
+        self.pid, self.to_child, self.from_child, self.splits = pid, to_child, from_child, splits
+
+    def split_of(self, loader):
+        for name, ld in self.splits.items():
+            if ld is loader:
+                return name
+        return None
+
+    def close(self):
+        try:
+            self.to_child.close()
+            self.from_child.close()
+            os.waitpid(self.pid, 0)
+        except Exception:
+            pass
+
+
+def start_tail_server(dataset: dict) -> bool:
+    """Forks the tail process (see above).  ``dataset``: what the reference's ``load_data`` returned (dataset_load.py:
+    631-672: the loaders under "train" / "valid" / "test", ``entity2id``, ``relation2id``).  Returns False - and
+    evaluation stays in line - with GNNRAG_EVAL_PIPELINE=0, without ``os.fork``, under a process group, or when this
+    process has already initialised the GPU."""
+    global _SERVER
+    import atexit
+    import sys
+    import torch.distributed as dist
+    if _SERVER is not None:
+        return True
+    if os.environ.get("GNNRAG_EVAL_PIPELINE", "1") == "0" or not hasattr(os, "fork"):
+        return False
+    if torch.cuda.is_initialized() or int(os.environ.get("WORLD_SIZE", "1")) > 1 or (dist.is_available() and dist.is_initialized()):
+        return False
+    splits = {k: dataset[k] for k in ("train", "valid", "test") if dataset.get(k) is not None}
+    down_r, down_w = os.pipe()
+    up_r, up_w = os.pipe()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    pid = os.fork()
+    if pid == 0:
+        code = 0
+        try:
+            os.close(down_w)
+            os.close(up_r)
+            _tail_server_loop(dataset, os.fdopen(down_r, "rb"), os.fdopen(up_w, "wb"))
+        except BaseException:
+            code = 1
+        finally:
+            os._exit(code)
+    os.close(down_r)
+    os.close(up_w)
+    _SERVER = _TailServer(pid, os.fdopen(down_w, "wb"), os.fdopen(up_r, "rb"), splits)
+    atexit.register(stop_tail_server)
+    return True
+
+
+def stop_tail_server() -> None:
+    global _SERVER
+    if _SERVER is not None:
+        _SERVER.close()
+        _SERVER = None
+
+
+def _evaluate_on_server(server, split, self, valid_data, test_batch_size, write_info):
+    """This process's half of an ``evaluate`` call: ``get_batch`` + forward + candidate selection in the reference's
+    batch order (evaluate.py:155-163), every batch's compacted candidates shipped to the tail process."""
+    import math
+    num_epoch = math.ceil(valid_data.num_data / test_batch_size)
+    sel = (len(self.id2entity), (1 - self.eps) / valid_data.max_local_entity, self.eps)
+    scalars = (str, int, float, bool, type(None))
+    _send(server.to_child, {"split": split, "test_batch_size": test_batch_size, "write_info": write_info,
+                            "num_iter": int(self.model.num_iter),
+                            "args": {k: v for k, v in self.args.items() if isinstance(v, scalars)}})
+    err = None
+    try:
+        self.model.eval()
+        valid_data.reset_batches(is_sequential=True)
+        for it in range(num_epoch):
+            batch = valid_data.get_batch(it, test_batch_size, fact_dropout=0.0, test=True)
+            with torch.no_grad():
+                loss, _, pred_dist, tp_list = self.model(batch[:-1])
+            local_entity, query_entities = batch[0], batch[1]
+            if pred_dist.shape[1] <= TOPP_MAX_N:
+                local_entity, query_entities, pred_dist = compact_batch(pred_dist, local_entity, query_entities, *sel)
+            _send(server.to_child, {"sample_ids": np.asarray(valid_data.sample_ids), "local_entity": local_entity,
+                                    "query_entities": query_entities, "pred_dist": _to_cpu(pred_dist),
+                                    "loss": _to_cpu(loss), "tp_list": _to_cpu(tp_list)})
+    except BrokenPipeError:
+        pass                                    # the tail process died: its message (or its silence) is reported below
+    except BaseException as e:
+        err = e
+    if err is not None:
+        stop_tail_server()                      # the child is waiting for batches that will not come
+        raise err
+    reply = _recv(server.from_child)
+    if reply is None:
+        stop_tail_server()
+        raise RuntimeError("gnnrag_amd.eval_tail: the evaluation tail process ended without a result")
+    kind, payload = reply
+    if kind != "ok":
+        raise RuntimeError("gnnrag_amd.eval_tail: the evaluation tail process failed:\n" + payload)
+    f1, h1, em = payload
+    return np.float64(f1), np.float64(h1), np.float64(em)
+
+
 def _delegating(orig_evaluate):
     def evaluate(self, valid_data, test_batch_size=20, write_info=False):
         """``Evaluator.evaluate`` (evaluate.py:147-240) itself, on device-compacted batches."""
         import torch.distributed as dist
+        if _SERVER is not None and getattr(self, "model_name", "") != "GraftNet" and os.environ.get("GNNRAG_EVAL_PIPELINE", "1") != "0":
+            split = _SERVER.split_of(valid_data)
+            if split is not None:
+                return _evaluate_on_server(_SERVER, split, self, valid_data, test_batch_size, write_info)
         state = {}
         get_batch, model = valid_data.get_batch, self.model
 
@@ -117,7 +326,9 @@ def _delegating(orig_evaluate):
 
 def patch_evaluator_class(evaluator_cls):
     """``Evaluator.evaluate`` of the reference's class -> the delegating form (tools/run_reference.py)."""
+    global _ORIG_EVALUATE
     if not getattr(evaluator_cls.evaluate, "_gnnrag_delegating", False):
+        _ORIG_EVALUATE = evaluator_cls.evaluate
         fn = _delegating(evaluator_cls.evaluate)
         fn._gnnrag_delegating = True
         evaluator_cls.evaluate = fn
@@ -126,5 +337,10 @@ def patch_evaluator_class(evaluator_cls):
 
 def patch_evaluator(evaluator):
     """Rebinds ``evaluator.evaluate`` (a reference ``Evaluator`` instance) to the delegating form."""
-    evaluator.evaluate = types.MethodType(_delegating(type(evaluator).evaluate), evaluator)
+    global _ORIG_EVALUATE
+    orig = type(evaluator).evaluate
+    if getattr(orig, "_gnnrag_delegating", False):          # the class is patched already
+        return evaluator
+    _ORIG_EVALUATE = orig
+    evaluator.evaluate = types.MethodType(_delegating(orig), evaluator)
     return evaluator

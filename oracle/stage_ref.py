@@ -67,7 +67,12 @@ VARIANTS.update({
     "normpos": {"argv": ["--entity_dim", "50", "--kg_dim", "25", "--name", "synth", "--normalized_gnn", "true", "--pos_emb",
                          "--norm_rel"], "train": "synthnp", "epochs": 8},
 })
-ROUND6_VARIANTS = ("fb6k", "cwqflags", "normpos")
+# the d200 checkpoint evaluated with --eps 0.3 (main.py's own flag, parsing.py:62): the top-p cut of f1_and_hits then
+# retrieves ~10 candidates per question (WebQSP's released model: 8.1) instead of ~115 at the default 0.95 - the Evaluator's
+# per-candidate Python tail at a realistic length
+VARIANTS["d200eps"] = {"argv": ["--entity_dim", "200", "--kg_dim", "100", "--name", "synth", "--eps", "0.3"], "train": "synth200",
+                       "epochs": 0, "data": DATA12}
+ROUND6_VARIANTS = ("fb6k", "cwqflags", "normpos", "d200eps")
 DATASET_VERSION = "r4-learnable-3"
 
 

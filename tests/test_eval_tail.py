@@ -83,8 +83,12 @@ def test_patched_evaluator_matches_reference(monkeypatch, tmp_path):
     monkeypatch.setattr(ops, "topp_candidates", fake_topp)
     outs = []
     # "huge": slots beyond the kernel's limit - the batch is left uncompacted and the reference's own loop walks it
-    for tag, patch in (("ref", False), ("fast", True), ("huge", True)):
-        monkeypatch.setattr(eval_tail, "TOPP_MAX_N", 0 if tag == "huge" else 1 << 24)
+    # "server" / "server_huge": the reference's tail in the forked tail process (eval_tail.start_tail_server), this process
+    # only scores; "fast" / "huge": everything in this process
+    for tag, patch in (("ref", False), ("fast", True), ("huge", True), ("server", True), ("server_huge", True)):
+        if tag == "server":
+            assert eval_tail.start_tail_server(dataset)
+        monkeypatch.setattr(eval_tail, "TOPP_MAX_N", 0 if tag.endswith("huge") else 1 << 24)
         ev_args = dict(args)
         ev_args["checkpoint_dir"] = str(tmp_path) + "/"
         ev_args["experiment_name"] = tag
@@ -94,8 +98,9 @@ def test_patched_evaluator_matches_reference(monkeypatch, tmp_path):
             eval_tail.patch_evaluator(ev)
         np.random.seed(5)
         outs.append(ev.evaluate(dataset["test"], 4, write_info=True))
-    assert tuple(outs[0]) == tuple(outs[1]) == tuple(outs[2])
-    for tag in ("fast", "huge"):
+    eval_tail.stop_tail_server()
+    assert all(tuple(o) == tuple(outs[0]) for o in outs[1:])
+    for tag in ("fast", "huge", "server", "server_huge"):
         assert filecmp.cmp(os.path.join(str(tmp_path), "ref_test.info"), os.path.join(str(tmp_path), tag + "_test.info"),
                            shallow=False)
     assert "get_batch" not in vars(dataset["test"])          # the loader's method is restored after every call

@@ -82,7 +82,9 @@ CASES = [("d50", "single"), ("d50", "force_dist"), ("d50", "structure_cache"), (
          ("cwq", "single"),
          # round 6: a 6000-type relation vocabulary (<= 300 per question: relation compaction, 6002-row tables), the released
          # CWQ flags (--num_iter 2 --num_ins 3, gnn/scripts/rearev_cwq.sh:14), and --normalized_gnn true --pos_emb --norm_rel
-         ("fb6k", "single"), ("fb6k", "structure_cache"), ("cwqflags", "single"), ("normpos", "single")]
+         ("fb6k", "single"), ("fb6k", "structure_cache"), ("cwqflags", "single"), ("normpos", "single"),
+         # --eps 0.3: ~10 retrieved candidates per question (the d200 checkpoint)
+         ("d200eps", "single")]
 # variants whose reference checkpoint need not answer a good part of the questions (a configuration the CPU trainer does
 # not learn within its budget still has to come out candidate for candidate like the reference's)
 NO_H1_GUARD = ()

@@ -111,6 +111,12 @@ def main():
 
         def load_data(*a, **kw):
             dataset = orig_load(*a, **kw)
+            # the reference's per-candidate evaluation tail in a process of its own (gnnrag_amd.eval_tail.start_tail_server):
+            # forked HERE - the splits are loaded, the GPU has not been touched yet (a fork behind a live ROCm context slows
+            # every host-to-device copy of the parent); GNNRAG_EVAL_PIPELINE=0 keeps the tail in this process
+            if is_eval and world == 1 and not force_dist and not os.environ.get("GNNRAG_NO_EVAL_PATCH"):
+                from gnnrag_amd import eval_tail as _et
+                _et.start_tail_server(dataset)
             for split in ("train", "valid", "test"):
                 if dataset.get(split) is not None:
                     # the per-question cache skips numpy RNG draws the reference makes (fact_mat.patch_loader):
