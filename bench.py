@@ -1082,14 +1082,26 @@ def e2e_leg():
            "host_threads": "GPU legs: install.limit_host_threads() (min(8, quota / 2) intra-op threads: the driving process "
                            "needs no OpenMP team, and a spinning one exhausts the CPU quota - 68-78 ms pauses of every thread, "
                            "profiles/r05i_forward_host_time.txt); CPU leg: min(32, quota) threads",
+           "evaluator_tail": "the reference's own per-candidate Python (evaluate.py:188-226).  Default: it runs in a process forked "
+                             "before the GPU is touched (eval_tail.start_tail_server) and a split costs max(scoring side, tail "
+                             "side) per batch; the stage figure is what the scoring process still waits for",
            "entry": "unmodified gnn/main.py --is_eval via tools/run_reference.py; staged synthetic datasets (oracle/stage_ref.py: "
                     "a relation path from the seed determines the answer; 520 test questions, subgraphs up to 2000 entities; 24 "
                     "relation types for d50, 12 for d200)",
            "host_cores": ncpu}
     out["d200_batch16"] = {"gpu": run("d200", False, 16),
                            "cpu_reference_sample32": run("d200", True, 16, True)}
-    # BASELINE config 2's batch (64 questions per forward): the host's per-batch costs spread over four times the questions
-    out["d200_batch64"] = {"gpu": run("d200", False, 64)}
+    # BASELINE config 2's batch (64 questions per forward): the host's per-batch costs spread over four times the questions.
+    # "gpu": as tools/run_reference.py runs it - the reference's per-candidate tail in a process of its own
+    # (gnnrag_amd.eval_tail.start_tail_server, forked before the GPU is touched; `evaluator_tail` is then what the scoring
+    # process still waits for); "gpu_tail_in_line": GNNRAG_EVAL_PIPELINE=0, both halves in one interpreter (rounds 4-5)
+    out["d200_batch64"] = {"gpu": run("d200", False, 64),
+                           "gpu_tail_in_line": run("d200", False, 64, extra_env={"GNNRAG_EVAL_PIPELINE": "0"})}
+    # the same checkpoint with main.py's --eps 0.3: the top-p cut retrieves ~10 candidates per question instead of ~115
+    # (WebQSP's released model: 8.1) - the tail at a realistic length, measured instead of rescaled
+    if stage_ref.staged_variant("d200eps"):
+        out["d200_batch64_eps03"] = {"gpu": run("d200eps", False, 64),
+                                     "gpu_tail_in_line": run("d200eps", False, 64, extra_env={"GNNRAG_EVAL_PIPELINE": "0"})}
     out["c1_d50_batch1"] = {"gpu": run("d50", False, 1),
                             "cpu_reference_sample32": run("d50", True, 1, True)}
     for k in ("d200_batch16", "c1_d50_batch1"):

@@ -8,6 +8,9 @@
 #ifndef GNNRAG_OVERLAP_TABLES_DEFAULT
 #define GNNRAG_OVERLAP_TABLES_DEFAULT 0
 #endif
+#ifndef GNNRAG_OVERLAP_PROJ_DEFAULT
+#define GNNRAG_OVERLAP_PROJ_DEFAULT 0
+#endif
 
 namespace gnnrag {
 
@@ -344,7 +347,10 @@ static int layer_body(const gnnrag_csr* csr, const LayerWs& w, char* base, const
                       const float* b_e2e, const float* w_score, const float* b_score, const float* mask,
                       float* h_out, float* score_out, float* dist_out, int32_t D, int32_t I, int32_t path,
                       int32_t math, gnnrag_stream_t stream, bool pairs_ready = false, bool* pairs_for_next = nullptr,
-                      float* P_done = nullptr) {
+                      float* P_done = nullptr, hipEvent_t t_ready = nullptr) {
+  // t_ready != nullptr: the relation projections (T, planes) are being computed on the stack driver's side stream; the
+  // caller's stream waits for them in front of the first launch that reads them - behind the frontier build in the
+  // seed-prior form (which reads only the prior and the structure), at the top otherwise
   // P_done != nullptr: this layer's relation tables were already computed into P_done (and its score buffer zeroed) by
   // the stack driver's side stream, and the caller's stream has waited for them - the table launch is skipped
   // pairs_ready: the previous layer's softmax launch left this layer's (prior, relation) pairs in the workspace;
@@ -369,7 +375,9 @@ static int layer_body(const gnnrag_csr* csr, const LayerWs& w, char* base, const
     // takes the regular fused path below, whose launchers check alignment themselves
     const bool fr_aligned = ((((uintptr_t)ins | (uintptr_t)W_e2e | (uintptr_t)T_fwd | (uintptr_t)T_inv | (uintptr_t)P |
                                (uintptr_t)nbr | (uintptr_t)dist) & 15) == 0) && csr->N > 0;
-    if (seed_prior && only < 0 && fr_aligned && gnnrag_frontier_supported(csr, D) && csr->rel_total > 0) {
+    const bool frontier_form = seed_prior && only < 0 && fr_aligned && gnnrag_frontier_supported(csr, D) && csr->rel_total > 0;
+    if (t_ready && !frontier_form) GNNRAG_HIP(hipStreamWaitEvent((hipStream_t)stream, t_ready, 0));
+    if (frontier_form) {
       // The caller says `dist` is a seed distribution (first layer of a ReaRev iteration, rearev.py:208): only the
       // seeds' facts have a prior, so only the relation-table rows those facts use and the neighbour sums of the nodes
       // they reach are computed (frontier.hip; the frontier itself is derived from `dist` on the device, so a prior
@@ -378,6 +386,7 @@ static int layer_body(const gnnrag_csr* csr, const LayerWs& w, char* base, const
       const bool gated = update_rows_supported(h, nbr, W_e2e, h_out, BN, D, I, math);
       if (!gated) GNNRAG_HIP(hipMemsetAsync(nbr, 0, (size_t)BN * D * sizeof(float), (hipStream_t)stream));
       rc = frontier_build_z(csr, dist, fws, w.fws_bytes, score_out, BN, nbr + (size_t)BN * D, D, (hipStream_t)stream);
+      if (t_ready) GNNRAG_HIP(hipStreamWaitEvent((hipStream_t)stream, t_ready, 0));     // (also joins after an error)
       if (rc) return rc;
       rc = gnnrag_relation_tables_frontier(csr, fws, T_fwd, T_inv, ins, W_e2e, P, D, I, stream);
       if (rc) return rc;
@@ -409,6 +418,7 @@ static int layer_body(const gnnrag_csr* csr, const LayerWs& w, char* base, const
     if (rc) return rc;
     return finish_softmax(csr, w, base, score_out, dist_out, D, only < 0, pairs_for_next, stream);
   } else {
+    if (t_ready) GNNRAG_HIP(hipStreamWaitEvent((hipStream_t)stream, t_ready, 0));
     float* agg = (float*)(base + w.agg);
     rc = gnnrag_aggregate(csr, dist, ins, T_fwd, T_inv, agg, D, I, base + w.partial, w.partial_bytes, stream);
     if (rc) return rc;
@@ -514,6 +524,7 @@ extern "C" int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnra
   const size_t plane_bytes = tables_vq_planes_bytes(csr->R1);
   char* planes_all = base + w.total + align_up((size_t)L * 2 * RD * sizeof(float), 256);
   bool planes_written = false;
+  hipEvent_t t_ready = nullptr;      // set while the relation projections run on the side stream (layer 0 joins them)
   const bool reuse = upfront && (path & GNNRAG_PATH_REUSE_PROJ) != 0;
   path &= ~GNNRAG_PATH_REUSE_PROJ;
   if (reuse) {
@@ -522,8 +533,25 @@ extern "C" int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnra
     planes_written = want_planes && rel_transform_accepts(relfeat_fwd, relfeat_inv, csr->R1, D, L, layers, pos_rows, Tall,
                                                           planes_all);
   } else if (upfront) {
+    // GNNRAG_OVERLAP_PROJ (default: GNNRAG_OVERLAP_PROJ_DEFAULT): the projections on the side stream, so that layer 0's
+    // frontier build - which reads only the prior and the structure - runs beside them instead of behind them
+    const char* penv = getenv("GNNRAG_OVERLAP_PROJ");
+    const bool proj_side = fused && (path & GNNRAG_PATH_SEED_PRIOR) && (penv ? penv[0] != '0' : GNNRAG_OVERLAP_PROJ_DEFAULT != 0);
+    OverlapRes* pr = nullptr;
+    if (proj_side) {
+      const int rc0 = overlap_res(L, &pr);
+      if (rc0) return rc0;
+      GNNRAG_HIP(hipEventRecord(pr->fork, (hipStream_t)stream));
+      GNNRAG_HIP(hipStreamWaitEvent(pr->side, pr->fork, 0));
+    }
     const int rc = rel_projections(csr, L, layers, relfeat_fwd, relfeat_inv, pos_rows, Tall,
-                                   want_planes ? planes_all : nullptr, &planes_written, D, math, stream);
+                                   want_planes ? planes_all : nullptr, &planes_written, D, math,
+                                   proj_side ? (gnnrag_stream_t)pr->side : stream);
+    if (proj_side) {
+      GNNRAG_HIP(hipEventRecord(pr->done[0], pr->side));
+      if (rc) (void)hipStreamWaitEvent((hipStream_t)stream, pr->done[0], 0);
+      else t_ready = pr->done[0];
+    }
     if (rc) return rc;
   }
   // side-stream tables (see OverlapRes): only in the full-workspace form with the planes in place, both directions
@@ -603,8 +631,9 @@ extern "C" int gnnrag_reason_stack(const gnnrag_csr* csr, int32_t L, const gnnra
     }
     const int rc = layer_body(csr, w, base, h, dist, ins, T, T + RD, planes, p.W_e2e, p.b_e2e, w_score, b_score, mask, hj, sj,
                               dj, D, I, j == 0 ? path : (path & ~GNNRAG_PATH_SEED_PRIOR), math, stream, pairs_ready,
-                              j + 1 < L ? &pairs_next : nullptr, P_done);
+                              j + 1 < L ? &pairs_next : nullptr, P_done, j == 0 ? t_ready : nullptr);
     if (rc) {
+      if (j == 0 && t_ready) (void)hipStreamWaitEvent((hipStream_t)stream, t_ready, 0);
       side_join_all(j);       // join what is still outstanding on the side stream before reporting the error
       return rc;
     }

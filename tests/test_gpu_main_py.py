@@ -87,7 +87,8 @@ CASES = [("d50", "single"), ("d50", "force_dist"), ("d50", "structure_cache"), (
          ("d200eps", "single")]
 # variants whose reference checkpoint need not answer a good part of the questions (a configuration the CPU trainer does
 # not learn within its budget still has to come out candidate for candidate like the reference's)
-NO_H1_GUARD = ()
+NO_H1_GUARD = ("fb6k", "cwqflags", "normpos")       # (8-22 epochs of the reference's CPU trainer leave all three on the
+                                                      # "uniform over the seed's neighbourhood" plateau: H@1 0.14-0.18)
 
 
 @pytest.mark.skipif(not STAGED, reason="oracle/_ref not staged (python oracle/stage_ref.py in the build container)")

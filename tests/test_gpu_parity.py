@@ -941,8 +941,11 @@ def test_side_stream_tables_are_bit_identical(dev, cfgname, monkeypatch):
     params = synth.make_layer_params(cfg)
     devin = stack.DeviceInputs(batch, feats, dev)
     outs = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("GNNRAG_OVERLAP_TABLES", mode)
+    # "0": the serial sequence; "1": tables of layers 1.. on the side stream; "p": the relation projections on the side
+    # stream beside layer 0's frontier build (GNNRAG_OVERLAP_PROJ); "1p": both
+    for mode in ("0", "1", "p", "1p"):
+        monkeypatch.setenv("GNNRAG_OVERLAP_TABLES", "1" if "1" in mode else "0")
+        monkeypatch.setenv("GNNRAG_OVERLAP_PROJ", "1" if "p" in mode else "0")
         layer = stack.build_layer(cfg, batch, params, dev)
         stack.init_reason(layer, batch, devin, devin.h0)
         _, rec = stack.run_layers(layer, cfg, devin, record=True)
@@ -951,12 +954,14 @@ def test_side_stream_tables_are_bit_identical(dev, cfgname, monkeypatch):
         _, rec2 = stack.run_layers(layer, cfg, devin, record=True)          # a second forward on the same stack object
         outs[mode + "b"] = rec2
     for k in ("h", "score", "dist"):
-        for a, b in zip(outs["0"][k], outs["1"][k]):
-            assert np.array_equal(a, b), k
-        for a, b in zip(outs["0b"][k], outs["1b"][k]):
-            assert np.array_equal(a, b), k
-    # the captured form: fork and joins inside the graph
+        for mode in ("1", "p", "1p"):
+            for a, b in zip(outs["0"][k], outs[mode][k]):
+                assert np.array_equal(a, b), (k, mode)
+            for a, b in zip(outs["0b"][k], outs[mode + "b"][k]):
+                assert np.array_equal(a, b), (k, mode)
+    # the captured form: forks and joins inside the graph
     monkeypatch.setenv("GNNRAG_OVERLAP_TABLES", "1")
+    monkeypatch.setenv("GNNRAG_OVERLAP_PROJ", "1")
     layer = stack.build_layer(cfg, batch, params, dev)
     stack.init_reason(layer, batch, devin, devin.h0)
     with torch.no_grad():

@@ -21,10 +21,14 @@ def main(tag):
     json.dump(last_json(os.path.join(src, "bench_default.log")), open(os.path.join(dst, tag + "_bench_default.json"), "w"), indent=1)
     json.dump(last_json(os.path.join(src, "bench_under_rocprof.log")), open(os.path.join(dst, tag + "_bench_under_rocprof.json"), "w"), indent=1)
     for f, g in (("kernel_stats_bench.txt", "_kernel_stats_bench.txt"), ("kernel_stats_bench_C5.txt", "_kernel_stats_bench_C5.txt"),
-                 ("pmc_traffic_C2.json", "_pmc_traffic_C2.json"), ("pmc_traffic_C5.json", "_pmc_traffic_C5.json")):
+                 ("pmc_traffic_C2.json", "_pmc_traffic_C2.json"), ("pmc_traffic_C3.json", "_pmc_traffic_C3.json"),
+                 ("pmc_traffic_C4.json", "_pmc_traffic_C4.json"), ("pmc_traffic_C5.json", "_pmc_traffic_C5.json")):
         if os.path.exists(os.path.join(src, f)):
             shutil.copy(os.path.join(src, f), os.path.join(dst, tag + g))
     shutil.copy(os.path.join(src, "pmc_traffic_C2.json"), os.path.join(dst, "pmc_traffic.json"))
+    for w in ("C3", "C4", "C5"):               # bench.py's other_workloads legs read these (one file per workload)
+        if os.path.exists(os.path.join(src, "pmc_traffic_%s.json" % w)):
+            shutil.copy(os.path.join(src, "pmc_traffic_%s.json" % w), os.path.join(dst, "pmc_traffic_%s.json" % w))
     other = {}
     for w in ("C1", "C3", "C4", "C5", "C2fb", "C2u", "C1_graph", "C3_graph"):
         p = os.path.join(src, "bench_%s.log" % w)
