@@ -1,2 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_gpu_main_py.py -m gpu -q -k "fb6k or cwqflags or normpos or d200eps" -s 2>&1 | grep -v "^$" | tail -40
+bash tools/refresh_profiles.sh r06j > gpurun_out/r06j_refresh.log 2>&1
+tail -30 gpurun_out/r06j_refresh.log
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r06j/gpu_tests.log 2>&1
+tail -3 gpurun_out/r06j/gpu_tests.log
