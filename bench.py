@@ -294,21 +294,36 @@ def main():
                 ops.linear(ga, gw)
             torch.cuda.synchronize()
         del src, dst, ga, gw
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-    last = drain() if distributed else last                  # the last step's all-gather is inside the timed region
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    # The interpreter's cyclic collector is off from the warm-up to the end of the timed region (collected right before,
+    # switched back on right after): a full collection over this process's heap - the synthetic batch, torch, numpy - is a
+    # 30-40 ms host pause, and in the many-launch workloads (C1 / C3: ~45 launches and a few hundred short-lived Python
+    # objects per step) one landed inside a 30-step timed region (1.48 / 1.69 ms per step in the loop against 0.34 / 0.48
+    # in the 200 single-step measurements behind it, profiles/r06j_other_workloads.json; a launch-count effect of the HIP
+    # runtime was ruled out: tools/probe/launch_stall_probe.py, 30 000 launches without a pause).  A serving process
+    # freezes its heap the same way (install.freeze_loaded_data); steps create no reference cycles that would need it.
+    import gc
+    gc_was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            last = step()
+        last = drain() if distributed else last                  # the last step's all-gather is inside the timed region
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    finally:
+        if gc_was:
+            gc.enable()
     if distributed:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -323,7 +338,6 @@ def main():
         pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(16)]
         ts, hs = [], []
         done = 0
-        import gc
         gc_was = gc.isenabled()
         gc.collect()
         gc.disable()             # a collection in the middle of a step is a host pause the GPU then waits out
@@ -457,6 +471,8 @@ def main():
         "dense_math": math_name,
         "pre_run": ("%.0f ms of HBM copy kernels and dummy matrix products before the warm-up steps (clock ramp of an idle chip; not steps, nothing of "
                     "the workload is computed or cached)" % args.clock_ramp_ms) if args.clock_ramp_ms > 0 else None,
+        "host_collector": "the interpreter's cyclic collector is off from the warm-up to the end of the timed region (a full "
+                          "collection is a 30-40 ms host pause; a serving process freezes its heap: install.freeze_loaded_data)",
         "ms_per_step_fp32": ms_per_step_fp32,      # the same step with every product in exact fp32 MFMA (rank 0, 20 steps)
         "step_ms_spread": spread,
         "launch": ("hipGraph replay of the captured L-layer sequence (+ one D2D copy of h0 per step)"
