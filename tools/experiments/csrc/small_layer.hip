@@ -552,3 +552,17 @@ int small_layer_launch(const gnnrag_csr* csr, const float* prev_score, const flo
 }
 
 }  // namespace gnnrag
+
+// ---- how it was wired in for the measurement (not in the library) ------------------------------------------------------
+// dense_internal.h:   bool small_layer_shape_ok(const gnnrag_csr*, int32_t L, int32_t D, int32_t I);
+//                     size_t small_tables_bytes(const gnnrag_csr*, int32_t D);
+//                     int small_tables_launch(...);  int small_layer_launch(...);          (signatures above)
+// build.py:           "small_layer.hip" in SOURCES
+// gnnrag_stack_workspace_bytes:  + (small_layer_shape_ok(csr, L, D, I) ? L * small_tables_bytes(csr, D) : 0)
+// gnnrag_reason_layer (behind rel_projections, when the path is not forced unfused / one-directional and the shape is ok):
+//     small_tables_launch(csr, 1, T_fwd, ins, {W_e2e}, {P}, D, I, stream);
+//     small_layer_launch(csr, nullptr, dist, nullptr, P, h, W_e2e, b_e2e, w_score, b_score, mask, h_out, score_out, D, I, stream);
+//     gnnrag_masked_softmax(score_out, dist_out, B, N, stream);
+// gnnrag_reason_stack (behind the up-front projections): small_tables_launch for all L layers into L table buffers behind
+//     the stack workspace, then per layer j  small_layer_launch(csr, j ? score_out[j - 1] : nullptr, j ? nullptr : dist0,
+//     j ? dist_out[j - 1] : nullptr, P[j], h[j - 1], ...), then gnnrag_masked_softmax of the last layer's scores.
