@@ -304,3 +304,44 @@ def test_bench_limits_the_thread_pools_before_importing_numpy_and_torch():
     # eight local ranks share the quota: this container's 8 cores // (2 * 8) -> 1 thread per pool
     assert run({"WORLD_SIZE": "8", "LOCAL_WORLD_SIZE": "8"}) == ["1", "1", "1"] or (os.cpu_count() or 1) >= 32
     assert run({"GNNRAG_HOST_THREADS": "0"}) == ["None", "None", "None"]
+
+
+def test_cache_rel_features_reuses_until_a_parameter_changes():
+    """install.cache_rel_features: ``ReaRev.get_rel_feature`` (rearev.py:91-111) re-encodes the whole relation vocabulary
+    on every forward; in evaluation (eval mode, no grad) the result is kept until a model parameter changes (storage or
+    version), training / grad-enabled calls always recompute."""
+    import torch
+    import gnnrag_amd  # noqa: F401
+    from gnnrag_amd.install import cache_rel_features
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.relation_embedding = torch.nn.Embedding(7, 4)
+            self.relation_linear = torch.nn.Linear(4, 3)
+            self.calls = 0
+
+        def get_rel_feature(self):
+            self.calls += 1
+            return self.relation_linear(self.relation_embedding.weight), self.relation_linear(self.relation_embedding.weight)
+
+    m = cache_rel_features(M()).eval()
+    assert cache_rel_features(m) is m                       # idempotent
+    with torch.no_grad():
+        a = m.get_rel_feature()
+        b = m.get_rel_feature()
+        assert m.calls == 1 and a[0] is b[0]
+        m.relation_linear.weight.add_(1.0)                   # in-place update: the version counter moves
+        c = m.get_rel_feature()
+        assert m.calls == 2 and not torch.equal(c[0], a[0])
+        m.load_state_dict({k: v.clone() * 0.5 for k, v in m.state_dict().items()})       # a checkpoint load
+        m.get_rel_feature()
+        assert m.calls == 3
+    m.get_rel_feature()                                      # grad enabled: never cached
+    m.get_rel_feature()
+    assert m.calls == 5
+    m.train()
+    with torch.no_grad():
+        m.get_rel_feature()
+        m.get_rel_feature()
+    assert m.calls == 7
