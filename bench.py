@@ -414,9 +414,10 @@ def main():
             ops.set_dense_math(old_math)
 
     # structure-build timings AFTER the timed loops: this leg allocates and frees hundreds of device blocks (one
-    # structure per question), and run before the timed region it left the HIP runtime with a one-off ~45 ms stall a few
-    # thousand launches later - inside the timed loop of the workloads with many launches per step (C3: 2.06 instead of
-    # 0.50 ms per step; tools/c3_probe.sh)
+    # structure per question) and thousands of Python objects; run before the timed region it was followed by a one-off
+    # ~45 ms pause inside the timed loop of the workloads with many launches per step (C3: 2.06 instead of 0.50 ms per step;
+    # tools/c3_probe.sh) - round 6 found such pauses to be full collections of the interpreter's cyclic collector, which is
+    # now off across the timed region (see above); the order is kept
     et = batch.edge_tuple
     t0 = time.perf_counter()
     for _ in range(3):
